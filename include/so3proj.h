@@ -1,0 +1,116 @@
+/* so3proj.h -- C ABI of libso3proj.so: batched 3x3 SVD -> SO(3) projection on AMD MI355X (gfx950).
+ *
+ * Drop-in boundary for the hot path of henrikgruner/PoseEstimation.  The reference has no FFI (it is
+ * pure Python bottoming out in ATen); each entry point below replaces one ATen op chain of the
+ * reference, cited as <file>:<lines> relative to the reference repository root.  A Python binding
+ * with the reference's own function names lives in poseestimation_amd/rotation_representation.py;
+ * the ctypes stub a maintainer would add to the reference is shown in INTEGRATION.md.
+ *
+ * Conventions (all entry points)
+ *   - Plain pointers and sizes only; no torch / HIP C++ types.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the legacy default stream).
+ *   - All pointers are DEVICE pointers owned by the caller.  The library never allocates or frees
+ *     device memory and keeps no pointer after the call returns.
+ *   - Enqueue-only: every call launches on `stream` and returns without synchronising; no hidden
+ *     hipMalloc / hipMemcpy / hipDeviceSynchronize, so calls are hipGraph-capturable.  The caller
+ *     selects the device (hipSetDevice) -- the library holds no global mutable state and is
+ *     re-entrant from several host threads and devices.
+ *   - Layout: row-major contiguous 3x3 blocks; (B,9) == (B,3,3); element (i,j) of matrix b at
+ *     offset 9*b + 3*i + j.  16-byte aligned base pointers take the vectorised path, any 4-byte
+ *     (2-byte for bf16) aligned pointer is accepted.
+ *   - Return value: 0 on success, otherwise a hipError_t value (or SO3_ERR_INVALID for a bad
+ *     argument); so3_last_error() gives a thread-local description.  Nothing throws.
+ *   - NaN/Inf in -> NaN out (the reference's CPU path raises from LAPACK instead; the reference's GPU
+ *     path returns NaN; documented divergence).
+ *   - B == 0 is a no-op that returns 0.
+ */
+#ifndef SO3PROJ_H_
+#define SO3PROJ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO3PROJ_VERSION 100          /* 0.1.0 */
+#define SO3_ERR_INVALID (-1)
+
+/* Library version (SO3PROJ_VERSION the library was built with). */
+int so3_version(void);
+
+/* Thread-local description of the last non-zero return on this thread ("" if none). */
+const char *so3_last_error(void);
+
+/* ---- K1: symmetric orthogonalization -------------------------------------------------------------
+ * R_b = U diag(1,1,det(U V^T)) V^T for M_b = U S V^T.
+ * Replaces rotation_representation.py:192-206 (view -> torch.svd -> transpose -> matmul -> det ->
+ * cat -> matmul; copies at 3D-Pose/main2.py:34-48, point_cloud/model_fetch.py:13-27, ...).
+ *   M    in   B*9 elements (f32, or bf16 bits for the _bf16 variant)
+ *   R    out  B*9 float32 (always float32: a bf16 rotation is not orthogonal to 1e-5)
+ *   flip out  optional (NULL to skip), B bytes: 1 where det(U V^T) < 0 (<=> det M < 0), else 0
+ */
+int so3_project_fwd_f32(const float *M, float *R, uint8_t *flip, int64_t B, void *stream);
+int so3_project_fwd_bf16(const void *M, float *R, uint8_t *flip, int64_t B, void *stream);
+
+/* ---- K2: backward of K1 ---------------------------------------------------------------------------
+ * dM_b = U' Bm V^T with the signed SVD M = U' diag(s') V^T (U', V in SO(3)), A = U'^T G V,
+ * Bm_ij = (A_ij - A_ji)/(s'_i + s'_j), Bm_ii = 0.  The SVD is recomputed from M (nothing else is
+ * saved by the forward).  Replaces autograd's svd_backward + the backward of the glue ops triggered
+ * at 3D-Pose/main.py:90, UPNA/main.py:63, Comparison/main.py:62.
+ * Denominators are clamped at 1e-12*s1 (the reference yields inf/NaN at s'_i + s'_j = 0).
+ *   M  in  B*9 (f32 / bf16),  G in B*9 float32 (dL/dR),  dM out B*9 (f32 / bf16)
+ */
+int so3_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B, void *stream);
+int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, void *stream);
+
+/* ---- K3: fused head forward + Frobenius loss + backward (config #4) ------------------------------
+ * loss = mean_b ||Rtrue_b - R_b||_F  (3D-Pose/loss.py:7-11; NOT squared),  dM = dloss/dM.
+ * Replaces the chain 3D-Pose/main.py:60 (head), :85 (loss), :90 (backward) in one launch.
+ *   M        in   B*9 (f32 / bf16)
+ *   Rtrue    in   B*9 float32
+ *   R        out  optional B*9 float32
+ *   dM       out  optional B*9 (f32 / bf16): d(mean loss)/dM, i.e. already divided by B
+ *   loss_sum out  1 double: sum_b ||Rtrue_b - R_b||_F (the caller divides by B).  Zeroed by the
+ *                 call itself (hipMemsetAsync on `stream`) before the kernel accumulates into it.
+ * A row whose difference is exactly zero contributes zero gradient (the reference gives NaN).
+ */
+int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum,
+                         int64_t B, void *stream);
+int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum,
+                          int64_t B, void *stream);
+
+/* ---- K4: geodesic angle error ----------------------------------------------------------------------
+ * theta_b = acos(clamp((tr(R1_b^T R2_b) - 1)/2, -1, 1)) evaluated in float64 on float32 data.
+ * Replaces rotation_representation.py:230-242 (angle_error; copies at Comparison/main.py:19-31,
+ * Iterative/utility.py:35-47, ...).
+ *   deg        out optional B doubles: angle in degrees (radians if `radians` != 0)
+ *   sum_count  out optional 2 doubles: (sum_b theta_b, B), accumulated on the device; zeroed by the
+ *                  call itself before the kernel runs.  This pair is what one RCCL all-reduce sums
+ *                  across GPUs.
+ *   range_flag out optional 1 int32: set to 1 if any cos is outside [-1.1, 1.1] -- the condition
+ *                  on which the reference raises ValueError (:237-239); zeroed by the call itself.
+ */
+int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count,
+                    int32_t *range_flag, int radians, int64_t B, void *stream);
+
+/* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
+ * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
+ * point_cloud/main.py:43-57). */
+int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream);
+
+/* ---- K5: fused Kabsch (config #3) ------------------------------------------------------------------
+ * H_b = sum_i q_bi p_bi^T (= bmm(Q^T, P)),  R_b = proj_SO(3)(H_b) = argmin_R sum_i |R p_bi - q_bi|^2.
+ * No centring: the reference's pairing rule q = R p has no translation (point_cloud/main.py:173-181).
+ * The reference has no closed-form solve (it learns R with PointNet++); the oracle is
+ * symmetric_orthogonalization(bmm(Q^T, P)).
+ *   P, Q in  B*N*3 float32, cloud-major then point-major (the (B,1024,3) tensors of
+ *            point_cloud/main.py:171);  R out B*9 float32;  H out optional B*9 float32.
+ */
+int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N,
+                   void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SO3PROJ_H_ */

@@ -1,0 +1,186 @@
+"""CPU oracle for the SVD -> SO(3) hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, on the CPU, what the reference computes on the path named by BASELINE.json.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the
+product (`poseestimation_amd/`) never does and fails loudly when its HIP library is missing.
+
+Two flavours of every function:
+
+* `*_np`   -- numpy, float64 LAPACK (`np.linalg.svd`).  The mathematical answer; used as the
+              "truth" that both the reference's fp32 path and the HIP kernels are measured against.
+* `*_torch`-- the reference's own ATen call sequence (torch.linalg.svd -> det -> scale last row
+              of Vh -> matmul) in the input dtype, on CPU tensors.  `torch.svd` (what the reference
+              literally calls) and `torch.linalg.svd` are bitwise identical on torch 2.10 (SURVEY
+              section 8c), so this is the "port" that `bench.py` times as `cpu_baseline`.
+
+Pinned (tests/test_oracle_golden.py) against golden vectors produced by importing the reference's
+own `rotation_representation.py` in the build container (tools/gen_golden.py, tests/golden/*.npz).
+
+Reference lines followed (all under /root/reference):
+  symmetric_orthogonalization          rotation_representation.py:192-206
+  compute_geodesic_distance_from_...   rotation_representation.py:209-227
+  angle_error                          rotation_representation.py:230-242
+  loss_frobenius                       3D-Pose/loss.py:7-11
+  rotation sampler (Kabsch pairs)      point_cloud/prepare.py:21-49, point_cloud/main.py:173-181
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:  # torch is only needed by the *_torch flavour
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+# --------------------------------------------------------------------------------------------
+# numpy / float64
+# --------------------------------------------------------------------------------------------
+def symmetric_orthogonalization_np(x, return_parts=False):
+    """R = U diag(1,1,det(U V^T)) V^T for every 3x3 block of x (rotation_representation.py:199-206).
+
+    float64 LAPACK regardless of the input dtype.  Returns (B,3,3) float64; with return_parts also
+    the singular values (B,3) and the flip sign d = det(U V^T) (B,).
+    """
+    m = np.asarray(x, dtype=np.float64).reshape(-1, 3, 3)          # :199  x.view(-1, 3, 3)
+    u, s, vt = np.linalg.svd(m)                                    # :200  torch.svd (v -> vt, :201)
+    d = np.linalg.det(u @ vt)                                      # :202
+    vt = vt.copy()
+    vt[:, 2, :] *= d[:, None]                                      # :204  last row of vt times det
+    r = u @ vt                                                     # :205
+    if return_parts:
+        return r, s, d
+    return r
+
+
+def flip_flag_np(x):
+    """det(U V^T) < 0  <=>  det(M) < 0, evaluated in float64 (rotation_representation.py:202)."""
+    m = np.asarray(x, dtype=np.float64).reshape(-1, 3, 3)
+    return np.linalg.det(m) < 0
+
+
+def angle_error_np(r1, r2, check=True):
+    """Geodesic angle in float64 degrees, tr(R1^T R2) (rotation_representation.py:230-242)."""
+    a = np.asarray(r1, dtype=np.float64).reshape(-1, 3, 3)
+    b = np.asarray(r2, dtype=np.float64).reshape(-1, 3, 3)
+    tr = np.einsum("bji,bji->b", a, b)                              # trace(R1^T R2)  :232-235
+    cos = (tr - 1.0) / 2.0                                          # :236
+    if check and (np.any(cos < -1.1) or np.any(cos > 1.1)):         # :237-239
+        raise ValueError("angle out of range, input probably not proper rotation matrices")
+    cos = np.clip(cos, -1.0, 1.0)                                   # :240
+    return np.arccos(cos) * (180.0 / np.pi)                         # :241-242
+
+
+def geodesic_np(m1, m2, dtype=np.float32):
+    """Radians, input dtype, tr(m1 m2^T), hard clamp (rotation_representation.py:209-227)."""
+    a = np.asarray(m1, dtype=dtype).reshape(-1, 3, 3)
+    b = np.asarray(m2, dtype=dtype).reshape(-1, 3, 3)
+    m = a @ b.transpose(0, 2, 1)                                    # :215
+    cos = (m[:, 0, 0] + m[:, 1, 1] + m[:, 2, 2] - dtype(1)) / dtype(2)   # :217
+    cos = np.minimum(cos, dtype(1))                                 # :218
+    cos = np.maximum(cos, dtype(-1))                                # :219
+    return np.arccos(cos)                                           # :222
+
+
+def loss_frobenius_np(r_pred, r_true):
+    """mean_b ||R_true - R_pred||_F, not squared (3D-Pose/loss.py:7-11)."""
+    d = np.asarray(r_true, np.float64).reshape(-1, 3, 3) - np.asarray(r_pred, np.float64).reshape(-1, 3, 3)
+    return np.sqrt((d * d).sum(axis=(1, 2))).mean()
+
+
+def projection_backward_np(x, g):
+    """dL/dM for R = proj(M), given G = dL/dR; closed form.
+
+    With the *signed* SVD M = U' diag(s') V^T, U',V in SO(3), s' = (s1, s2, d*s3):
+        A = U'^T G V,   B_ij = (A_ij - A_ji) / (s'_i + s'_j),  B_ii = 0,   dM = U' B V^T.
+    Checked against torch autograd through the reference function in tests/test_oracle_golden.py.
+    """
+    m = np.asarray(x, dtype=np.float64).reshape(-1, 3, 3)
+    g = np.asarray(g, dtype=np.float64).reshape(-1, 3, 3)
+    u, s, vt = np.linalg.svd(m)
+    d = np.linalg.det(u @ vt)
+    u = u.copy()
+    u[:, :, 2] *= d[:, None]            # U' = U diag(1,1,d)  (V kept as LAPACK returns it)
+    sp = s.copy()
+    sp[:, 2] *= d                       # s' so that M = U' diag(s') V^T exactly
+    v = vt.transpose(0, 2, 1)
+    a = u.transpose(0, 2, 1) @ g @ v
+    den = sp[:, :, None] + sp[:, None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b = (a - a.transpose(0, 2, 1)) / den
+    idx = np.arange(3)
+    b[:, idx, idx] = 0.0
+    return u @ b @ vt
+
+
+def frobenius_fwd_bwd_np(x, r_true):
+    """loss = mean_b ||R_true - proj(M_b)||_F and dloss/dM (3D-Pose/main.py:60,85,90 chain)."""
+    r = symmetric_orthogonalization_np(x)
+    t = np.asarray(r_true, np.float64).reshape(-1, 3, 3)
+    diff = r - t
+    nrm = np.sqrt((diff * diff).sum(axis=(1, 2)))
+    b = r.shape[0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g = diff / (nrm[:, None, None] * b)
+    return nrm.mean(), projection_backward_np(x, g), r
+
+
+def sample_rotations_axis_angle_np(rng, batch):
+    """The reference's pair generator (point_cloud/prepare.py:21-49), numpy/float64, CPU.
+
+    theta ~ U(-pi, pi), axis = normalised N(0,I); quaternion (cos theta, axis sin theta), i.e. the
+    rotation angle is 2*theta -- reproduced as written.
+    """
+    theta = rng.uniform(-1.0, 1.0, batch) * np.pi                   # :23
+    sin = np.sin(theta)                                             # :24
+    axis = rng.standard_normal((batch, 3))                          # :25
+    axis = axis / np.maximum(np.linalg.norm(axis, axis=1, keepdims=True), 1e-8)   # :26 / :12-18
+    qw = np.cos(theta)                                              # :27
+    qx, qy, qz = axis[:, 0] * sin, axis[:, 1] * sin, axis[:, 2] * sin   # :28-30
+    xx, yy, zz = qx * qx, qy * qy, qz * qz
+    xy, xz, yz = qx * qy, qx * qz, qy * qz
+    xw, yw, zw = qx * qw, qy * qw, qz * qw
+    row0 = np.stack((1 - 2 * yy - 2 * zz, 2 * xy - 2 * zw, 2 * xz + 2 * yw), 1)   # :43
+    row1 = np.stack((2 * xy + 2 * zw, 1 - 2 * xx - 2 * zz, 2 * yz - 2 * xw), 1)   # :44
+    row2 = np.stack((2 * xz - 2 * yw, 2 * yz + 2 * xw, 1 - 2 * xx - 2 * yy), 1)   # :45
+    return np.stack((row0, row1, row2), 1)                          # :47
+
+
+def cross_covariance_np(p, q):
+    """H_b = sum_i q_i p_i^T = bmm(Q^T, P), float64 (config #3)."""
+    p = np.asarray(p, np.float64)
+    q = np.asarray(q, np.float64)
+    return np.einsum("bia,bic->bac", q, p)
+
+
+def kabsch_np(p, q):
+    """argmin_R sum_i |R p_i - q_i|^2 over SO(3) = proj(H) (no centring, as the pairing rule
+    point_cloud/main.py:173-181 has no translation)."""
+    return symmetric_orthogonalization_np(cross_covariance_np(p, q))
+
+
+# --------------------------------------------------------------------------------------------
+# torch / input dtype: the reference's ATen call sequence ("port" timed as cpu_baseline)
+# --------------------------------------------------------------------------------------------
+def symmetric_orthogonalization_torch(x):
+    m = x.reshape(-1, 3, 3)
+    u, _, vh = torch.linalg.svd(m)                                  # == torch.svd + transpose(v)
+    det = torch.det(torch.matmul(u, vh)).view(-1, 1, 1)
+    vh = torch.cat((vh[:, :2, :], vh[:, -1:, :] * det), 1)
+    return torch.matmul(u, vh)
+
+
+def angle_error_torch(r1, r2):
+    off = torch.matmul(r1.transpose(1, 2).double(), r2.double())
+    cos = (off.diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+    if torch.any(cos < -1.1) or torch.any(cos > 1.1):
+        raise ValueError("angle out of range, input probably not proper rotation matrices")
+    return torch.acos(torch.clamp(cos, -1, 1)) * (180 / np.pi)
+
+
+def loss_frobenius_torch(r_pred, r_true):
+    return torch.linalg.matrix_norm(r_true - r_pred, ord="fro").mean()
+
+
+def kabsch_torch(p, q):
+    return symmetric_orthogonalization_torch(torch.bmm(q.transpose(1, 2), p))

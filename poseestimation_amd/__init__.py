@@ -1,0 +1,21 @@
+"""poseestimation_amd -- MI355X-native SVD -> SO(3) projection head (drop-in for the hot path of
+henrikgruner/PoseEstimation's rotation_representation.py).  See DESIGN.md / INTEGRATION.md."""
+from .rotation_representation import (  # noqa: F401
+    angle_error,
+    compute_geodesic_distance_from_two_matrices,
+    frobenius_head,
+    kabsch_rotation,
+    loss_frobenius,
+    symmetric_orthogonalization,
+    transform_output,
+)
+
+__all__ = [
+    "symmetric_orthogonalization",
+    "angle_error",
+    "compute_geodesic_distance_from_two_matrices",
+    "loss_frobenius",
+    "frobenius_head",
+    "kabsch_rotation",
+    "transform_output",
+]

@@ -1,0 +1,64 @@
+"""ctypes binding of libso3proj.so (the C ABI declared in include/so3proj.h).
+
+No CPU fallback: if the shared library is missing or a tensor is not on a HIP device the call
+raises.  The library is looked up in-tree only (next to this file), so the driver sees the native
+code that was actually loaded.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libso3proj.so")
+
+# name -> (restype, argtypes); must list every symbol include/so3proj.h declares.
+_P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int
+SYMBOLS = {
+    "so3_version": (_INT, []),
+    "so3_last_error": (ctypes.c_char_p, []),
+    "so3_project_fwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_project_fwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_project_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_project_bwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_frob_fwd_bwd_f32": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
+    "so3_frob_fwd_bwd_bf16": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
+    "so3_angle_error": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
+    "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_kabsch_f32": (_INT, [_P, _P, _P, _P, _I64, _I32, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class So3ProjError(RuntimeError):
+    """A C-ABI call returned non-zero."""
+
+
+def load():
+    """dlopen libso3proj.so and declare signatures.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: the HIP extension has not been built. "
+                    "Run `python -m poseestimation_amd.build` (needs hipcc; cross-compiles gfx950 "
+                    "without a GPU). There is no CPU fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().so3_last_error().decode("utf-8", "replace")
+        raise So3ProjError(f"{what} failed with code {code}: {msg}")

@@ -1,0 +1,45 @@
+"""Build libso3proj.so (hipcc, gfx950) in-tree.  `python -m poseestimation_amd.build [--force]`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libso3proj.so")
+SOURCES = ["so3proj.hip"]
+HEADERS = ["so3_device.h", os.path.join("..", "..", "include", "so3proj.h")]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm); libso3proj.so cannot be built")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU).  Returns the .so path."""
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,501 @@
+// so3proj.hip -- kernels and C ABI of libso3proj.so (gfx950 only).  See include/so3proj.h.
+//
+// Data movement common to K1-K4: one lane owns one 3x3 block, but a lane-per-row global access of
+// 36-byte records is 9 strided dword accesses.  Instead a 256-thread workgroup owns a contiguous
+// tile of 256 blocks (9216 B), moves it with coalesced 16-byte accesses (576 float4 per tile)
+// through LDS, and each lane picks its nine floats out of LDS at a 9-dword stride (odd stride ->
+// conflict-free for ds_read_b32 / ds_write_b32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/so3proj.h"
+#include "so3_device.h"
+
+namespace {
+
+using so3::SignedSvd;
+
+constexpr int kBlock = 256;                 // lanes (= 3x3 blocks) per workgroup tile
+constexpr int kTileFloats = kBlock * 9;     // 2304 floats = 9216 B
+constexpr int kTileVec4 = kTileFloats / 4;  // 576 float4
+
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, code == SO3_ERR_INVALID ? "invalid argument" : hipGetErrorString((hipError_t)code));
+    return code;
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail((int)e, what);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- tile movers ----------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const __bf16 h = static_cast<__bf16>(f);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
+// Global (f32) -> LDS tile.  `n` = valid blocks in this tile (<= 256).  VEC: 16-byte path allowed.
+template <bool VEC>
+__device__ __forceinline__ void tile_in_f32(const float *__restrict__ g, int n, float *tile) {
+    const int tid = threadIdx.x;
+    if (VEC && n == kBlock) {
+        const float4 *src = reinterpret_cast<const float4 *>(g);
+        float4 *dst = reinterpret_cast<float4 *>(tile);
+        const float4 a = src[tid], b = src[tid + kBlock];
+        float4 c;
+        if (tid < kTileVec4 - 2 * kBlock) c = src[tid + 2 * kBlock];
+        dst[tid] = a;
+        dst[tid + kBlock] = b;
+        if (tid < kTileVec4 - 2 * kBlock) dst[tid + 2 * kBlock] = c;
+    } else {
+        for (int i = tid; i < n * 9; i += kBlock) tile[i] = g[i];
+    }
+}
+
+template <bool VEC>
+__device__ __forceinline__ void tile_out_f32(float *__restrict__ g, int n, const float *tile) {
+    const int tid = threadIdx.x;
+    if (VEC && n == kBlock) {
+        float4 *dst = reinterpret_cast<float4 *>(g);
+        const float4 *src = reinterpret_cast<const float4 *>(tile);
+        dst[tid] = src[tid];
+        dst[tid + kBlock] = src[tid + kBlock];
+        if (tid < kTileVec4 - 2 * kBlock) dst[tid + 2 * kBlock] = src[tid + 2 * kBlock];
+    } else {
+        for (int i = tid; i < n * 9; i += kBlock) g[i] = tile[i];
+    }
+}
+
+// bf16 in global <-> f32 in the LDS tile (conversion on the way through).
+__device__ __forceinline__ void tile_in_bf16(const uint16_t *__restrict__ g, int n, float *tile) {
+    for (int i = threadIdx.x; i < n * 9; i += kBlock) tile[i] = bf16_to_f32(g[i]);
+}
+__device__ __forceinline__ void tile_out_bf16(uint16_t *__restrict__ g, int n, const float *tile) {
+    for (int i = threadIdx.x; i < n * 9; i += kBlock) g[i] = f32_to_bf16(tile[i]);
+}
+
+template <bool BF16, bool VEC>
+__device__ __forceinline__ void tile_in(const void *base, int64_t first, int n, float *tile) {
+    if (BF16) tile_in_bf16(static_cast<const uint16_t *>(base) + first * 9, n, tile);
+    else tile_in_f32<VEC>(static_cast<const float *>(base) + first * 9, n, tile);
+}
+template <bool BF16, bool VEC>
+__device__ __forceinline__ void tile_out(void *base, int64_t first, int n, const float *tile) {
+    if (BF16) tile_out_bf16(static_cast<uint16_t *>(base) + first * 9, n, tile);
+    else tile_out_f32<VEC>(static_cast<float *>(base) + first * 9, n, tile);
+}
+
+__device__ __forceinline__ void lane_get(const float *tile, bool active, float (&m)[9]) {
+    const float *p = tile + threadIdx.x * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = active ? p[i] : ((i & 3) == 0 ? 1.f : 0.f);   // idle lanes: identity
+}
+__device__ __forceinline__ void lane_put(float *tile, const float (&m)[9]) {
+    float *p = tile + threadIdx.x * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) p[i] = m[i];
+}
+
+// ---- K1 -------------------------------------------------------------------------------------------
+template <bool BF16, bool VEC, bool FLIP>
+__global__ __launch_bounds__(kBlock) void k_project_fwd(const void *__restrict__ M, float *__restrict__ R,
+                                                        uint8_t *__restrict__ flip, int64_t B) {
+    __shared__ __attribute__((aligned(16))) float tile[kTileFloats];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<BF16, VEC>(M, first, n, tile);
+    __syncthreads();
+    float m[9], r[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile, active, m);
+    const SignedSvd f = so3::signed_svd<false>(m);
+    so3::rotation_from(f, r);
+    if (FLIP && active) flip[first + threadIdx.x] = so3::det_negative(m) ? 1 : 0;
+    lane_put(tile, r);          // each lane overwrites only the nine words it alone has read
+    __syncthreads();
+    tile_out<false, VEC>(R, first, n, tile);
+}
+
+// ---- K2 -------------------------------------------------------------------------------------------
+template <bool BF16, bool VEC>
+__global__ __launch_bounds__(kBlock) void k_project_bwd(const void *__restrict__ M, const float *__restrict__ G,
+                                                        void *__restrict__ dM, int64_t B) {
+    __shared__ __attribute__((aligned(16))) float tile_m[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile_g[kTileFloats];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<BF16, VEC>(M, first, n, tile_m);
+    tile_in<false, VEC>(G, first, n, tile_g);
+    __syncthreads();
+    float m[9], g[9], dm[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile_m, active, m);
+    lane_get(tile_g, active, g);
+    const SignedSvd f = so3::signed_svd<true>(m);
+    so3::project_backward(f, g, dm);
+    lane_put(tile_m, dm);
+    __syncthreads();
+    tile_out<BF16, VEC>(dM, first, n, tile_m);
+}
+
+// ---- block reduction of one double (sum) --------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double block_sum(double v, double *scratch /* >= 4 doubles of LDS */) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// ---- K3 -------------------------------------------------------------------------------------------
+template <bool BF16, bool VEC, bool WANT_R, bool WANT_DM>
+__global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict__ M, const float *__restrict__ Rtrue,
+                                                         float *__restrict__ R, void *__restrict__ dM,
+                                                         double *__restrict__ loss_sum, int64_t B, float inv_b) {
+    __shared__ __attribute__((aligned(16))) float tile_m[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
+    __shared__ double red[4];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<BF16, VEC>(M, first, n, tile_m);
+    tile_in<false, VEC>(Rtrue, first, n, tile_t);
+    __syncthreads();
+    float m[9], t[9], r[9], g[9], dm[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile_m, active, m);
+    lane_get(tile_t, active, t);
+    const SignedSvd f = so3::signed_svd<WANT_DM>(m);
+    so3::rotation_from(f, r);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        g[i] = r[i] - t[i];                       // d||Rtrue - R||/dR = (R - Rtrue)/||.||
+        n2 = fmaf(g[i], g[i], n2);
+    }
+    const float nrm = n2 * so3::rsq(fmaxf(n2, 1e-37f));
+    const float gs = (n2 > 0.f) ? inv_b * so3::rsq(n2) : 0.f;    // zero difference -> zero gradient
+    const double total = block_sum(active ? static_cast<double>(nrm) : 0.0, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+    if (WANT_DM) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] *= gs;
+        so3::project_backward(f, g, dm);
+        lane_put(tile_m, dm);
+    }
+    if (WANT_R) lane_put(tile_t, r);
+    __syncthreads();
+    if (WANT_DM) tile_out<BF16, VEC>(dM, first, n, tile_m);
+    if (WANT_R) tile_out<false, VEC>(R, first, n, tile_t);
+}
+
+// ---- K4 -------------------------------------------------------------------------------------------
+template <bool VEC, bool WANT_DEG, bool WANT_SUM>
+__global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict__ R1, const float *__restrict__ R2,
+                                                        double *__restrict__ out, double *__restrict__ sum_count,
+                                                        int32_t *__restrict__ range_flag, double unit, int64_t B) {
+    __shared__ __attribute__((aligned(16))) float tile_a[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile_b[kTileFloats];
+    __shared__ double red[4];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<false, VEC>(R1, first, n, tile_a);
+    tile_in<false, VEC>(R2, first, n, tile_b);
+    __syncthreads();
+    float a[9], b[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile_a, active, a);
+    lane_get(tile_b, active, b);
+    double tr = 0.0;                                   // tr(R1^T R2) = sum_ij R1_ij R2_ij, float64
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(a[i]), static_cast<double>(b[i]), tr);
+    const double c_raw = (tr - 1.0) * 0.5;
+    const bool bad = active && (c_raw < -1.1 || c_raw > 1.1);  // NaN compares false, as torch.any(...) does
+    double c = fmin(fmax(c_raw, -1.0), 1.0);                   // torch.clamp ...
+    if (c_raw != c_raw) c = c_raw;                             // ... which keeps NaN (fmin/fmax drop it)
+    const double ang = acos(c) * unit;
+    if (range_flag != nullptr && __any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
+    }
+    if (WANT_DEG && active) out[first + threadIdx.x] = ang;
+    if (WANT_SUM) {
+        const double total = block_sum(active ? ang : 0.0, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(sum_count, total);
+            atomicAdd(sum_count + 1, static_cast<double>(n));
+        }
+    }
+}
+
+// float32 radians variant (rotation_representation.py:209-227): tr(m1 m2^T) in float32, hard clamp.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict__ R1, const float *__restrict__ R2,
+                                                         float *__restrict__ theta, int64_t B) {
+    __shared__ __attribute__((aligned(16))) float tile_a[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile_b[kTileFloats];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<false, VEC>(R1, first, n, tile_a);
+    tile_in<false, VEC>(R2, first, n, tile_b);
+    __syncthreads();
+    float a[9], b[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile_a, active, a);
+    lane_get(tile_b, active, b);
+    // diagonal of m1 m2^T, summed in the reference's order: m00 + m11 + m22
+    const float d0 = fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0]));
+    const float d1 = fmaf(a[5], b[5], fmaf(a[4], b[4], a[3] * b[3]));
+    const float d2 = fmaf(a[8], b[8], fmaf(a[7], b[7], a[6] * b[6]));
+    float c = (d0 + d1 + d2 - 1.f) * 0.5f;
+    c = (c > 1.f) ? 1.f : c;     // torch.min / torch.max with a constant: NaN stays NaN
+    c = (c < -1.f) ? -1.f : c;
+    if (active) theta[first + threadIdx.x] = acosf(c);
+}
+
+// ---- K5 -------------------------------------------------------------------------------------------
+// One wave per cloud at a time; lane i takes points i, i+64, ... as 12-byte (dwordx3) loads, so each
+// wave-instruction reads 768 contiguous bytes.  The nine partial sums are reduced across the wave
+// (DPP within rows of 16, then two cross-row exchanges); lane j of the wave keeps the H of the j-th
+// cloud the wave has processed, and after its last cloud the wave runs the K1 body once with one
+// cloud per lane.
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+}
+__device__ __forceinline__ float dpp_mirror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    v += dpp_xor1(v);
+    v += dpp_xor2(v);
+    v += dpp_half_mirror(v);
+    v += dpp_mirror(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+struct P3 {
+    float x, y, z;
+};
+
+constexpr int kKabschUnroll = 4;
+
+__global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, const float *__restrict__ Q,
+                                                   float *__restrict__ R, float *__restrict__ H, int64_t B, int32_t N,
+                                                   int clouds_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+    const int64_t c0 = wave * clouds_per_wave;
+    if (c0 >= B) return;
+    const int nc = static_cast<int>(min<int64_t>(clouds_per_wave, B - c0));
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = (i & 3) == 0 ? 1.f : 0.f;
+    for (int j = 0; j < nc; ++j) {
+        const P3 *__restrict__ p = reinterpret_cast<const P3 *>(P) + (c0 + j) * N;
+        const P3 *__restrict__ q = reinterpret_cast<const P3 *>(Q) + (c0 + j) * N;
+        float acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+        int i0 = lane;
+        for (; i0 + 64 * (kKabschUnroll - 1) < N; i0 += 64 * kKabschUnroll) {
+            P3 pp[kKabschUnroll], qq[kKabschUnroll];
+#pragma unroll
+            for (int u = 0; u < kKabschUnroll; ++u) {
+                pp[u] = p[i0 + 64 * u];
+                qq[u] = q[i0 + 64 * u];
+            }
+#pragma unroll
+            for (int u = 0; u < kKabschUnroll; ++u) {
+                acc[0] = fmaf(qq[u].x, pp[u].x, acc[0]); acc[1] = fmaf(qq[u].x, pp[u].y, acc[1]); acc[2] = fmaf(qq[u].x, pp[u].z, acc[2]);
+                acc[3] = fmaf(qq[u].y, pp[u].x, acc[3]); acc[4] = fmaf(qq[u].y, pp[u].y, acc[4]); acc[5] = fmaf(qq[u].y, pp[u].z, acc[5]);
+                acc[6] = fmaf(qq[u].z, pp[u].x, acc[6]); acc[7] = fmaf(qq[u].z, pp[u].y, acc[7]); acc[8] = fmaf(qq[u].z, pp[u].z, acc[8]);
+            }
+        }
+        for (; i0 < N; i0 += 64) {
+            const P3 pp = p[i0], qq = q[i0];
+            acc[0] = fmaf(qq.x, pp.x, acc[0]); acc[1] = fmaf(qq.x, pp.y, acc[1]); acc[2] = fmaf(qq.x, pp.z, acc[2]);
+            acc[3] = fmaf(qq.y, pp.x, acc[3]); acc[4] = fmaf(qq.y, pp.y, acc[4]); acc[5] = fmaf(qq.y, pp.z, acc[5]);
+            acc[6] = fmaf(qq.z, pp.x, acc[6]); acc[7] = fmaf(qq.z, pp.y, acc[7]); acc[8] = fmaf(qq.z, pp.z, acc[8]);
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float tot = wave_allsum(acc[i]);
+            h[i] = (lane == j) ? tot : h[i];
+        }
+    }
+    const bool active = lane < nc;
+    const SignedSvd f = so3::signed_svd<false>(h);
+    float r[9];
+    so3::rotation_from(f, r);
+    if (active) {
+        float *out = R + (c0 + lane) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] = r[i];
+        if (H != nullptr) {
+            float *ho = H + (c0 + lane) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ho[i] = h[i];
+        }
+    }
+}
+
+inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
+
+#define SO3_CHECK_ARGS(cond, name) \
+    do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
+#define SO3_MAX_B (INT64_C(2147483647) * kBlock)
+
+template <bool BF16>
+int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
+    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_fwd_bwd: loss_sum is null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+    if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
+    const dim3 grid(grid_for(B)), block(kBlock);
+    const float inv_b = 1.0f / static_cast<float>(B);
+    bool vec = aligned16(Rtrue) && (R == nullptr || aligned16(R));
+    if (!BF16) vec = vec && aligned16(M) && (dM == nullptr || aligned16(dM));
+#define LAUNCH(VE, WR, WD) hipLaunchKernelGGL((k_frob_fwd_bwd<BF16, VE, WR, WD>), grid, block, 0, s, M, Rtrue, R, dM, loss_sum, B, inv_b)
+#define PICK(VE) do { if (R && dM) LAUNCH(VE, true, true); else if (R) LAUNCH(VE, true, false); else if (dM) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
+    if (vec) PICK(true); else PICK(false);
+#undef PICK
+#undef LAUNCH
+    return check_launch("so3_frob_fwd_bwd");
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int so3_version(void) { return SO3PROJ_VERSION; }
+const char *so3_last_error(void) { return g_err; }
+
+
+static int project_fwd(bool bf16, const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && R != nullptr, "so3_project_fwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(B)), block(kBlock);
+    const bool vec = (bf16 || aligned16(M)) && aligned16(R);   // for bf16 input VEC only governs the R store
+#define LAUNCH(BF, VE, FL) hipLaunchKernelGGL((k_project_fwd<BF, VE, FL>), grid, block, 0, s, M, R, flip, B)
+#define PICK(BF) do { if (vec) { if (flip) LAUNCH(BF, true, true); else LAUNCH(BF, true, false); } \
+                      else { if (flip) LAUNCH(BF, false, true); else LAUNCH(BF, false, false); } } while (0)
+    if (bf16) PICK(true); else PICK(false);
+#undef PICK
+#undef LAUNCH
+    return check_launch("so3_project_fwd");
+}
+
+int so3_project_fwd_f32(const float *M, float *R, uint8_t *flip, int64_t B, void *stream) {
+    return project_fwd(false, M, R, flip, B, stream);
+}
+int so3_project_fwd_bf16(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
+    return project_fwd(true, M, R, flip, B, stream);
+}
+
+static int project_bwd(bool bf16, const void *M, const float *G, void *dM, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_bwd: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && G != nullptr && dM != nullptr, "so3_project_bwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(B)), block(kBlock);
+    if (bf16) {
+        if (aligned16(G)) hipLaunchKernelGGL((k_project_bwd<true, true>), grid, block, 0, s, M, G, dM, B);
+        else hipLaunchKernelGGL((k_project_bwd<true, false>), grid, block, 0, s, M, G, dM, B);
+    } else {
+        if (aligned16(M) && aligned16(G) && aligned16(dM)) hipLaunchKernelGGL((k_project_bwd<false, true>), grid, block, 0, s, M, G, dM, B);
+        else hipLaunchKernelGGL((k_project_bwd<false, false>), grid, block, 0, s, M, G, dM, B);
+    }
+    return check_launch("so3_project_bwd");
+}
+int so3_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B, void *stream) {
+    return project_bwd(false, M, G, dM, B, stream);
+}
+int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, void *stream) {
+    return project_bwd(true, M, G, dM, B, stream);
+}
+
+int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
+    return frob<false>(M, Rtrue, R, dM, loss_sum, B, stream);
+}
+int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
+    return frob<true>(M, Rtrue, R, dM, loss_sum, B, stream);
+}
+
+int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
+                    int radians, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipSuccess;
+    if (sum_count) e = hipMemsetAsync(sum_count, 0, 2 * sizeof(double), s);
+    if (e == hipSuccess && range_flag) e = hipMemsetAsync(range_flag, 0, sizeof(int32_t), s);
+    if (e != hipSuccess) return fail((int)e, "so3_angle_error: memset");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
+    const dim3 grid(grid_for(B)), block(kBlock);
+    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
+    const bool vec = aligned16(R1) && aligned16(R2);
+#define LAUNCH(VE, WD, WS) hipLaunchKernelGGL((k_angle_error<VE, WD, WS>), grid, block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B)
+#define PICK(VE) do { if (deg && sum_count) LAUNCH(VE, true, true); else if (deg) LAUNCH(VE, true, false); else if (sum_count) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
+    if (vec) PICK(true); else PICK(false);
+#undef PICK
+#undef LAUNCH
+    return check_launch("so3_angle_error");
+}
+
+int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_geodesic_f32: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && theta != nullptr, "so3_geodesic_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(B)), block(kBlock);
+    if (aligned16(R1) && aligned16(R2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, R1, R2, theta, B);
+    else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, R1, R2, theta, B);
+    return check_launch("so3_geodesic_f32");
+}
+
+int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 40) && N >= 0, "so3_kabsch_f32: B/N");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R != nullptr && (N == 0 || (P != nullptr && Q != nullptr)), "so3_kabsch_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // enough waves to fill 256 CUs x 16 waves, at most 64 clouds per wave (one per lane for the SVD)
+    int64_t cpw = B / (256 * 16);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const int64_t waves = (B + cpw - 1) / cpw;
+    const int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    SO3_CHECK_ARGS(blocks <= 2147483647, "so3_kabsch_f32: B too large");
+    hipLaunchKernelGGL(k_kabsch, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, s, P, Q, R, H, B, N, static_cast<int>(cpw));
+    return check_launch("so3_kabsch_f32");
+}
+
+}  // extern "C"

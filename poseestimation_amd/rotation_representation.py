@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's hot-path interface, backed by libso3proj.so.
+
+Same names, argument meaning and error behaviour as the reference functions they replace
+(paths relative to the reference repository root):
+
+    symmetric_orthogonalization(x)                     rotation_representation.py:192-206
+    compute_geodesic_distance_from_two_matrices(m1,m2) rotation_representation.py:209-227
+    angle_error(t_R1, t_R2)                            rotation_representation.py:230-242
+    loss_frobenius(R_pred, R_true)                     3D-Pose/loss.py:7-11
+    transform_output                                   rotation_representation.py:323-324
+
+plus two fused entry points the reference spells as several calls:
+
+    frobenius_head(x, R_true)      head + loss (+ backward in the same launch)   3D-Pose/main.py:60,85,90
+    kabsch_rotation(P, Q)          bmm(Q^T, P) + head                            SURVEY.md section 8 a7
+
+PyTorch is plumbing here: it owns device memory, the stream and autograd bookkeeping.  All
+arithmetic happens in hand-written gfx950 kernels behind the C ABI (include/so3proj.h).  There is
+no CPU path: a CPU tensor, or a missing libso3proj.so, raises.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+_RANGE_MSG = "angle out of range, input probably not proper rotation matrices"   # rotation_representation.py:238-239
+
+
+# --------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------
+def _require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"expected a torch.Tensor, got {type(t).__name__}")
+        if not t.is_cuda:
+            raise RuntimeError(
+                "poseestimation_amd runs on a HIP device only (tensor is on '%s'); there is no CPU "
+                "fallback -- move the tensor to the MI355X with .cuda()" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _as_blocks(x: torch.Tensor) -> torch.Tensor:
+    """x.view(-1, 3, 3) semantics (rotation_representation.py:199) -> contiguous (B, 9)."""
+    if x.numel() % 9 != 0:
+        raise RuntimeError(f"shape '[-1, 3, 3]' is invalid for input of size {x.numel()}")
+    return x.reshape(-1, 9).contiguous()
+
+
+def _head_input(x: torch.Tensor) -> torch.Tensor:
+    """Kernel-ready (B,9) tensor: float32, or bfloat16 kept as stored (math is fp32 in registers)."""
+    m = _as_blocks(x)
+    if m.dtype in (torch.float32, torch.bfloat16):
+        return m
+    if m.dtype == torch.float16:
+        return m.float()
+    raise TypeError(
+        f"symmetric_orthogonalization: unsupported dtype {m.dtype}; the gfx950 kernel computes in "
+        "float32 (inputs: float32, bfloat16, float16)")
+
+
+def _f32_blocks(t: torch.Tensor) -> torch.Tensor:
+    return _as_blocks(t).float()
+
+
+# --------------------------------------------------------------------------------------------
+# K1 / K2: the head
+# --------------------------------------------------------------------------------------------
+class _SymmetricOrthogonalization(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        dev = _require_device(x)
+        m = _head_input(x.detach())
+        b = m.shape[0]
+        r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        fn = lib.so3_project_fwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_fwd_f32
+        with torch.cuda.device(dev):
+            _lib.check(fn(_ptr(m), _ptr(r), None, b, _stream(dev)), "so3_project_fwd")
+        ctx.save_for_backward(m)
+        ctx.in_shape = x.shape
+        ctx.in_dtype = x.dtype
+        return r
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_r):
+        (m,) = ctx.saved_tensors
+        dev = m.device
+        g = grad_r.reshape(-1, 9).contiguous().float()
+        b = m.shape[0]
+        dm = torch.empty_like(m)
+        lib = _lib.load()
+        fn = lib.so3_project_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_bwd_f32
+        with torch.cuda.device(dev):
+            _lib.check(fn(_ptr(m), _ptr(g), _ptr(dm), b, _stream(dev)), "so3_project_bwd")
+        return dm.to(ctx.in_dtype).view(ctx.in_shape)
+
+
+def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
+    """Maps 9D input vectors onto SO(3) via symmetric orthogonalization (SVD).
+
+    x: [batch_size, 9] (any shape whose numel is a multiple of 9, as `x.view(-1, 3, 3)` accepts).
+    Returns [batch_size, 3, 3] float32 rotations R = U diag(1,1,det(UV^T)) V^T, differentiable.
+    """
+    return _SymmetricOrthogonalization.apply(x)
+
+
+def symmetric_orthogonalization_with_flip(x: torch.Tensor):
+    """(R, flip): flip[b] is True where det(U V^T) < 0, the sign the reference multiplies into the
+    last row of V^T (rotation_representation.py:202-204).  Not differentiable."""
+    dev = _require_device(x)
+    m = _head_input(x.detach())
+    b = m.shape[0]
+    r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    flip = torch.empty((b,), dtype=torch.uint8, device=dev)
+    lib = _lib.load()
+    fn = lib.so3_project_fwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_fwd_f32
+    with torch.cuda.device(dev):
+        _lib.check(fn(_ptr(m), _ptr(r), _ptr(flip), b, _stream(dev)), "so3_project_fwd")
+    return r, flip.bool()
+
+
+# --------------------------------------------------------------------------------------------
+# K4: metrics
+# --------------------------------------------------------------------------------------------
+def _angle_call(r1, r2, want_deg, want_sum, radians=False):
+    dev = _require_device(r1, r2)
+    a, b_ = _f32_blocks(r1), _f32_blocks(r2)
+    if a.shape != b_.shape:
+        raise RuntimeError(f"angle_error: shape mismatch {tuple(r1.shape)} vs {tuple(r2.shape)}")
+    n = a.shape[0]
+    deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
+    sc = torch.empty((2,), dtype=torch.float64, device=dev) if want_sum else None
+    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_angle_error(_ptr(a), _ptr(b_), _ptr(deg), _ptr(sc), _ptr(flag),
+                                               1 if radians else 0, n, _stream(dev)), "so3_angle_error")
+    return deg, sc, flag
+
+
+def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """Geodesic angle between rotations, float64 degrees, shape (B,).
+
+    Raises ValueError("angle out of range, ...") when any cosine is outside [-1.1, 1.1], exactly as
+    the reference does; that needs one device->host read (the reference's two `torch.any` cost two).
+    `check=False` skips the read (and the raise) for benchmarking / graph capture.
+    """
+    deg, _, flag = _angle_call(t_R1, t_R2, True, False)
+    if check and int(flag.item()) != 0:
+        raise ValueError(_RANGE_MSG)
+    return deg
+
+
+def angle_error_sum_count(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> torch.Tensor:
+    """Device tensor of two float64: (sum of angles in degrees, row count), reduced on the device.
+
+    This pair is what one all-reduce sums across GPUs (poseestimation_amd.distributed); the
+    per-row vector is never materialised."""
+    _, sc, flag = _angle_call(t_R1, t_R2, False, True)
+    if check and int(flag.item()) != 0:
+        raise ValueError(_RANGE_MSG)
+    return sc
+
+
+def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+    """Geodesic distance in radians, float32, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,)."""
+    dev = _require_device(m1, m2)
+    a, b_ = _f32_blocks(m1), _f32_blocks(m2)
+    if a.shape != b_.shape:
+        raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
+    n = a.shape[0]
+    theta = torch.empty((n,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_geodesic_f32(_ptr(a), _ptr(b_), _ptr(theta), n, _stream(dev)), "so3_geodesic_f32")
+    return theta
+
+
+# --------------------------------------------------------------------------------------------
+# K3: loss
+# --------------------------------------------------------------------------------------------
+def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
+    """mean_b ||R_true - R_pred||_F (not squared), differentiable w.r.t. both arguments.
+
+    Stand-alone form for callers that already hold R_pred.  A training step should use
+    `frobenius_head`, which fuses head, loss and backward into one launch."""
+    _require_device(R_pred, R_true)
+    diff = R_true - R_pred
+    return diff.reshape(-1, 9).norm(dim=1).mean()
+
+
+class _FrobeniusHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r_true, want_r):
+        dev = _require_device(x, r_true)
+        m = _head_input(x.detach())
+        t = _f32_blocks(r_true.detach())
+        b = m.shape[0]
+        if t.shape[0] != b:
+            raise RuntimeError(f"frobenius_head: {b} predictions vs {t.shape[0]} targets")
+        need_grad = x.requires_grad
+        r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if want_r else None
+        dm = torch.empty_like(m) if need_grad else None
+        loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
+        lib = _lib.load()
+        fn = lib.so3_frob_fwd_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
+        with torch.cuda.device(dev):
+            _lib.check(fn(_ptr(m), _ptr(t), _ptr(r), _ptr(dm), _ptr(loss_sum), b, _stream(dev)), "so3_frob_fwd_bwd")
+        loss = (loss_sum[0] / max(b, 1)).to(torch.float32)
+        ctx.dm = dm
+        ctx.in_shape = x.shape
+        ctx.in_dtype = x.dtype
+        if want_r:
+            ctx.mark_non_differentiable(r)
+            return loss, r
+        return loss, torch.empty(0, device=dev)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loss, _grad_r):
+        dm = ctx.dm
+        if dm is None:
+            return None, None, None
+        return (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape), None, None
+
+
+def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool = True):
+    """Fused `out = symmetric_orthogonalization(x); loss = loss_frobenius(R_true, out)`.
+
+    One kernel computes R, the loss and d(loss)/dx; `loss.backward()` then only scales the stored
+    gradient.  Returns (loss, R) -- R is detached (use it for metrics) -- or loss alone.
+    """
+    loss, r = _FrobeniusHead.apply(x, R_true, return_rotation)
+    return (loss, r) if return_rotation else loss
+
+
+# --------------------------------------------------------------------------------------------
+# K5: Kabsch
+# --------------------------------------------------------------------------------------------
+def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
+    """R_b = argmin_R sum_i |R p_bi - q_bi|^2 over SO(3) = proj(sum_i q_bi p_bi^T).
+
+    P, Q: (B, N, 3) float32 clouds as in point_cloud/main.py:171-181 (q = R p, no translation).
+    Equivalent to symmetric_orthogonalization(torch.bmm(Q.transpose(1, 2), P)) in one launch."""
+    dev = _require_device(P, Q)
+    if P.dim() != 3 or P.shape[-1] != 3 or P.shape != Q.shape:
+        raise RuntimeError(f"kabsch_rotation: expected two (B, N, 3) tensors, got {tuple(P.shape)} and {tuple(Q.shape)}")
+    p = P.detach().contiguous().float()
+    q = Q.detach().contiguous().float()
+    b, n, _ = p.shape
+    r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_kabsch_f32(_ptr(p), _ptr(q), _ptr(r), _ptr(h), b, n, _stream(dev)), "so3_kabsch_f32")
+    return (r, h) if return_h else r
+
+
+# Head dispatch table, keyed like the reference's (rotation_representation.py:323-324;
+# Comparison/models.py:18-19; 3D-Pose/main.py:46).  Only the SVD head is in scope.
+transform_output = {"SVD": (9, symmetric_orthogonalization)}

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE in the build container.
+
+Run once, here, with /root/reference mounted:   python tools/gen_golden.py
+The reference never travels: only the inputs and the outputs it produced are committed
+(SURVEY.md section 8c).  Nothing under tests/, bench.py or the package imports this script.
+
+How the reference code is executed
+  * rotation_representation.py imports cleanly (torch, numpy only) -> imported as a module.
+  * loss_frobenius (3D-Pose/loss.py:7-11) and the rotation sampler
+    (point_cloud/prepare.py:12-49) live in files whose *module-level imports* need packages that
+    are not installed (spatialmath, trimesh).  Their function bodies need only torch/numpy, so the
+    function definitions are compiled straight from the reference files with `ast` and executed --
+    the reference's own code runs, nothing is retyped.
+  * Two reference functions hard-code `.cuda()` (rotation_representation.py:218-219,
+    point_cloud/prepare.py:23,25).  There is no GPU here, so `Tensor.cuda` is made the identity
+    for the duration of this script; arithmetic is unchanged.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self          # CPU container: see docstring
+torch.set_num_threads(1)                                # deterministic LAPACK path
+
+sys.path.insert(0, REF)
+import rotation_representation as rr  # noqa: E402
+
+
+def functions_from(path, names):
+    """Compile the named top-level functions of a reference file without importing the file."""
+    with open(path) as fh:
+        tree = ast.parse(fh.read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in keep} == set(names), (path, names)
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+(loss_frobenius,) = functions_from(os.path.join(REF, "3D-Pose", "loss.py"), ["loss_frobenius"])
+normalize_vector, sample_rot = functions_from(
+    os.path.join(REF, "point_cloud", "prepare.py"),
+    ["normalize_vector", "get_sampled_rotation_matrices_by_axisAngle"])
+
+
+def svd_parts(x):
+    """s and det(u v^T) exactly as the reference computes them (rotation_representation.py:200-202)."""
+    m = x.view(-1, 3, 3)
+    u, s, v = torch.svd(m)
+    det = torch.det(torch.matmul(u, torch.transpose(v, 1, 2)))
+    return s, det
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def main():
+    # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
+    torch.manual_seed(0)
+    x = torch.randn(256, 9)
+    r = rr.symmetric_orthogonalization(x)
+    s, det = svd_parts(x)
+    r64 = rr.symmetric_orthogonalization(x.double())
+    save("g1_gaussian256.npz", x=x, r=r, s=s, det=det, r_f64=r64)
+
+    # ---- G2: adversarial inputs ------------------------------------------------------------------
+    torch.manual_seed(2)
+    q = rr.symmetric_orthogonalization(torch.randn(4, 9))
+    cases, names = [], []
+
+    def add(name, m):
+        names.append(name)
+        cases.append(torch.as_tensor(m, dtype=torch.float32).reshape(3, 3))
+    add("zero", torch.zeros(3, 3))
+    add("identity", torch.eye(3))
+    add("reflection_z", torch.diag(torch.tensor([1., 1., -1.])))
+    add("neg_identity", -torch.eye(3))
+    add("rank1_e1", torch.diag(torch.tensor([2., 0., 0.])))
+    add("rank1_ones", torch.ones(3, 3))
+    add("rank2_diag", torch.diag(torch.tensor([1., 1., 0.])))
+    add("rank2_rot", q[0] @ torch.diag(torch.tensor([3., 0.5, 0.])) @ q[1].T)
+    add("rotation", q[2])
+    add("rotation_scaled_1e-20", q[2] * 1e-20)
+    add("rotation_scaled_1e+15", q[2] * 1e15)
+    add("improper_rotation", q[3] @ torch.diag(torch.tensor([1., 1., -1.])))
+    add("near_equal_sv", q[0] @ torch.diag(torch.tensor([1.0, 1.0 - 1e-6, 1.0 - 2e-6])) @ q[1].T)
+    add("near_equal_sv_flip", q[0] @ torch.diag(torch.tensor([1.0, 0.7, -0.3])) @ q[1].T)
+    add("flip_close_s2_s3", q[0] @ torch.diag(torch.tensor([1.0, 0.5, -0.499])) @ q[1].T)
+    add("tiny_s3_pos", q[2] @ torch.diag(torch.tensor([1.0, 0.5, 1e-6])) @ q[3].T)
+    add("tiny_s3_neg", q[2] @ torch.diag(torch.tensor([1.0, 0.5, -1e-6])) @ q[3].T)
+    add("graded", q[1] @ torch.diag(torch.tensor([1e3, 1.0, 1e-3])) @ q[0].T)
+    add("upper_triangular", torch.tensor([[1., 2., 3.], [0., 4., 5.], [0., 0., 6.]]))
+    add("permutation_odd", torch.tensor([[0., 1., 0.], [1., 0., 0.], [0., 0., 1.]]))
+    add("permutation_even", torch.tensor([[0., 1., 0.], [0., 0., 1.], [1., 0., 0.]]))
+    xa = torch.stack(cases).reshape(-1, 9)
+    ra = rr.symmetric_orthogonalization(xa)
+    sa, deta = svd_parts(xa)
+    save("g2_adversarial.npz", x=xa, r=ra, s=sa, det=deta, names=np.array(names),
+         r_f64=rr.symmetric_orthogonalization(xa.double()))
+    # view semantics: any shape with numel % 9 == 0 (rotation_representation.py:199)
+    torch.manual_seed(3)
+    xs = torch.randn(2, 5, 9)
+    save("g2_shape_2x5x9.npz", x=xs, r=rr.symmetric_orthogonalization(xs))
+
+    # ---- G3: angle_error / geodesic ----------------------------------------------------------------
+    torch.manual_seed(4)
+    r1 = rr.symmetric_orthogonalization(torch.randn(256, 9))
+    r2 = rr.symmetric_orthogonalization(torch.randn(256, 9))
+    r2[0] = r1[0]                                                   # 0 degrees
+    r2[1] = r1[1] @ torch.diag(torch.tensor([1., -1., -1.]))        # 180 degrees
+    r2[2] = r1[2] @ torch.diag(torch.tensor([-1., -1., 1.]))        # 180 degrees
+    small = rr.so3_exp_map(torch.tensor([[1e-4, 0., 0.], [0., 3e-3, 0.]])) if hasattr(rr, "so3_exp_map") else None
+    if small is not None and small.shape == (2, 3, 3):
+        r2[3] = r1[3] @ small[0].float()
+        r2[4] = r1[4] @ small[1].float()
+    deg = rr.angle_error(r1, r2)
+    rad = rr.compute_geodesic_distance_from_two_matrices(r1, r2)
+    bad1 = torch.eye(3).repeat(3, 1, 1)
+    bad2 = torch.eye(3).repeat(3, 1, 1)
+    bad2[1] = 1.5 * torch.eye(3)          # trace 4.5 -> cos 1.75 > 1.1 : must raise
+    raised = False
+    try:
+        rr.angle_error(bad1, bad2)
+    except ValueError as exc:
+        raised = True
+        msg = str(exc)
+    assert raised
+    nearly = torch.eye(3).repeat(2, 1, 1)
+    nearly2 = nearly.clone()
+    nearly2[1] = 1.05 * torch.eye(3)      # cos = 1.075: inside the tolerance band, clamped, no raise
+    deg_nearly = rr.angle_error(nearly, nearly2)
+    save("g3_angles.npz", r1=r1, r2=r2, deg=deg, rad=rad, bad1=bad1, bad2=bad2, raise_msg=np.array(msg),
+         nearly1=nearly, nearly2=nearly2, deg_nearly=deg_nearly)
+
+    # ---- G4: config #4, 512 rows bf16-rounded, Frobenius loss forward + backward ------------------
+    torch.manual_seed(0)
+    x4 = torch.randn(512, 9).bfloat16()
+    torch.manual_seed(1)
+    rt = rr.symmetric_orthogonalization(torch.randn(512, 9))
+    xf = x4.float().requires_grad_(True)
+    out = rr.symmetric_orthogonalization(xf)
+    loss = loss_frobenius(rt, out)                      # call order of 3D-Pose/main.py:85 (R, out)
+    loss.backward()
+    # generic upstream gradient through the head alone (K2)
+    torch.manual_seed(5)
+    g = torch.randn(512, 3, 3)
+    xg = x4.float().requires_grad_(True)
+    rr.symmetric_orthogonalization(xg).backward(g)
+    # float64 versions of both gradients (the reference code, double input)
+    xd = x4.double().requires_grad_(True)
+    lossd = loss_frobenius(rt.double(), rr.symmetric_orthogonalization(xd))
+    lossd.backward()
+    xgd = x4.double().requires_grad_(True)
+    rr.symmetric_orthogonalization(xgd).backward(g.double())
+    save("g4_frobenius512.npz", x_bf16_bits=x4.view(torch.int16), r_true=rt, r=out.detach(), loss=loss.detach(),
+         dx=xf.grad, g=g, dx_g=xg.grad, loss_f64=lossd.detach(), dx_f64=xd.grad, dx_g_f64=xgd.grad)
+
+    # ---- G5: Kabsch pairs (config #3 contract), 6 clouds x 1024 + 24 clouds x 64 --------------------
+    for tag, (b, n) in {"6x1024": (6, 1024), "24x64": (24, 64)}.items():
+        torch.manual_seed(7)
+        np.random.seed(7)
+        p = torch.rand(b, n, 3) - 0.5
+        r_gt = sample_rot(b)                                         # point_cloud/prepare.py:21-49
+        qpts = torch.bmm(r_gt, p.transpose(1, 2)).transpose(1, 2).contiguous()   # point_cloud/main.py:176-181
+        qn = qpts + 0.01 * torch.randn(b, n, 3)
+        h = torch.bmm(qn.transpose(1, 2), p)
+        save("g5_kabsch_%s.npz" % tag, p=p, q=qn, r_gt=r_gt, h=h, r=rr.symmetric_orthogonalization(h),
+             r_f64=rr.symmetric_orthogonalization(torch.bmm(qn.double().transpose(1, 2), p.double())))
+
+    # ---- G6: scalar statistics at config #2's full size (inputs regenerated from the seeds) -------
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    xb = torch.randn(1_000_000, 9)
+    torch.manual_seed(1)
+    tb = rr.symmetric_orthogonalization(torch.randn(1_000_000, 9))
+    rb = rr.symmetric_orthogonalization(xb)
+    sb, detb = svd_parts(xb)
+    ang = rr.angle_error(rb, tb)
+    rb64 = rr.symmetric_orthogonalization(xb.double())
+    ang64 = rr.angle_error(rb64, tb.double())
+    orth = torch.linalg.matrix_norm(rb.transpose(1, 2) @ rb - torch.eye(3), ord="fro")
+    save("g6_stats_1m.npz", n=1_000_000, seed_x=0, seed_t=1,
+         mean_angle_deg=ang.mean(), mean_angle_deg_f64=ang64.mean(),
+         flip_count=(detb < 0).sum(), max_orth_err=orth.max(),
+         x_head=xb[:64], r_head=rb[:64], t_head=tb[:64], x_checksum=xb.double().sum(), t_checksum=tb.double().sum(),
+         flip_bits=np.packbits((detb < 0).numpy()))
+
+
+if __name__ == "__main__":
+    main()

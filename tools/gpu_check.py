@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Quick GPU sanity + timing script used during development (not a test; tests/ holds the parity suite)."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import poseestimation_amd as pa
+from poseestimation_amd import rotation_representation as rr
+from oracle import c_oracle
+
+def main():
+    dev = torch.device("cuda:0")
+    print(torch.cuda.get_device_name(0))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1_000_000, 9, generator=g)
+    xd = x.to(dev)
+    r, flip = rr.symmetric_orthogonalization_with_flip(xd)
+    torch.cuda.synchronize()
+    r_ref, f_ref = c_oracle.project(x.numpy(), want_flip=True)
+    rc = r.cpu().numpy()
+    err = np.abs(rc - r_ref).reshape(len(x), -1).max(1)
+    orth = np.linalg.norm(np.einsum('bji,bjk->bik', rc, rc) - np.eye(3), axis=(1, 2))
+    print("K1: max|dR| %.3e p99.9 %.3e median %.3e  orth max %.3e  flip mismatches %d  nan %d" % (
+        err.max(), np.quantile(err, .999), np.median(err), orth.max(), (flip.cpu().numpy() != f_ref).sum(), np.isnan(rc).sum()))
+    # angle error
+    t = rr.symmetric_orthogonalization(torch.randn(1_000_000, 9, generator=torch.Generator().manual_seed(1)).to(dev))
+    deg = rr.angle_error(r, t)
+    sc = rr.angle_error_sum_count(r, t)
+    deg_ref, _ = c_oracle.angle_error(rc, t.cpu().numpy())
+    print("K4: mean %.9f (sum/count %.9f) oracle-on-same-R %.9f  max|d| %.3e" % (
+        deg.mean().item(), (sc[0] / sc[1]).item(), deg_ref.mean(), np.abs(deg.cpu().numpy() - deg_ref).max()))
+    deg_o, _ = c_oracle.angle_error(r_ref, c_oracle.project(torch.randn(1_000_000, 9, generator=torch.Generator().manual_seed(1)).numpy()))
+    print("    mean angle, oracle end to end %.9f  delta %.3e deg" % (deg_o.mean(), deg.mean().item() - deg_o.mean()))
+    # backward
+    xg = xd[:4096].clone().requires_grad_(True)
+    gg = torch.randn(4096, 3, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    rr.symmetric_orthogonalization(xg).backward(gg)
+    ref = c_oracle.project_bwd(x[:4096].numpy(), gg.cpu().numpy())
+    e = np.abs(xg.grad.cpu().numpy().reshape(-1, 3, 3) - ref).reshape(4096, -1).max(1) / (1 + np.abs(ref).reshape(4096, -1).max(1))
+    print("K2: rel err max %.3e p99 %.3e median %.3e" % (e.max(), np.quantile(e, .99), np.median(e)))
+    # fused
+    xf = xd[:512].clone().requires_grad_(True)
+    loss, rf = rr.frobenius_head(xf, t[:512])
+    loss.backward()
+    xr = xd[:512].clone().requires_grad_(True)
+    l2 = rr.loss_frobenius(t[:512], rr.symmetric_orthogonalization(xr)); l2.backward()
+    print("K3: loss %.7f vs unfused %.7f ; grad max diff %.3e" % (loss.item(), l2.item(), (xf.grad - xr.grad).abs().max().item()))
+    # kabsch
+    B, N = 4096, 1024
+    P = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
+    Rgt = rr.symmetric_orthogonalization(torch.randn(B, 9, generator=g).to(dev))
+    Q = torch.bmm(P, Rgt.transpose(1, 2)) + 0.01 * torch.randn(B, N, 3, device=dev)
+    Rk, H = rr.kabsch_rotation(P, Q, return_h=True)
+    Ro, Ho = c_oracle.kabsch(P.cpu().numpy(), Q.cpu().numpy(), want_h=True)
+    print("K5: max|dH| %.3e max|dR| %.3e  angle to gt mean %.4f deg" % (np.abs(H.cpu().numpy() - Ho).max(), np.abs(Rk.cpu().numpy() - Ro).max(), rr.angle_error(Rk, Rgt).mean().item()))
+
+    # timing K1 with rotating buffers
+    nb = 10
+    xs = [torch.randn(1_000_000, 9, device=dev) for _ in range(nb)]
+    outs = [torch.empty(1_000_000, 3, 3, device=dev) for _ in range(nb)]
+    lib = pa._lib.load()
+    import ctypes
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def launch(i):
+        lib.so3_project_fwd_f32(ctypes.c_void_p(xs[i % nb].data_ptr()), ctypes.c_void_p(outs[i % nb].data_ptr()), None, 1_000_000, st)
+    for i in range(5): launch(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    K = 50
+    e0.record()
+    for i in range(K): launch(i)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / K
+    print("K1 1M rotating: %.2f us/launch  %.2f Gproj/s  %.1f GB/s (%.1f%% of 8 TB/s)" % (ms * 1e3, 1e6 / ms / 1e6, 72e6 / ms / 1e6, 72e6 / ms / 1e6 / 8000 * 100))
+    e0.record()
+    for i in range(K): launch(0)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / K
+    print("K1 1M same buffer (cache resident): %.2f us/launch  %.1f GB/s" % (ms * 1e3, 72e6 / ms / 1e6))
+    # kabsch timing
+    B = 65536
+    P = torch.rand(B, 1024, 3, device=dev) - 0.5
+    Q = torch.rand(B, 1024, 3, device=dev) - 0.5
+    Rk = torch.empty(B, 3, 3, device=dev)
+    def lk():
+        lib.so3_kabsch_f32(ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(Q.data_ptr()), ctypes.c_void_p(Rk.data_ptr()), None, B, 1024, st)
+    for i in range(3): lk()
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(10): lk()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print("K5 65536x1024: %.1f us  %.1f GB/s (%.1f%% of 8 TB/s)" % (ms * 1e3, B * 24612 / ms / 1e6, B * 24612 / ms / 1e6 / 8000 * 100))
+
+if __name__ == "__main__":
+    main()
