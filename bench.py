@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the SVD -> SO(3) hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic Gaussian (rows, 9) float32 -> (rows, 3, 3) rotations,
+rows = 1,000,000 per GPU.  A "step" is one K1 launch over one resident batch.  Inputs and outputs
+rotate over 8 buffer pairs (576 MB per GPU) so the 256 MiB Infinity Cache cannot serve replays:
+the reported number is an HBM number.  With N > 1 every rank owns its own rows (weak scaling, no
+data-path collective); after the timed region the mean geodesic angle error is reduced on the
+device per rank (K4) and summed with ONE all-reduce (RCCL).
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job projections/s.
+Extra objects: "roofline" (HBM roofline of k_project_fwd from HIP events on the launch stream) and
+"cpu_baseline" (the oracle's torch port -- the reference's ATen call sequence -- timed on this box's
+host cores; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS_DEFAULT = 1_000_000
+NBUF = 8
+BYTES_PER_PROJECTION = 72          # 36 B read + 36 B written
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--rows", type=int, default=ROWS_DEFAULT, help="rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(rows: int):
+    """The oracle's torch port (== the reference's ATen sequence) on the host cores, bounded sample."""
+    from oracle import so3_oracle as so
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, 9, generator=g)
+    so.symmetric_orthogonalization_torch(x[: max(1, rows // 50)])            # LAPACK warm-up
+    best = float("inf")
+    t_start = time.perf_counter()
+    reps = 0
+    while reps < 3 and (time.perf_counter() - t_start) < 25.0:
+        t0 = time.perf_counter()
+        so.symmetric_orthogonalization_torch(x)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    cpu_name = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    cpu_name = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": rows / best, "unit": "projections/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{rows} rows of the same Gaussian workload, torch.linalg.svd-based restatement of "
+                      f"rotation_representation.py:199-205 (oracle/so3_oracle.py), best of {reps}, {cpu_name}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from poseestimation_amd import _lib
+    from poseestimation_amd import rotation_representation as rr
+    from poseestimation_amd.distributed import allreduce_sum_count
+    lib = _lib.load()                      # raises if the HIP extension is missing
+
+    rows = args.rows
+    # buffer 0 of rank r is config #2/#5's generator: torch.manual_seed(r); randn(rows, 9) on the CPU
+    g = torch.Generator().manual_seed(rank)
+    x0 = torch.randn(rows, 9, generator=g)
+    xs = [x0.to(dev)]
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
+    for _ in range(NBUF - 1):
+        xs.append(torch.randn(rows, 9, device=dev, generator=gen))
+    outs = [torch.empty(rows, 3, 3, device=dev) for _ in range(NBUF)]
+    stream = torch.cuda.current_stream()
+    st = ctypes.c_void_p(stream.cuda_stream)
+    calls = [(ctypes.c_void_p(xs[i].data_ptr()), ctypes.c_void_p(outs[i].data_ptr())) for i in range(NBUF)]
+    fwd = lib.so3_project_fwd_f32
+    brows = ctypes.c_int64(rows)
+
+    def step(i):
+        a, b = calls[i % NBUF]
+        rc = fwd(a, b, None, brows, st)
+        if rc != 0:
+            raise RuntimeError("so3_project_fwd_f32 failed: %s" % lib.so3_last_error().decode())
+
+    for i in range(args.warmup):
+        step(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for i in range(args.steps):
+        step(i)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, ev_ms = tmax[0].item(), tmax[1].item()
+
+    # parity metric: mean geodesic angle vs the decoy target (config #2), one all-reduce of (sum, count)
+    gt = torch.Generator().manual_seed(1 + 1000 * rank)
+    t_rot = rr.symmetric_orthogonalization(torch.randn(rows, 9, generator=gt).to(dev))
+    step(0)
+    sc = rr.angle_error_sum_count(outs[0], t_rot, check=False)
+    allreduce_sum_count(sc)
+    mean_angle = (sc[0] / sc[1]).item()
+    delta = None
+    golden = os.path.join(ROOT, "tests", "golden", "g6_stats_1m.npz")
+    if rank == 0 and world == 1 and rows == ROWS_DEFAULT and os.path.exists(golden):
+        delta = mean_angle - float(np.load(golden)["mean_angle_deg"])      # vs the reference's own number
+
+    if rank == 0:
+        total_rows = rows * world
+        per_launch_s = ev_ms * 1e-3 / args.steps
+        achieved = BYTES_PER_PROJECTION * rows / per_launch_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        out = {
+            "metric": "3x3 SVD->SO(3) projections/sec @ batch 1M",
+            "value": total_rows * args.steps / wall,
+            "unit": "projections/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: batch 1M synthetic 3x3 Gaussian -> SO(3) projection, fp32, per GPU",
+                       "rows_per_gpu": rows, "global_rows": total_rows, "buffer_pairs_rotated": NBUF,
+                       "parallelism": f"dp{world} (row shards, one all-reduce of (sum,count) for the metric)"},
+            "mean_angle_error_deg": mean_angle,
+            "mean_angle_error_delta_vs_ref_deg": delta,
+            "roofline": {"bound": "hbm", "kernel": "k_project_fwd<f32,vec>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
+                         "avg_launch_us": per_launch_s * 1e6},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,11 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libso3proj.so")
 SOURCES = ["so3proj.hip"]
 HEADERS = ["so3_device.h", os.path.join("..", "..", "include", "so3proj.h")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+# -fno-slp-vectorize: hipcc's SLP pass packs the 3-vector arithmetic into v_pk_fma_f32/v_pk_mul_f32,
+# which on gfx950 issue at half the rate of the scalar forms (tools/ubench/valu_rates.hip: same
+# FLOP/s) and cost ~250 extra v_mov_b32 per lane to build the register pairs.
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+               "-fno-slp-vectorize"]
 
 
 def hipcc() -> str:

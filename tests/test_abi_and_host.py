@@ -1,0 +1,97 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every declared symbol, the
+Python mirror refuses to run without a HIP device (no CPU fallback, no oracle in the product)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "so3proj.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(so3_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = ctypes.CDLL(built_library)
+    names = header_symbols()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/so3proj.h but not exported"
+
+
+def test_binding_table_matches_header(built_library):
+    from poseestimation_amd import _lib
+    assert sorted(_lib.SYMBOLS) == header_symbols()
+    lib = _lib.load()
+    assert lib.so3_version() == 100
+    assert lib.so3_last_error() == b""
+
+
+def test_argument_validation_without_gpu(built_library):
+    """Bad arguments are rejected on the host before any launch (no GPU needed)."""
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    assert lib.so3_project_fwd_f32(None, None, None, -1, None) == -1
+    assert b"so3_project_fwd" in lib.so3_last_error()
+    assert lib.so3_project_fwd_f32(None, None, None, 5, None) == -1          # null pointers with B > 0
+    assert lib.so3_project_fwd_f32(None, None, None, 0, None) == 0           # B == 0 is a no-op
+    assert lib.so3_project_bwd_f32(None, None, None, 3, None) == -1
+    assert lib.so3_geodesic_f32(None, None, None, 0, None) == 0
+    assert lib.so3_kabsch_f32(None, None, None, None, 0, 1024, None) == 0
+    assert lib.so3_kabsch_f32(None, None, None, None, 4, -1, None) == -1
+
+
+def test_cpu_tensor_is_refused_not_silently_computed():
+    import poseestimation_amd as pa
+    x = torch.randn(4, 9)
+    for call in (lambda: pa.symmetric_orthogonalization(x),
+                 lambda: pa.angle_error(torch.eye(3)[None], torch.eye(3)[None]),
+                 lambda: pa.compute_geodesic_distance_from_two_matrices(torch.eye(3)[None], torch.eye(3)[None]),
+                 lambda: pa.loss_frobenius(torch.eye(3)[None], torch.eye(3)[None]),
+                 lambda: pa.frobenius_head(x, torch.eye(3).repeat(4, 1, 1)),
+                 lambda: pa.kabsch_rotation(torch.randn(2, 8, 3), torch.randn(2, 8, 3))):
+        with pytest.raises(RuntimeError, match="no CPU fallback|HIP device"):
+            call()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from poseestimation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libso3proj.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "poseestimation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "so3_oracle" not in text and "libso3oracle" not in text, f
+                assert "linalg.svd" not in text and "torch.svd" not in text, f
+
+
+def test_dispatch_table_keys():
+    import poseestimation_amd as pa
+    dim, fn = pa.transform_output["SVD"]
+    assert dim == 9 and fn is pa.symmetric_orthogonalization
+
+
+def test_shard_range_partitions():
+    from poseestimation_amd.distributed import shard_range
+    for total in (0, 1, 7, 16, 1_000_003, 16_000_000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)

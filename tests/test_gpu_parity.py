@@ -1,0 +1,361 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (via the ctypes binding), against
+(1) the golden vectors produced by the reference, (2) the oracle on the same seeded inputs, and
+(3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (float32 path):
+  * flip flags: bit-exact.
+  * orthogonality ||R^T R - I||_F < 1e-5 on every row.
+  * |mean angle - reference mean angle| < 1e-4 degrees.
+  * per-row |R - R_ref|: float32 conditioning -- eps * s1/gap with gap = s2+s3 (no flip) or s2-s3
+    (flip); asserted as  err * gap/s1 < 3e-6  and  < 1e-5 absolute on well-conditioned rows.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, orth_err, well_conditioned
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def pa():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import poseestimation_amd as pa_
+    from poseestimation_amd import _lib
+    _lib.load()                                   # fail loudly if the HIP extension is missing
+    return pa_
+
+
+@pytest.fixture(scope="module")
+def rr(pa):
+    from poseestimation_amd import rotation_representation
+    return rotation_representation
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+def cond_scaled_err(r, r_ref, s, det):
+    s = np.asarray(s, np.float64)
+    gap = np.where(np.asarray(det) < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2])
+    err = np.abs(np.asarray(r, np.float64) - r_ref).reshape(len(s), -1).max(1)
+    return err, err * gap / np.maximum(s[:, 0], 1e-300)
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 against the reference's golden vectors
+# ------------------------------------------------------------------------------------------------
+def test_g1_config1_256_rows(rr):
+    g = load_golden("g1_gaussian256.npz")
+    r, flip = rr.symmetric_orthogonalization_with_flip(dev(g["x"]))
+    r = r.cpu().numpy()
+    assert r.shape == (256, 3, 3) and r.dtype == np.float32
+    assert np.array_equal(flip.cpu().numpy(), g["det"] < 0)            # det-sign flip: bit-exact
+    assert orth_err(r).max() < 1e-5
+    err, scaled = cond_scaled_err(r, g["r_f64"], g["s"], g["det"])
+    assert scaled.max() < 3e-6
+    ok = well_conditioned(g["s"], g["det"])
+    assert np.abs(r[ok] - g["r"][ok]).max() < 1e-5                      # vs the reference's own float32 output
+    # closer to the float64 answer than the reference's float32 path is, on aggregate
+    err_ref = np.abs(g["r"] - g["r_f64"]).reshape(256, -1).max(1)
+    assert np.median(err) <= np.median(err_ref)
+
+
+def test_g2_adversarial(rr):
+    g = load_golden("g2_adversarial.npz")
+    names = [str(n) for n in g["names"]]
+    r = rr.symmetric_orthogonalization(dev(g["x"])).cpu().numpy()
+    assert np.isfinite(r).all()
+    assert orth_err(r).max() < 1e-5
+    assert np.abs(np.linalg.det(r.astype(np.float64)) - 1).max() < 1e-5
+    unique = {"identity": 1e-6, "rank2_diag": 1e-6, "rank2_rot": 2e-5, "rotation": 1e-6, "rotation_scaled_1e-20": 1e-6,
+              "rotation_scaled_1e+15": 1e-6, "near_equal_sv": 5e-6, "near_equal_sv_flip": 2e-6, "flip_close_s2_s3": 5e-4,
+              "tiny_s3_pos": 2e-6, "tiny_s3_neg": 2e-6, "graded": 2e-6, "upper_triangular": 2e-6, "permutation_even": 1e-6}
+    for n, tol in unique.items():
+        i = names.index(n)
+        assert np.abs(r[i] - g["r_f64"][i]).max() < tol, n
+    # behaviours of the reference a caller may rely on
+    assert np.allclose(r[names.index("zero")], np.eye(3), atol=1e-7)
+    assert np.allclose(r[names.index("reflection_z")], np.eye(3), atol=1e-7)
+
+
+def test_view_semantics_and_bad_shapes(rr):
+    g = load_golden("g2_shape_2x5x9.npz")
+    r = rr.symmetric_orthogonalization(dev(g["x"]))
+    assert tuple(r.shape) == (10, 3, 3)
+    assert np.abs(r.cpu().numpy() - g["r"]).max() < 1e-5
+    with pytest.raises(RuntimeError, match=r"shape '\[-1, 3, 3\]' is invalid for input of size 10"):
+        rr.symmetric_orthogonalization(torch.zeros(10, device=DEV))
+    with pytest.raises(TypeError):
+        rr.symmetric_orthogonalization(torch.zeros(2, 9, device=DEV, dtype=torch.float64))
+    assert tuple(rr.symmetric_orthogonalization(torch.zeros(0, 9, device=DEV)).shape) == (0, 3, 3)
+
+
+@pytest.mark.parametrize("b", [1, 63, 64, 65, 255, 256, 257, 511, 513, 1000])
+def test_ragged_batches_and_unaligned_pointers(rr, c_oracle, b):
+    rng = np.random.default_rng(b)
+    x = rng.standard_normal((b + 3, 9)).astype(np.float32)
+    xd = dev(x)
+    for off in (0, 1, 3):                                   # row offset 1 -> base pointer 36 B off: not 16-B aligned
+        r = rr.symmetric_orthogonalization(xd[off:off + b]).cpu().numpy()
+        ref, _ = c_oracle.project(x[off:off + b], want_flip=True)
+        assert np.quantile(np.abs(r - ref), 0.9) < 1e-6
+        assert orth_err(r).max() < 1e-5
+    # non-contiguous input (every other row)
+    r = rr.symmetric_orthogonalization(xd[::2]).cpu().numpy()
+    assert np.quantile(np.abs(r - c_oracle.project(x[::2])), 0.9) < 1e-6
+
+
+def test_nan_rows_stay_local(rr):
+    x = torch.randn(300, 9, device=DEV)
+    x[7, 4] = float("nan")
+    x[200, 0] = float("inf")
+    r = rr.symmetric_orthogonalization(x)
+    bad = torch.isnan(r).reshape(300, -1).any(1)
+    assert bad[7] and bad[200] and int(bad.sum()) == 2
+
+
+def test_bf16_input(rr, c_oracle):
+    g = load_golden("g4_frobenius512.npz")
+    xb = torch.from_numpy(g["x_bf16_bits"]).view(torch.bfloat16).to(DEV)
+    r = rr.symmetric_orthogonalization(xb)
+    assert r.dtype == torch.float32
+    assert np.quantile(np.abs(r.cpu().numpy() - g["r"]), 0.99) < 5e-6
+    r16 = rr.symmetric_orthogonalization(xb.float().half())
+    assert orth_err(r16.cpu().numpy()).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 + K4 at BASELINE.json's full size (config #2: 1M rows)
+# ------------------------------------------------------------------------------------------------
+def test_config2_one_million_rows(rr, c_oracle):
+    g = load_golden("g6_stats_1m.npz")
+    n = int(g["n"])
+    torch.manual_seed(int(g["seed_x"]))
+    x = torch.randn(n, 9)
+    torch.manual_seed(int(g["seed_t"]))
+    t_in = torch.randn(n, 9)
+    assert np.array_equal(x[:64].numpy(), g["x_head"])
+    r, flip = rr.symmetric_orthogonalization_with_flip(x.to(DEV))
+    t = rr.symmetric_orthogonalization(t_in.to(DEV))
+    # every one of the 1M flip flags equals the reference's
+    assert np.array_equal(np.packbits(flip.cpu().numpy()), g["flip_bits"])
+    rc = r.cpu().numpy()
+    assert orth_err(rc).max() < 1e-5
+    assert np.abs(rc[:64] - g["r_head"]).max() < 1e-5
+    # mean geodesic angle vs the decoy target: the BASELINE metric
+    deg = rr.angle_error(r, t)
+    assert deg.dtype == torch.float64 and tuple(deg.shape) == (n,)
+    mean = deg.mean().item()
+    assert abs(mean - float(g["mean_angle_deg"])) < 1e-4            # vs the reference (float32 torch.svd)
+    assert abs(mean - float(g["mean_angle_deg_f64"])) < 1e-4        # vs the reference run in float64
+    sc = rr.angle_error_sum_count(r, t)
+    assert sc[1].item() == n and abs(sc[0].item() / n - mean) < 1e-9
+    # row by row against the float64 C oracle
+    ref = c_oracle.project(x.numpy())
+    err = np.abs(rc - ref).reshape(n, -1).max(1)
+    assert np.median(err) < 2e-7 and np.quantile(err, 0.999) < 3e-6
+    deg_or, _ = c_oracle.angle_error(rc, t.cpu().numpy())           # K4 against the oracle on identical inputs
+    assert np.abs(deg.cpu().numpy() - deg_or).max() < 1e-9
+
+
+def test_properties_at_full_size(rr):
+    n = 1_000_000
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    m = torch.randn(n, 3, 3, device=DEV, generator=gen)
+    r = rr.symmetric_orthogonalization(m)
+    # idempotence: a rotation projects to itself
+    rr2 = rr.symmetric_orthogonalization(r)
+    assert (rr2 - r).abs().max().item() < 2e-6
+    # scale invariance, including power-of-two and non-power-of-two factors
+    for f in (2.0 ** -40, 3.7e5):
+        assert (rr.symmetric_orthogonalization(m * f) - r).abs().median().item() < 2e-7
+    # equivariance proj(Q M P) = Q proj(M) P for rotations Q, P
+    q = rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen))
+    p = rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen))
+    lhs = rr.symmetric_orthogonalization(q @ m @ p)
+    rhs = q @ r @ p
+    d = (lhs - rhs).abs().reshape(n, -1).max(1).values
+    assert d.median().item() < 5e-7 and d.quantile(0.999).item() < 2e-5
+    # det = +1 and optimality: tr(R^T M) >= tr(T^T M) for any other rotation T
+    assert (torch.linalg.det(r.double()) - 1).abs().max().item() < 1e-5
+    gain = (r * m).sum((1, 2)) - (q * m).sum((1, 2))
+    assert gain.min().item() > -1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# K4 details
+# ------------------------------------------------------------------------------------------------
+def test_g3_angle_error_and_raise(rr):
+    g = load_golden("g3_angles.npz")
+    deg = rr.angle_error(dev(g["r1"]), dev(g["r2"]))
+    assert np.abs(deg.cpu().numpy() - g["deg"]).max() < 1e-9
+    with pytest.raises(ValueError, match="angle out of range, input probably not proper rotation matrices"):
+        rr.angle_error(dev(g["bad1"]), dev(g["bad2"]))
+    assert tuple(rr.angle_error(dev(g["bad1"]), dev(g["bad2"]), check=False).shape) == (3,)
+    assert np.abs(rr.angle_error(dev(g["nearly1"]), dev(g["nearly2"])).cpu().numpy() - g["deg_nearly"]).max() < 1e-12
+    assert tuple(rr.angle_error(torch.zeros(0, 3, 3, device=DEV), torch.zeros(0, 3, 3, device=DEV)).shape) == (0,)
+
+
+def test_g3_geodesic_radians(rr):
+    g = load_golden("g3_angles.npz")
+    rad = rr.compute_geodesic_distance_from_two_matrices(dev(g["r1"]), dev(g["r2"]))
+    assert rad.dtype == torch.float32 and tuple(rad.shape) == (256,)
+    got = rad.cpu().numpy().astype(np.float64)
+    assert np.abs(np.cos(got) - np.cos(g["rad"].astype(np.float64))).max() < 1e-6
+    assert np.abs(got[5:] - g["rad"][5:]).max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# K2 / K3: backward and the fused loss (config #4)
+# ------------------------------------------------------------------------------------------------
+def test_g4_backward_generic_gradient(rr):
+    g = load_golden("g4_frobenius512.npz")
+    x = torch.from_numpy(g["x_bf16_bits"]).view(torch.bfloat16).float().to(DEV).requires_grad_(True)
+    rr.symmetric_orthogonalization(x).backward(dev(g["g"]))
+    got = x.grad.cpu().numpy()
+    ref = g["dx_g_f64"]
+    rel = np.abs(got - ref).max(1) / (1e-3 + np.abs(ref).max(1))
+    rel_ref = np.abs(g["dx_g"] - ref).max(1) / (1e-3 + np.abs(ref).max(1))   # the reference's float32 autograd
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.99) < 1e-4
+    assert np.median(rel) <= 2 * np.median(rel_ref) + 1e-7
+
+
+def test_g4_config4_fused_head_loss_backward(rr):
+    g = load_golden("g4_frobenius512.npz")
+    xb = torch.from_numpy(g["x_bf16_bits"]).view(torch.bfloat16).to(DEV)
+    rt = dev(g["r_true"])
+    # (a) bf16 storage end to end: gradient comes back in bf16
+    x = xb.clone().requires_grad_(True)
+    loss, r = rr.frobenius_head(x, rt)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    assert abs(loss.item() - float(g["loss_f64"])) < 2e-6
+    assert np.quantile(np.abs(r.cpu().numpy() - g["r"]), 0.99) < 5e-6
+    assert x.grad.dtype == torch.bfloat16
+    ref = g["dx_f64"]
+    got = x.grad.float().cpu().numpy()
+    assert np.median(np.abs(got - ref).max(1) / (1e-6 + np.abs(ref).max(1))) < 4e-3      # bf16 rounding: 2^-8
+    # (b) float32 storage: tight against the float64 autograd of the reference
+    xf = xb.float().requires_grad_(True)
+    loss_f, _ = rr.frobenius_head(xf, rt)
+    (2.0 * loss_f).backward()                                # upstream scale must be honoured
+    got = xf.grad.cpu().numpy() / 2.0
+    rel = np.abs(got - ref).max(1) / (1e-6 + np.abs(ref).max(1))
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.99) < 1e-4
+    # (c) unfused path gives the same numbers
+    xu = xb.float().requires_grad_(True)
+    lu = rr.loss_frobenius(rt, rr.symmetric_orthogonalization(xu))
+    lu.backward()
+    assert abs(lu.item() - loss_f.item()) < 1e-6
+    assert (xu.grad - xf.grad / 2.0).abs().max().item() < 1e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_backward_matches_oracle_on_random_batch(rr, c_oracle):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((5000, 9)).astype(np.float32)
+    gup = rng.standard_normal((5000, 9)).astype(np.float32)
+    xd = dev(x).requires_grad_(True)
+    rr.symmetric_orthogonalization(xd).backward(dev(gup).view(-1, 3, 3))
+    ref = c_oracle.project_bwd(x, gup).reshape(5000, 9)
+    rel = np.abs(xd.grad.cpu().numpy() - ref).max(1) / (1e-3 + np.abs(ref).max(1))
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.99) < 2e-4
+    # the gradient is orthogonal to M's radial direction: proj(M) is scale invariant
+    radial = (xd.grad * xd.detach()).sum(1)
+    assert radial.abs().max().item() < 1e-3 * xd.grad.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------
+# K5: fused Kabsch (config #3 contract)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["6x1024", "24x64"])
+def test_g5_kabsch_golden(rr, tag):
+    g = load_golden("g5_kabsch_%s.npz" % tag)
+    r, h = rr.kabsch_rotation(dev(g["p"]), dev(g["q"]), return_h=True)
+    assert np.abs(h.cpu().numpy() - g["h"]).max() < 3e-6 * np.abs(g["h"]).max() + 1e-5
+    assert np.abs(r.cpu().numpy() - g["r_f64"]).max() < 5e-6
+    assert np.abs(r.cpu().numpy() - g["r"]).max() < 5e-6
+    assert orth_err(r.cpu().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("b,n", [(1, 1), (3, 7), (5, 64), (17, 65), (70, 200), (300, 1024), (4100, 256)])
+def test_kabsch_ragged(rr, c_oracle, b, n):
+    rng = np.random.default_rng(b * 1000 + n)
+    p = (rng.random((b, n, 3)) - 0.5).astype(np.float32)
+    q = (rng.random((b, n, 3)) - 0.5).astype(np.float32)
+    r, h = rr.kabsch_rotation(dev(p), dev(q), return_h=True)
+    ro, ho = c_oracle.kabsch(p, q, want_h=True)
+    assert np.abs(h.cpu().numpy() - ho).max() < 1e-5 * max(1.0, np.abs(ho).max())
+    assert orth_err(r.cpu().numpy()).max() < 1e-5
+    if n >= 64:                                             # H well conditioned -> R comparable
+        assert np.quantile(np.abs(r.cpu().numpy() - ro), 0.9) < 5e-5
+
+
+def test_config3_kabsch_recovers_rotations(rr):
+    """Round trip at a large size: Q = R_gt P (no noise) -> Kabsch returns R_gt."""
+    b, n = 8192, 1024
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    p = torch.rand(b, n, 3, device=DEV, generator=gen) - 0.5
+    r_gt = rr.symmetric_orthogonalization(torch.randn(b, 9, device=DEV, generator=gen))
+    q = torch.bmm(p, r_gt.transpose(1, 2))
+    r = rr.kabsch_rotation(p, q)
+    assert (r - r_gt).abs().max().item() < 5e-6
+    via_head = rr.symmetric_orthogonalization(torch.bmm(q.transpose(1, 2), p))     # the unfused spelling
+    assert (r - via_head).abs().max().item() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# the C ABI itself: streams, nullable outputs, error codes
+# ------------------------------------------------------------------------------------------------
+def test_c_abi_direct_on_side_stream(pa, c_oracle):
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(10_000, 9, device=DEV)
+    r = torch.empty(10_000, 9, device=DEV)
+    flip = torch.empty(10_000, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        rc = lib.so3_project_fwd_f32(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(r.data_ptr()),
+                                     ctypes.c_void_p(flip.data_ptr()), 10_000, ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0
+    side.synchronize()
+    ref, f = c_oracle.project(x.cpu().numpy(), want_flip=True)
+    assert np.quantile(np.abs(r.cpu().numpy().reshape(-1, 3, 3) - ref), 0.99) < 2e-6
+    assert np.array_equal(flip.cpu().numpy().astype(bool), f)
+    # sum_count / range_flag are zeroed by the call itself: call twice, get the same answer
+    sc = torch.full((2,), 123.0, dtype=torch.float64, device=DEV)
+    fl = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        rc = lib.so3_angle_error(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None,
+                                 ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(fl.data_ptr()), 0, 10_000,
+                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    assert sc[1].item() == 10_000 and fl.item() == 0 and sc[0].item() / 10_000 < 0.2
+
+
+def test_graph_capture_of_the_head(pa):
+    """Enqueue-only contract: the C-ABI launches can be captured into a hipGraph and replayed."""
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(4096, 9, device=DEV)
+    r = torch.zeros(4096, 9, device=DEV)
+    sc = torch.zeros(2, dtype=torch.float64, device=DEV)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.so3_project_fwd_f32(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(r.data_ptr()), None, 4096, st) == 0
+        assert lib.so3_angle_error(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None,
+                                   ctypes.c_void_p(sc.data_ptr()), None, 0, 4096, st) == 0
+    x.normal_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert orth_err(r.cpu().numpy()).max() < 1e-5 and sc[1].item() == 4096
