@@ -49,14 +49,26 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """CPU share of this process: cgroup quota if set, else affinity, capped at the 16 cores a one-GPU box grants."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("SO3_CPU_BASELINE_THREADS", "16"))))
+
+
 def cpu_baseline(rows: int):
     """The oracle's torch port (== the reference's ATen sequence) on the host cores, bounded sample."""
     from oracle import so3_oracle as so
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows, 9, generator=g)

@@ -27,6 +27,7 @@ namespace so3 {
 constexpr int kSweeps = 4;          // fixed; fp32 converges in 3 on Gaussian input (proto_jacobi.py)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
 constexpr float kTinyNorm2 = 1e-30f;
+constexpr float kTieBreak = 1.0f - 4e-6f;
 
 struct V3 {
     float x, y, z;
@@ -107,7 +108,10 @@ __device__ __forceinline__ SignedSvd signed_svd(const float (&m_in)[9]) {
 
     // 3. smallest column last, cyclic order kept (so det of the implied V stays +1)
     const float n0 = dot(a0, a0), n1 = dot(a1, a1), n2 = dot(a2, a2);
-    const bool z2 = (n2 <= n0) && (n2 <= n1);
+    // Ties (equal singular values to within a few ulp, e.g. diag(1,1,-1)) go to the LAST column, as
+    // LAPACK's ordering does: the reference then maps a pure reflection to the identity.
+    const float n2t = n2 * kTieBreak;
+    const bool z2 = (n2t <= n0) && (n2t <= n1);
     const bool z0 = (n0 <= n1);
     const V3 x = sel(z2, a0, sel(z0, a1, a2));
     const V3 y = sel(z2, a1, sel(z0, a2, a0));

@@ -76,7 +76,8 @@ def test_g2_adversarial(rr):
     assert np.abs(np.linalg.det(r.astype(np.float64)) - 1).max() < 1e-5
     unique = {"identity": 1e-6, "rank2_diag": 1e-6, "rank2_rot": 2e-5, "rotation": 1e-6, "rotation_scaled_1e-20": 1e-6,
               "rotation_scaled_1e+15": 1e-6, "near_equal_sv": 5e-6, "near_equal_sv_flip": 2e-6, "flip_close_s2_s3": 5e-4,
-              "tiny_s3_pos": 2e-6, "tiny_s3_neg": 2e-6, "graded": 2e-6, "upper_triangular": 2e-6, "permutation_even": 1e-6}
+              "tiny_s3_pos": 2e-6, "tiny_s3_neg": 2e-6, "graded": 1e-4,   # graded: s1/gap = 1e3 -> eps*1e3 (reference f32: 4e-5)
+              "upper_triangular": 2e-6, "permutation_even": 1e-6}
     for n, tol in unique.items():
         i = names.index(n)
         assert np.abs(r[i] - g["r_f64"][i]).max() < tol, n
