@@ -19,86 +19,164 @@
 // relative accuracy; measured against float64 LAPACK the result is closer than the reference's
 // own float32 LAPACK path (tools/proto_jacobi.py, DESIGN.md section "accuracy").
 // Rank <= 1 input (where the SVD is not unique) takes a rarely-executed divergent branch.
+//
+// The arithmetic is written once, generic over the "scalar" type T:
+//   T = float  : one matrix per lane;
+//   T = f32x2  : TWO matrices per lane, one in each half of a 64-bit register pair.  A Jacobi sweep
+//                is one long dependent chain, and a gfx950 SIMD issues dependent VALU instructions of
+//                one wave at only ~0.5/ns against ~0.9/ns for independent ones
+//                (tools/ubench/valu_rates.hip).  Packing two independent matrices into v_pk_fma_f32 /
+//                v_pk_mul_f32 / v_pk_add_f32 (which do two lanes' worth of work per issue slot) restores
+//                the full rate without relying on the scheduler to interleave two scalar streams.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace so3 {
 
-constexpr int kSweeps = 4;          // fixed; fp32 converges in 3 on Gaussian input (proto_jacobi.py)
+#ifndef SO3_SWEEPS
+#define SO3_SWEEPS 4
+#endif
+constexpr int kSweeps = SO3_SWEEPS;  // fixed; fp32 converges in 3-4 on Gaussian input (proto_jacobi.py)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
 constexpr float kTinyNorm2 = 1e-30f;
 constexpr float kTieBreak = 1.0f - 4e-6f;
 
-struct V3 {
-    float x, y, z;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// ---- scalar-type traits ------------------------------------------------------------------------------
+template <class T> struct Tr;
+template <> struct Tr<float> {
+    typedef bool mask;
+    typedef int ivec;
+    static constexpr int kLanes = 1;
+    static __device__ __forceinline__ float splat(float v) { return v; }
+    static __device__ __forceinline__ float get(float v, int) { return v; }
+    static __device__ __forceinline__ void set(float &v, int, float x) { v = x; }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return fmaf(a, b, c); }
+    static __device__ __forceinline__ float abs(float a) { return fabsf(a); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float copysign(float a, float b) { return copysignf(a, b); }
+    static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+    // exponent that brings x into [0.5, 1), clamped so that 2^e stays finite (denormal input)
+    static __device__ __forceinline__ int neg_frexp_exp(float x) { return min(-__builtin_amdgcn_frexp_expf(x), 126); }
+    static __device__ __forceinline__ float ldexp(float x, int e) { return ldexpf(x, e); }
+    static __device__ __forceinline__ float sel(bool c, float a, float b) { return c ? a : b; }
+    static __device__ __forceinline__ bool le(float a, float b) { return a <= b; }
+    static __device__ __forceinline__ bool ge(float a, float b) { return a >= b; }
+    static __device__ __forceinline__ bool gt(float a, float b) { return a > b; }
+    static __device__ __forceinline__ bool any(bool m) { return m; }
+    static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
+};
+template <> struct Tr<f32x2> {
+    typedef i32x2 mask;     // all-ones / zero per component
+    typedef i32x2 ivec;
+    static constexpr int kLanes = 2;
+    static __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
+    static __device__ __forceinline__ float get(f32x2 v, int i) { return i ? v.y : v.x; }
+    static __device__ __forceinline__ void set(f32x2 &v, int i, float x) { if (i) v.y = x; else v.x = x; }
+    static __device__ __forceinline__ f32x2 fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+    static __device__ __forceinline__ f32x2 abs(f32x2 a) { return __builtin_elementwise_abs(a); }
+    static __device__ __forceinline__ f32x2 max(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+    static __device__ __forceinline__ f32x2 copysign(f32x2 a, f32x2 b) { return f32x2{copysignf(a.x, b.x), copysignf(a.y, b.y)}; }
+    static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+    static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; }
+    static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+    static __device__ __forceinline__ i32x2 neg_frexp_exp(f32x2 x) {
+        return i32x2{min(-__builtin_amdgcn_frexp_expf(x.x), 126), min(-__builtin_amdgcn_frexp_expf(x.y), 126)};
+    }
+    static __device__ __forceinline__ f32x2 ldexp(f32x2 x, i32x2 e) { return f32x2{ldexpf(x.x, e.x), ldexpf(x.y, e.y)}; }
+    static __device__ __forceinline__ f32x2 sel(i32x2 c, f32x2 a, f32x2 b) { return f32x2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+    static __device__ __forceinline__ i32x2 le(f32x2 a, f32x2 b) { return i32x2{a.x <= b.x ? -1 : 0, a.y <= b.y ? -1 : 0}; }
+    static __device__ __forceinline__ i32x2 ge(f32x2 a, f32x2 b) { return i32x2{a.x >= b.x ? -1 : 0, a.y >= b.y ? -1 : 0}; }
+    static __device__ __forceinline__ i32x2 gt(f32x2 a, f32x2 b) { return i32x2{a.x > b.x ? -1 : 0, a.y > b.y ? -1 : 0}; }
+    static __device__ __forceinline__ bool any(i32x2 m) { return (m.x | m.y) != 0; }
+    static __device__ __forceinline__ bool lane_of(i32x2 m, int i) { return (i ? m.y : m.x) != 0; }
 };
 
-__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
-__device__ __forceinline__ V3 scale(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 axpy(float s, V3 a, V3 b) {   // s*a + b
-    return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z));
+// ---- 3-vectors over T -----------------------------------------------------------------------------
+template <class T> struct V3 {
+    T x, y, z;
+};
+template <class T> __device__ __forceinline__ V3<T> mk(T x, T y, T z) { return V3<T>{x, y, z}; }
+template <class T> __device__ __forceinline__ T dot(V3<T> a, V3<T> b) {
+    return Tr<T>::fma(a.z, b.z, Tr<T>::fma(a.y, b.y, a.x * b.x));
 }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) {
-    return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+template <class T> __device__ __forceinline__ V3<T> scale(V3<T> a, T s) { return mk<T>(a.x * s, a.y * s, a.z * s); }
+template <class T> __device__ __forceinline__ V3<T> axpy(T s, V3<T> a, V3<T> b) {   // s*a + b
+    return mk<T>(Tr<T>::fma(s, a.x, b.x), Tr<T>::fma(s, a.y, b.y), Tr<T>::fma(s, a.z, b.z));
 }
-__device__ __forceinline__ V3 sel(bool c, V3 a, V3 b) { return mk(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
-__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }      // v_rsq_f32, 1 ulp
-__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32, 1 ulp
+template <class T> __device__ __forceinline__ V3<T> cross(V3<T> a, V3<T> b) {
+    return mk<T>(Tr<T>::fma(a.y, b.z, -(a.z * b.y)), Tr<T>::fma(a.z, b.x, -(a.x * b.z)), Tr<T>::fma(a.x, b.y, -(a.y * b.x)));
+}
+template <class T> __device__ __forceinline__ V3<T> sel(typename Tr<T>::mask c, V3<T> a, V3<T> b) {
+    return mk<T>(Tr<T>::sel(c, a.x, b.x), Tr<T>::sel(c, a.y, b.y), Tr<T>::sel(c, a.z, b.z));
+}
 
 // Orthogonalise columns p and q by a plane rotation (p, q) <- (c p + s q, c q - s p).
 // With d = |p|^2 - |q|^2, g = 2 p.q, h = sqrt(d^2 + g^2):  (c, s) = (d + sgn(d) h, g) normalised,
 // i.e. tan(theta) = g / (d + sgn(d) h), |theta| <= pi/4 (up to a common sign of both new columns,
 // which a one-sided sweep does not care about).  Two transcendentals, no division.
-__device__ __forceinline__ void rotate(V3 &p, V3 &q) {
-    const float al = dot(p, p), be = dot(q, q), ga = dot(p, q);
-    const float d = al - be;
-    const float g = ga + ga;
-    const float gg = g * g;
-    const float h = fsqrt(fmaf(d, d, gg)) + kDelta;
-    const float ae = d + copysignf(h, d);
-    const float rw = rsq(fmaf(ae, ae, gg));
-    const float c = ae * rw, s = g * rw;
-    const V3 np = mk(fmaf(c, p.x, s * q.x), fmaf(c, p.y, s * q.y), fmaf(c, p.z, s * q.z));
-    const V3 nq = mk(fmaf(c, q.x, -(s * p.x)), fmaf(c, q.y, -(s * p.y)), fmaf(c, q.z, -(s * p.z)));
+template <class T> __device__ __forceinline__ void rotate(V3<T> &p, V3<T> &q) {
+    typedef Tr<T> R;
+    const T al = dot(p, p), be = dot(q, q), ga = dot(p, q);
+    const T d = al - be;
+    const T g = ga + ga;
+    const T gg = g * g;
+    const T h = R::sqrt(R::fma(d, d, gg)) + R::splat(kDelta);
+    const T ae = d + R::copysign(h, d);
+    const T rw = R::rsq(R::fma(ae, ae, gg));
+    const T c = ae * rw, s = g * rw;
+    const V3<T> np = mk<T>(R::fma(c, p.x, s * q.x), R::fma(c, p.y, s * q.y), R::fma(c, p.z, s * q.z));
+    const V3<T> nq = mk<T>(R::fma(c, q.x, -(s * p.x)), R::fma(c, q.y, -(s * p.y)), R::fma(c, q.z, -(s * p.z)));
     p = np;
     q = nq;
 }
 
 // A unit vector orthogonal to the unit vector u: e_k x u, k = index of the smallest |u_k| (z first).
-__device__ __forceinline__ V3 any_perp(V3 u) {
+__device__ __forceinline__ V3<float> any_perp(V3<float> u) {
     const float ax = fabsf(u.x), ay = fabsf(u.y), az = fabsf(u.z);
-    V3 w;
-    if (az <= ax && az <= ay) w = mk(-u.y, u.x, 0.f);
-    else if (ay <= ax) w = mk(u.z, 0.f, -u.x);
-    else w = mk(0.f, -u.z, u.y);
-    return scale(w, rsq(dot(w, w)));
+    V3<float> w;
+    if (az <= ax && az <= ay) w = mk<float>(-u.y, u.x, 0.f);
+    else if (ay <= ax) w = mk<float>(u.z, 0.f, -u.x);
+    else w = mk<float>(0.f, -u.z, u.y);
+    return scale<float>(w, __builtin_amdgcn_rsqf(dot(w, w)));
 }
 
-struct SignedSvd {
-    V3 u1, u2, u3;      // columns of U' (right-handed)
-    V3 v1, v2, v3;      // columns of V  (right-handed)
-    float s1, s2, s3;   // s3 carries the sign; in units of the PRESCALED matrix
-    float inv_scale;    // M_prescaled = M * 2^k ;  inv_scale = 2^k  (multiply gradients by it)
+template <class T> struct SignedSvd {
+    V3<T> u1, u2, u3;   // columns of U' (right-handed)
+    V3<T> v1, v2, v3;   // columns of V  (right-handed)
+    T s1, s2, s3;       // s3 carries the sign; in units of the PRESCALED matrix
+    T inv_scale;        // M_prescaled = M * 2^k ;  inv_scale = 2^k  (multiply gradients by it)
 };
 
+template <class T> __device__ __forceinline__ V3<float> lane3(V3<T> v, int i) {
+    return mk<float>(Tr<T>::get(v.x, i), Tr<T>::get(v.y, i), Tr<T>::get(v.z, i));
+}
+template <class T> __device__ __forceinline__ void set_lane3(V3<T> &v, int i, V3<float> s) {
+    Tr<T>::set(v.x, i, s.x); Tr<T>::set(v.y, i, s.y); Tr<T>::set(v.z, i, s.z);
+}
+
 // m: row-major 3x3 (m[3*i+j]).  WANT_S: also fill s1,s2,s3 (backward needs them).
-template <bool WANT_S>
-__device__ __forceinline__ SignedSvd signed_svd(const float (&m_in)[9]) {
-    SignedSvd o;
+template <bool WANT_S, class T>
+__device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
+    typedef Tr<T> R;
+    SignedSvd<T> o;
     // 1. exact power-of-two prescale: largest |entry| lands in [0.5, 1)
-    float mx = fmaxf(fmaxf(fabsf(m_in[0]), fabsf(m_in[1])), fabsf(m_in[2]));
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(m_in[3]), fabsf(m_in[4])), fabsf(m_in[5])));
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(m_in[6]), fabsf(m_in[7])), fabsf(m_in[8])));
-    const int ex = -__builtin_amdgcn_frexp_expf(mx);    // 0 for mx == 0; finite for inf/NaN too
-    float m[9];
+    T mx = R::max(R::max(R::abs(m_in[0]), R::abs(m_in[1])), R::abs(m_in[2]));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[3]), R::abs(m_in[4])), R::abs(m_in[5])));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[6]), R::abs(m_in[7])), R::abs(m_in[8])));
+    const typename R::ivec ex = R::neg_frexp_exp(mx);    // 0 for mx == 0; finite for inf/NaN too
+    const T sc = R::ldexp(R::splat(1.0f), ex);
+    T m[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) m[i] = ldexpf(m_in[i], ex);
-    o.inv_scale = ldexpf(1.0f, ex);
+    for (int i = 0; i < 9; ++i) m[i] = m_in[i] * sc;     // exact: sc is a power of two
+    o.inv_scale = sc;
 
     // 2. one-sided Jacobi on the columns
-    V3 a0 = mk(m[0], m[3], m[6]), a1 = mk(m[1], m[4], m[7]), a2 = mk(m[2], m[5], m[8]);
+    V3<T> a0 = mk<T>(m[0], m[3], m[6]), a1 = mk<T>(m[1], m[4], m[7]), a2 = mk<T>(m[2], m[5], m[8]);
 #pragma unroll
     for (int sweep = 0; sweep < kSweeps; ++sweep) {
         rotate(a0, a1);
@@ -106,73 +184,84 @@ __device__ __forceinline__ SignedSvd signed_svd(const float (&m_in)[9]) {
         rotate(a1, a2);
     }
 
-    // 3. smallest column last, cyclic order kept (so det of the implied V stays +1)
-    const float n0 = dot(a0, a0), n1 = dot(a1, a1), n2 = dot(a2, a2);
+    // 3. smallest column last, cyclic order kept (so det of the implied V stays +1).
     // Ties (equal singular values to within a few ulp, e.g. diag(1,1,-1)) go to the LAST column, as
     // LAPACK's ordering does: the reference then maps a pure reflection to the identity.
-    const float n2t = n2 * kTieBreak;
-    const bool z2 = (n2t <= n0) && (n2t <= n1);
-    const bool z0 = (n0 <= n1);
-    const V3 x = sel(z2, a0, sel(z0, a1, a2));
-    const V3 y = sel(z2, a1, sel(z0, a2, a0));
-    const V3 z = sel(z2, a2, sel(z0, a0, a1));
-    const float nx = z2 ? n0 : (z0 ? n1 : n2);
+    const T n0 = dot(a0, a0), n1 = dot(a1, a1), n2 = dot(a2, a2);
+    const T n2t = n2 * R::splat(kTieBreak);
+    const typename R::mask z2 = R::le(n2t, n0) & R::le(n2t, n1);
+    const typename R::mask z0 = R::le(n0, n1);
+    const V3<T> x = sel<T>(z2, a0, sel<T>(z0, a1, a2));
+    const V3<T> y = sel<T>(z2, a1, sel<T>(z0, a2, a0));
+    const V3<T> z = sel<T>(z2, a2, sel<T>(z0, a0, a1));
+    const T nx = R::sel(z2, n0, R::sel(z0, n1, n2));
 
-    V3 u1 = scale(x, rsq(nx));
-    V3 w = axpy(-dot(u1, y), u1, y);
-    float nw = dot(w, w);
-    V3 u2 = scale(w, rsq(nw));
-    const V3 mr0 = mk(m[0], m[1], m[2]), mr1 = mk(m[3], m[4], m[5]), mr2 = mk(m[6], m[7], m[8]);
-    V3 t1 = axpy(u1.z, mr2, axpy(u1.y, mr1, scale(mr0, u1.x)));     // M^T u1 = s1 v1
-    V3 t2 = axpy(u2.z, mr2, axpy(u2.y, mr1, scale(mr0, u2.x)));     // M^T u2 = s2 v2
-    float nt1 = dot(t1, t1);
-    V3 v1 = scale(t1, rsq(nt1));
-    V3 r2 = axpy(-dot(v1, t2), v1, t2);
-    float nr2 = dot(r2, r2);
-    V3 v2 = scale(r2, rsq(nr2));
+    V3<T> u1 = scale<T>(x, R::rsq(nx));
+    V3<T> w = axpy<T>(-dot(u1, y), u1, y);
+    T nw = dot(w, w);
+    V3<T> u2 = scale<T>(w, R::rsq(nw));
+    const V3<T> mr0 = mk<T>(m[0], m[1], m[2]), mr1 = mk<T>(m[3], m[4], m[5]), mr2 = mk<T>(m[6], m[7], m[8]);
+    V3<T> t1 = axpy<T>(u1.z, mr2, axpy<T>(u1.y, mr1, scale<T>(mr0, u1.x)));     // M^T u1 = s1 v1
+    V3<T> t2 = axpy<T>(u2.z, mr2, axpy<T>(u2.y, mr1, scale<T>(mr0, u2.x)));     // M^T u2 = s2 v2
+    T nt1 = dot(t1, t1);
+    V3<T> v1 = scale<T>(t1, R::rsq(nt1));
+    V3<T> r2 = axpy<T>(-dot(v1, t2), v1, t2);
+    T nr2 = dot(r2, r2);
+    V3<T> v2 = scale<T>(r2, R::rsq(nr2));
 
     // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.
     // (`<=` comparisons are false for NaN, so NaN input flows through the fast path to NaN output.)
-    if (__builtin_expect(nx <= kTinyNorm2 || nw <= kTinyNorm2 || nt1 <= kTinyNorm2 || nr2 <= kTinyNorm2, 0)) {
-        const bool b0 = (n0 >= n1) && (n0 >= n2);
-        const bool b1 = (n1 >= n2);
-        const V3 big = sel(b0, a0, sel(b1, a1, a2));
-        const float nb = b0 ? n0 : (b1 ? n1 : n2);
-        if (nb <= kTinyNorm2) {                      // M == 0  ->  identity (matches the reference)
-            u1 = mk(1.f, 0.f, 0.f);
-            v1 = u1;
-        } else {
-            u1 = scale(big, rsq(nb));
-            t1 = axpy(u1.z, mr2, axpy(u1.y, mr1, scale(mr0, u1.x)));
-            v1 = scale(t1, rsq(dot(t1, t1)));
+    const T tiny = R::splat(kTinyNorm2);
+    const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, tiny) | R::le(nt1, tiny) | R::le(nr2, tiny);
+    if (__builtin_expect(R::any(degenerate), 0)) {
+#pragma unroll
+        for (int i = 0; i < R::kLanes; ++i) {
+            if (!R::lane_of(degenerate, i)) continue;
+            const float f0 = R::get(n0, i), f1 = R::get(n1, i), f2 = R::get(n2, i);
+            const bool b0 = (f0 >= f1) && (f0 >= f2);
+            const bool b1 = (f1 >= f2);
+            const V3<float> big = b0 ? lane3<T>(a0, i) : (b1 ? lane3<T>(a1, i) : lane3<T>(a2, i));
+            const float nb = b0 ? f0 : (b1 ? f1 : f2);
+            const V3<float> q0 = lane3<T>(mr0, i), q1 = lane3<T>(mr1, i), q2 = lane3<T>(mr2, i);
+            V3<float> su1, sv1;
+            if (nb <= kTinyNorm2) {                  // M == 0  ->  identity (matches the reference)
+                su1 = mk<float>(1.f, 0.f, 0.f);
+                sv1 = su1;
+            } else {
+                su1 = scale<float>(big, __builtin_amdgcn_rsqf(nb));
+                const V3<float> st1 = axpy<float>(su1.z, q2, axpy<float>(su1.y, q1, scale<float>(q0, su1.x)));
+                sv1 = scale<float>(st1, __builtin_amdgcn_rsqf(dot(st1, st1)));
+            }
+            set_lane3<T>(u1, i, su1);
+            set_lane3<T>(v1, i, sv1);
+            set_lane3<T>(u2, i, any_perp(su1));
+            set_lane3<T>(v2, i, any_perp(sv1));
+            if (WANT_S) { R::set(nt1, i, nb); R::set(nr2, i, 0.f); }
         }
-        u2 = any_perp(u1);
-        v2 = any_perp(v1);
-        if (WANT_S) { nt1 = nb; nr2 = 0.f; }
     }
-    o.u1 = u1; o.u2 = u2; o.u3 = cross(u1, u2);
-    o.v1 = v1; o.v2 = v2; o.v3 = cross(v1, v2);
+    o.u1 = u1; o.u2 = u2; o.u3 = cross<T>(u1, u2);
+    o.v1 = v1; o.v2 = v2; o.v3 = cross<T>(v1, v2);
     if (WANT_S) {
         // s_k = u_k^T M v_k; cheaper: |M^T u_k| for k = 1,2 and u3 . z for the signed one.
-        o.s1 = nt1 * rsq(fmaxf(nt1, kTinyNorm2));
-        o.s2 = nr2 * rsq(fmaxf(nr2, kTinyNorm2));
+        o.s1 = nt1 * R::rsq(R::max(nt1, tiny));
+        o.s2 = nr2 * R::rsq(R::max(nr2, tiny));
         o.s3 = dot(o.u3, z);
     } else {
-        o.s1 = o.s2 = o.s3 = 0.f;
+        o.s1 = o.s2 = o.s3 = R::splat(0.f);
     }
     return o;
 }
 
 // R = U' V^T, row-major.
-__device__ __forceinline__ void rotation_from(const SignedSvd &f, float (&r)[9]) {
-    const float ux[3] = {f.u1.x, f.u2.x, f.u3.x}, uy[3] = {f.u1.y, f.u2.y, f.u3.y}, uz[3] = {f.u1.z, f.u2.z, f.u3.z};
-    const V3 v[3] = {f.v1, f.v2, f.v3};
-    V3 r0 = scale(v[0], ux[0]), r1 = scale(v[0], uy[0]), r2 = scale(v[0], uz[0]);
+template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd<T> &f, T (&r)[9]) {
+    const T ux[3] = {f.u1.x, f.u2.x, f.u3.x}, uy[3] = {f.u1.y, f.u2.y, f.u3.y}, uz[3] = {f.u1.z, f.u2.z, f.u3.z};
+    const V3<T> v[3] = {f.v1, f.v2, f.v3};
+    V3<T> r0 = scale<T>(v[0], ux[0]), r1 = scale<T>(v[0], uy[0]), r2 = scale<T>(v[0], uz[0]);
 #pragma unroll
     for (int k = 1; k < 3; ++k) {
-        r0 = axpy(ux[k], v[k], r0);
-        r1 = axpy(uy[k], v[k], r1);
-        r2 = axpy(uz[k], v[k], r2);
+        r0 = axpy<T>(ux[k], v[k], r0);
+        r1 = axpy<T>(uy[k], v[k], r1);
+        r2 = axpy<T>(uz[k], v[k], r2);
     }
     r[0] = r0.x; r[1] = r0.y; r[2] = r0.z;
     r[3] = r1.x; r[4] = r1.y; r[5] = r1.z;
@@ -187,27 +276,29 @@ __device__ __forceinline__ bool det_negative(const float (&m)[9]) {
 }
 
 // dM = U' Bm V^T for upstream G (row-major), Bm_ij = (A_ij - A_ji)/(s_i + s_j), A = U'^T G V.
-__device__ __forceinline__ void project_backward(const SignedSvd &f, const float (&g)[9], float (&dm)[9]) {
-    const V3 g0 = mk(g[0], g[1], g[2]), g1 = mk(g[3], g[4], g[5]), g2 = mk(g[6], g[7], g[8]);
+template <class T>
+__device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T (&g)[9], T (&dm)[9]) {
+    typedef Tr<T> R;
+    const V3<T> g0 = mk<T>(g[0], g[1], g[2]), g1 = mk<T>(g[3], g[4], g[5]), g2 = mk<T>(g[6], g[7], g[8]);
     // G v_j
-    const V3 gv1 = mk(dot(g0, f.v1), dot(g1, f.v1), dot(g2, f.v1));
-    const V3 gv2 = mk(dot(g0, f.v2), dot(g1, f.v2), dot(g2, f.v2));
-    const V3 gv3 = mk(dot(g0, f.v3), dot(g1, f.v3), dot(g2, f.v3));
-    const float a12 = dot(f.u1, gv2), a21 = dot(f.u2, gv1);
-    const float a13 = dot(f.u1, gv3), a31 = dot(f.u3, gv1);
-    const float a23 = dot(f.u2, gv3), a32 = dot(f.u3, gv2);
-    const float floor_ = fmaf(1e-12f, f.s1, 1e-30f);
-    const float k = f.inv_scale;                     // singular values are in prescaled units
-    const float b12 = (a12 - a21) * k * frcp(fmaxf(f.s1 + f.s2, floor_));
-    const float b13 = (a13 - a31) * k * frcp(fmaxf(f.s1 + f.s3, floor_));
-    const float b23 = (a23 - a32) * k * frcp(fmaxf(f.s2 + f.s3, floor_));
+    const V3<T> gv1 = mk<T>(dot(g0, f.v1), dot(g1, f.v1), dot(g2, f.v1));
+    const V3<T> gv2 = mk<T>(dot(g0, f.v2), dot(g1, f.v2), dot(g2, f.v2));
+    const V3<T> gv3 = mk<T>(dot(g0, f.v3), dot(g1, f.v3), dot(g2, f.v3));
+    const T a12 = dot(f.u1, gv2), a21 = dot(f.u2, gv1);
+    const T a13 = dot(f.u1, gv3), a31 = dot(f.u3, gv1);
+    const T a23 = dot(f.u2, gv3), a32 = dot(f.u3, gv2);
+    const T floor_ = R::fma(R::splat(1e-12f), f.s1, R::splat(1e-30f));
+    const T k = f.inv_scale;                         // singular values are in prescaled units
+    const T b12 = (a12 - a21) * k * R::rcp(R::max(f.s1 + f.s2, floor_));
+    const T b13 = (a13 - a31) * k * R::rcp(R::max(f.s1 + f.s3, floor_));
+    const T b23 = (a23 - a32) * k * R::rcp(R::max(f.s2 + f.s3, floor_));
     // T = U' Bm : t1 = -b12 u2 - b13 u3 ; t2 = b12 u1 - b23 u3 ; t3 = b13 u1 + b23 u2
-    const V3 t1 = axpy(-b12, f.u2, scale(f.u3, -b13));
-    const V3 t2 = axpy(b12, f.u1, scale(f.u3, -b23));
-    const V3 t3 = axpy(b13, f.u1, scale(f.u2, b23));
-    const V3 r0 = axpy(t3.x, f.v3, axpy(t2.x, f.v2, scale(f.v1, t1.x)));
-    const V3 r1 = axpy(t3.y, f.v3, axpy(t2.y, f.v2, scale(f.v1, t1.y)));
-    const V3 r2 = axpy(t3.z, f.v3, axpy(t2.z, f.v2, scale(f.v1, t1.z)));
+    const V3<T> t1 = axpy<T>(-b12, f.u2, scale<T>(f.u3, -b13));
+    const V3<T> t2 = axpy<T>(b12, f.u1, scale<T>(f.u3, -b23));
+    const V3<T> t3 = axpy<T>(b13, f.u1, scale<T>(f.u2, b23));
+    const V3<T> r0 = axpy<T>(t3.x, f.v3, axpy<T>(t2.x, f.v2, scale<T>(f.v1, t1.x)));
+    const V3<T> r1 = axpy<T>(t3.y, f.v3, axpy<T>(t2.y, f.v2, scale<T>(f.v1, t1.y)));
+    const V3<T> r2 = axpy<T>(t3.z, f.v3, axpy<T>(t2.z, f.v2, scale<T>(f.v1, t1.z)));
     dm[0] = r0.x; dm[1] = r0.y; dm[2] = r0.z;
     dm[3] = r1.x; dm[4] = r1.y; dm[5] = r1.z;
     dm[6] = r2.x; dm[7] = r2.y; dm[8] = r2.z;

@@ -12,10 +12,17 @@
 
 #include "../../include/so3proj.h"
 #include "so3_device.h"
+#include "so3_stream.h"
 
 namespace {
 
-using so3::SignedSvd;
+
+#ifndef SO3_STREAM_NPL
+#define SO3_STREAM_NPL 2                    // matrices per lane in the streaming K1 kernel (1 or 2)
+#endif
+#ifndef SO3_STREAM_WAVES_PER_SIMD
+#define SO3_STREAM_WAVES_PER_SIMD 3         // persistent waves per SIMD launched by the streaming kernel
+#endif
 
 constexpr int kBlock = 256;                 // lanes (= 3x3 blocks) per workgroup tile
 constexpr int kTileFloats = kBlock * 9;     // 2304 floats = 9216 B
@@ -118,13 +125,14 @@ __global__ __launch_bounds__(kBlock) void k_project_fwd(const void *__restrict__
     float m[9], r[9];
     const bool active = static_cast<int>(threadIdx.x) < n;
     lane_get(tile, active, m);
-    const SignedSvd f = so3::signed_svd<false>(m);
+    const auto f = so3::signed_svd<false>(m);
     so3::rotation_from(f, r);
     if (FLIP && active) flip[first + threadIdx.x] = so3::det_negative(m) ? 1 : 0;
     lane_put(tile, r);          // each lane overwrites only the nine words it alone has read
     __syncthreads();
     tile_out<false, VEC>(R, first, n, tile);
 }
+
 
 // ---- K2 -------------------------------------------------------------------------------------------
 template <bool BF16, bool VEC>
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bwd(const void *__restrict__
     const bool active = static_cast<int>(threadIdx.x) < n;
     lane_get(tile_m, active, m);
     lane_get(tile_g, active, g);
-    const SignedSvd f = so3::signed_svd<true>(m);
+    const auto f = so3::signed_svd<true>(m);
     so3::project_backward(f, g, dm);
     lane_put(tile_m, dm);
     __syncthreads();
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
     const bool active = static_cast<int>(threadIdx.x) < n;
     lane_get(tile_m, active, m);
     lane_get(tile_t, active, t);
-    const SignedSvd f = so3::signed_svd<WANT_DM>(m);
+    const auto f = so3::signed_svd<WANT_DM>(m);
     so3::rotation_from(f, r);
     float n2 = 0.f;
 #pragma unroll
@@ -187,8 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
         g[i] = r[i] - t[i];                       // d||Rtrue - R||/dR = (R - Rtrue)/||.||
         n2 = fmaf(g[i], g[i], n2);
     }
-    const float nrm = n2 * so3::rsq(fmaxf(n2, 1e-37f));
-    const float gs = (n2 > 0.f) ? inv_b * so3::rsq(n2) : 0.f;    // zero difference -> zero gradient
+    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+    const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;    // zero difference -> zero gradient
     const double total = block_sum(active ? static_cast<double>(nrm) : 0.0, red);
     if (threadIdx.x == 0) atomicAdd(loss_sum, total);
     if (WANT_DM) {
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
         }
     }
     const bool active = lane < nc;
-    const SignedSvd f = so3::signed_svd<false>(h);
+    const auto f = so3::signed_svd<false>(h);
     float r[9];
     so3::rotation_from(f, r);
     if (active) {
@@ -398,13 +406,40 @@ int so3_version(void) { return SO3PROJ_VERSION; }
 const char *so3_last_error(void) { return g_err; }
 
 
+// Streaming launch geometry: one resident wave slot per (CU, SIMD, slot), tiles dealt round-robin.
+static unsigned stream_grid(int64_t ntiles /* wave rounds */, int waves_per_simd) {
+    const int64_t max_blocks = 256LL * waves_per_simd;                 // 256 CUs x (4 SIMDs x slots / 4 waves per block)
+    const int64_t want = (ntiles + so3::kWavesPerBlock - 1) / so3::kWavesPerBlock;
+    return static_cast<unsigned>(want < max_blocks ? want : max_blocks);
+}
+
 static int project_fwd(bool bf16, const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(M != nullptr && R != nullptr, "so3_project_fwd: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(B)), block(kBlock);
+    const dim3 block(kBlock);
     const bool vec = (bf16 || aligned16(M)) && aligned16(R);   // for bf16 input VEC only governs the R store
+    constexpr int kNpl = SO3_STREAM_NPL;                       // matrices per lane in the streaming kernel
+    if (!bf16 && vec && B >= so3::kUnitRows) {
+        // full 64-row units stream through the persistent kernel; a < 64-row remainder goes to the block-tile kernel
+        const int64_t nunits = B / so3::kUnitRows;
+        const dim3 sgrid(stream_grid((nunits + kNpl - 1) / kNpl, SO3_STREAM_WAVES_PER_SIMD));
+        const float *Mf = static_cast<const float *>(M);
+        if (flip) hipLaunchKernelGGL((so3::k_project_fwd_stream<kNpl, true, SO3_STREAM_WAVES_PER_SIMD>), sgrid, block, 0, s, Mf, R, flip, nunits, nullptr);
+        else hipLaunchKernelGGL((so3::k_project_fwd_stream<kNpl, false, SO3_STREAM_WAVES_PER_SIMD>), sgrid, block, 0, s, Mf, R, flip, nunits, nullptr);
+        const int64_t done = nunits * so3::kUnitRows;
+        if (done < B) {
+            const void *Mt = Mf + done * 9;
+            float *Rt = R + done * 9;
+            uint8_t *ft = flip ? flip + done : nullptr;
+            const int64_t rest = B - done;
+            if (flip) hipLaunchKernelGGL((k_project_fwd<false, false, true>), dim3(1), block, 0, s, Mt, Rt, ft, rest);
+            else hipLaunchKernelGGL((k_project_fwd<false, false, false>), dim3(1), block, 0, s, Mt, Rt, ft, rest);
+        }
+        return check_launch("so3_project_fwd");
+    }
+    const dim3 grid(grid_for(B));
 #define LAUNCH(BF, VE, FL) hipLaunchKernelGGL((k_project_fwd<BF, VE, FL>), grid, block, 0, s, M, R, flip, B)
 #define PICK(BF) do { if (vec) { if (flip) LAUNCH(BF, true, true); else LAUNCH(BF, true, false); } \
                       else { if (flip) LAUNCH(BF, false, true); else LAUNCH(BF, false, false); } } while (0)

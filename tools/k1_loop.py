@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Launch K1 (1M rows, rotating buffers) N times -- the program rocprofv3 wraps for kernel traces / PMC passes."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from poseestimation_amd import _lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+lib = _lib.load()
+dev = torch.device("cuda:0")
+nb = 8
+xs = [torch.randn(rows, 9, device=dev) for _ in range(nb)]
+outs = [torch.empty(rows, 9, device=dev) for _ in range(nb)]
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+for i in range(n):
+    lib.so3_project_fwd_f32(ctypes.c_void_p(xs[i % nb].data_ptr()), ctypes.c_void_p(outs[i % nb].data_ptr()), None, rows, st)
+torch.cuda.synchronize()
+print("done", n)

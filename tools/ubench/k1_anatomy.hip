@@ -1,0 +1,90 @@
+// k1_anatomy: stand-alone timing / in-kernel-stamp tool for the streaming K1 kernel.
+// Instantiates the SAME kernel template the library ships (csrc/so3_stream.h) in several
+// geometries, times each with hipEvents over rotating buffers, and (STAMP build of the same
+// template) reports per-wave lifetimes and the shader clock from s_memtime / s_memrealtime.
+// Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -o k1_anatomy k1_anatomy.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "../../poseestimation_amd/csrc/so3_stream.h"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+constexpr int64_t ROWS = 1000000;
+constexpr int NBUF = 8;
+
+__global__ void fill(float *p, int64_t n, unsigned seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        p[i] = ((h & 0xFFFFFF) / 8388608.0f - 1.0f) * 1.7f;      // uniform(-1.7, 1.7): unit-ish variance, generic matrices
+    }
+}
+
+template <int NPL, int WPS>
+void run(float **in, float **out, unsigned long long *stamps_d) {
+    const int64_t nunits = ROWS / 64;
+    const int64_t rounds = (nunits + NPL - 1) / NPL;
+    const int64_t want = (rounds + 3) / 4;
+    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * WPS);
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i)
+        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+    CHECK(hipDeviceSynchronize());
+    const int K = 40;
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < K; ++i)
+        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / K;
+    // stamped build of the same template: wave lifetimes and clock
+    hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, true>), dim3(blocks), dim3(256), 0, 0, in[0], out[0], nullptr, nunits, stamps_d);
+    CHECK(hipDeviceSynchronize());
+    const int64_t nw = std::min<int64_t>((int64_t)blocks * 4, rounds);
+    std::vector<unsigned long long> st(4 * nw);
+    CHECK(hipMemcpy(st.data(), stamps_d, st.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long r0 = ~0ull, r1 = 0; double life = 0, clk = 0; std::vector<double> starts;
+    for (int64_t w = 0; w < nw; ++w) {
+        r0 = std::min(r0, st[4 * w]); r1 = std::max(r1, st[4 * w + 1]);
+        life += (double)(st[4 * w + 1] - st[4 * w]);
+        clk += (double)(st[4 * w + 3] & 0xFFFFFFFull) / (double)(st[4 * w + 1] - st[4 * w]);
+    }
+    for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st[4 * w] - r0) * 0.01);
+    std::sort(starts.begin(), starts.end());
+    {   // per-wave dump for offline analysis: wave, rounds, start_us, end_us, cycles, hw_id, xcc
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_npl%d_wps%d.csv", NPL, WPS);
+        FILE *fh = fopen(name, "w");
+        if (fh) {
+            fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc\n");
+            const int64_t nwv = (int64_t)blocks * 4;
+            for (int64_t w = 0; w < nw; ++w) {
+                const int64_t nr = (rounds - w + nwv - 1) / nwv;
+                fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu\n", (long long)w, (long long)nr, (double)(st[4 * w] - r0) * 0.01,
+                        (double)(st[4 * w + 1] - r0) * 0.01, st[4 * w + 3] & 0xFFFFFFFull, st[4 * w + 3] >> 32, (st[4 * w + 3] >> 28) & 0xF);
+            }
+            fclose(fh);
+        }
+    }
+    printf("NPL=%d WPS=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+           "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
+           NPL, WPS, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
+}
+
+int main() {
+    float *in[NBUF], *out[NBUF];
+    for (int i = 0; i < NBUF; ++i) {
+        CHECK(hipMalloc(&in[i], ROWS * 9 * 4)); CHECK(hipMalloc(&out[i], ROWS * 9 * 4));
+        hipLaunchKernelGGL(fill, dim3((ROWS * 9 + 255) / 256), dim3(256), 0, 0, in[i], ROWS * 9, 1234u + i);
+    }
+    unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 4 * 8192 * 4));
+    CHECK(hipDeviceSynchronize());
+    run<1, 8>(in, out, stamps);
+    run<2, 4>(in, out, stamps);
+    run<2, 3>(in, out, stamps);
+    return 0;
+}
