@@ -15,16 +15,19 @@
 
 constexpr int64_t ROWS = 1000000;
 constexpr int NBUF = 8;
+static int g_launches = 40;
 
 __global__ void fill(float *p, int64_t n, unsigned seed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
-        p[i] = ((h & 0xFFFFFF) / 8388608.0f - 1.0f) * 1.7f;      // uniform(-1.7, 1.7): unit-ish variance, generic matrices
+        unsigned h2 = h * 747796405u + 2891336453u; h2 ^= h2 >> 16; h2 *= 2246822519u; h2 ^= h2 >> 13;
+        const float u1 = ((h & 0xFFFFFF) + 1) / 16777217.0f, u2 = (h2 & 0xFFFFFF) / 16777216.0f;
+        p[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);  // N(0,1) (Box-Muller): the benchmark's distribution
     }
 }
 
-template <int NPL, int WPS>
+template <int NPL, int WPS, int SWEEPS, bool ADAPT>
 void run(float **in, float **out, unsigned long long *stamps_d) {
     const int64_t nunits = ROWS / 64;
     const int64_t rounds = (nunits + NPL - 1) / NPL;
@@ -32,17 +35,17 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
     const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * WPS);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
     CHECK(hipDeviceSynchronize());
-    const int K = 40;
+    const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
-    hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, true>), dim3(blocks), dim3(256), 0, 0, in[0], out[0], nullptr, nunits, stamps_d);
+    hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, true, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[0], out[0], nullptr, nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
     const int64_t nw = std::min<int64_t>((int64_t)blocks * 4, rounds);
     std::vector<unsigned long long> st(4 * nw);
@@ -56,7 +59,7 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
     for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st[4 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
     {   // per-wave dump for offline analysis: wave, rounds, start_us, end_us, cycles, hw_id, xcc
-        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_npl%d_wps%d.csv", NPL, WPS);
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_npl%d_wps%d_s%d%s.csv", NPL, WPS, SWEEPS, ADAPT ? "a" : "");
         FILE *fh = fopen(name, "w");
         if (fh) {
             fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc\n");
@@ -69,9 +72,9 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
             fclose(fh);
         }
     }
-    printf("NPL=%d WPS=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("NPL=%d WPS=%d sweeps=%d%s blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           NPL, WPS, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
 }
 
@@ -83,8 +86,12 @@ int main() {
     }
     unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 4 * 8192 * 4));
     CHECK(hipDeviceSynchronize());
-    run<1, 8>(in, out, stamps);
-    run<2, 4>(in, out, stamps);
-    run<2, 3>(in, out, stamps);
+    for (int k : {40, 200, 1000, 40}) {
+        g_launches = k;
+        printf("--- %d timed launches per measurement\n", k);
+        run<2, 4, -1, false>(in, out, stamps);     // copy through the same path: the data-movement floor
+        run<2, 3, 3, true>(in, out, stamps);
+        run<2, 3, 4, false>(in, out, stamps);
+    }
     return 0;
 }
