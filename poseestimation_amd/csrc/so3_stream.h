@@ -121,11 +121,11 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         wave_lds_fence();
         const int64_t tn = t + nwaves;
         const bool more = tn < nrounds;
-        const int64_t tf = more ? tn : t;                   // last round re-reads its own units: harmless L2 hits
+        const int64_t tf = more ? tn : t;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {                     // prefetch: in flight during the sweeps below
-            const int64_t u = tf * NPL + k;
-            unit_fetch(in[k], unit_rsrc(M, u < nunits ? u : tf * NPL, true), lane);
+        for (int k = 0; k < NPL; ++k) {                     // prefetch: in flight during the sweeps below.
+            const int64_t u = tf * NPL + k;                 // After the last round the descriptor is empty: the
+            unit_fetch(in[k], unit_rsrc(M, u < nunits ? u : tf * NPL, more), lane);   // loads return 0, no traffic
         }
         if constexpr (SWEEPS < 0) {                         // diagnostic: pure data movement, no arithmetic
 #pragma unroll
