@@ -180,4 +180,80 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
 }
 
 
+// ---- K4, streaming form ---------------------------------------------------------------------------------
+// theta = acos(clamp((tr(R1^T R2) - 1)/2)) in float64 on float32 data (rotation_representation.py:230-242).
+// 1024-thread workgroups (16 waves, two per CU), each wave walks units w, w+W, ... with the same
+// wave-private LDS staging as K1 and keeps a per-lane float64 partial sum; ONE atomicAdd per workgroup then
+// carries the fused (sum) reduction -- same-address float64 atomics cost ~12 ns each, so a per-tile atomic
+// (thousands per launch) would dominate the kernel.
+constexpr int kAngleBlock = 1024;
+constexpr int kAngleWaves = kAngleBlock / 64;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool WANT_DEG, bool WANT_SUM>
+__global__ __launch_bounds__(kAngleBlock) void k_angle_error_stream(const float *__restrict__ R1, const float *__restrict__ R2,
+                                                                    double *__restrict__ out, double *__restrict__ sum_count,
+                                                                    int32_t *__restrict__ range_flag, double unit_scale,
+                                                                    int64_t nunits) {
+    __shared__ __attribute__((aligned(16))) float lds[kAngleWaves][2][kUnitFloats];
+    __shared__ double red[kAngleWaves];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float(*tile)[kUnitFloats] = lds[wave_in_block];
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kAngleWaves;
+    const int idx3 = lane < 16 ? lane + 128 : lane;
+    double acc = 0.0;
+    bool any_bad = false;
+    int64_t t = static_cast<int64_t>(blockIdx.x) * kAngleWaves + wave_in_block;
+    if (t < nunits) {
+        f32x4 in[2][3];
+        unit_fetch(in[0], unit_rsrc(R1, t, true), lane);
+        unit_fetch(in[1], unit_rsrc(R2, t, true), lane);
+        while (true) {
+            unit_to_lds(tile[0], in[0], lane, idx3);
+            unit_to_lds(tile[1], in[1], lane, idx3);
+            wave_lds_fence();
+            float a[9], b[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { a[i] = tile[0][lane * 9 + i]; b[i] = tile[1][lane * 9 + i]; }
+            wave_lds_fence();
+            const int64_t tn = t + nwaves;
+            const bool more = tn < nunits;
+            unit_fetch(in[0], unit_rsrc(R1, more ? tn : t, more), lane);      // prefetch (empty descriptor at the end)
+            unit_fetch(in[1], unit_rsrc(R2, more ? tn : t, more), lane);
+            double tr = 0.0;                                 // tr(R1^T R2) = sum_ij R1_ij R2_ij, float64
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(a[i]), static_cast<double>(b[i]), tr);
+            const double c_raw = (tr - 1.0) * 0.5;
+            any_bad |= (c_raw < -1.1 || c_raw > 1.1);        // NaN compares false, as torch.any(...) does
+            double c = fmin(fmax(c_raw, -1.0), 1.0);         // torch.clamp ...
+            if (c_raw != c_raw) c = c_raw;                   // ... which keeps NaN (fmin/fmax drop it)
+            const double ang = acos(c) * unit_scale;
+            if (WANT_DEG) out[t * kUnitRows + lane] = ang;
+            if (WANT_SUM) acc += ang;
+            if (!more) break;
+            t = tn;
+        }
+    }
+    if (range_flag != nullptr && __any(any_bad)) {
+        if (lane == 0) atomicOr(range_flag, 1);
+    }
+    if (WANT_SUM) {
+        acc = wave_sum_f64(acc);
+        if (lane == 0) red[wave_in_block] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double total = 0.0;
+#pragma unroll
+            for (int w = 0; w < kAngleWaves; ++w) total += red[w];
+            atomicAdd(sum_count, total);
+        }
+    }
+}
+
 }  // namespace so3

@@ -243,10 +243,14 @@ __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict_
     if (WANT_SUM) {
         const double total = block_sum(active ? ang : 0.0, red);
         if (threadIdx.x == 0) {
-            atomicAdd(sum_count, total);
-            atomicAdd(sum_count + 1, static_cast<double>(n));
+            atomicAdd(sum_count, total);       // the row count is written once by k_set_count
         }
     }
+}
+
+__global__ void k_angle_init(double *sum_count, int32_t *range_flag, double count) {
+    if (sum_count) { sum_count[0] = 0.0; sum_count[1] = count; }
+    if (range_flag) *range_flag = 0;
 }
 
 // float32 radians variant (rotation_representation.py:209-227): tr(m1 m2^T) in float32, hard clamp.
@@ -489,20 +493,30 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
                     int radians, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipSuccess;
-    if (sum_count) e = hipMemsetAsync(sum_count, 0, 2 * sizeof(double), s);
-    if (e == hipSuccess && range_flag) e = hipMemsetAsync(range_flag, 0, sizeof(int32_t), s);
-    if (e != hipSuccess) return fail((int)e, "so3_angle_error: memset");
+    // one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
+    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
-    const dim3 grid(grid_for(B)), block(kBlock);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
     const bool vec = aligned16(R1) && aligned16(R2);
-#define LAUNCH(VE, WD, WS) hipLaunchKernelGGL((k_angle_error<VE, WD, WS>), grid, block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B)
-#define PICK(VE) do { if (deg && sum_count) LAUNCH(VE, true, true); else if (deg) LAUNCH(VE, true, false); else if (sum_count) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
-    if (vec) PICK(true); else PICK(false);
-#undef PICK
+    const int64_t nunits = vec ? B / so3::kUnitRows : 0;       // full 64-row units take the streaming kernel
+    const int64_t done = nunits * so3::kUnitRows;
+    if (nunits > 0) {
+        const int64_t want = (nunits + so3::kAngleWaves - 1) / so3::kAngleWaves;
+        const dim3 sgrid(static_cast<unsigned>(want < 512 ? want : 512)), sblock(so3::kAngleBlock);
+#define SLAUNCH(WD, WS) hipLaunchKernelGGL((so3::k_angle_error_stream<WD, WS>), sgrid, sblock, 0, s, R1, R2, deg, sum_count, range_flag, unit, nunits)
+        if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
+#undef SLAUNCH
+    }
+    if (done < B) {                                            // remainder (< 64 rows) or unaligned input
+        const int64_t rest = B - done;
+        const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
+        double *dg = deg ? deg + done : nullptr;
+        const dim3 grid(grid_for(rest)), block(kBlock);
+#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_error<false, WD, WS>), grid, block, 0, s, A1, A2, dg, sum_count, range_flag, unit, rest)
+        if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
 #undef LAUNCH
+    }
     return check_launch("so3_angle_error");
 }
 

@@ -94,3 +94,32 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def time_k4():
+    import ctypes
+    dev = torch.device("cuda:0")
+    lib = pa._lib.load()
+    n = 1_000_000
+    a = [rr.symmetric_orthogonalization(torch.randn(n, 9, device=dev)) for _ in range(4)]
+    b = [rr.symmetric_orthogonalization(torch.randn(n, 9, device=dev)) for _ in range(4)]
+    deg = torch.empty(n, dtype=torch.float64, device=dev)
+    sc = torch.empty(2, dtype=torch.float64, device=dev)
+    fl = torch.empty(1, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, dptr, sptr in (("sum only", None, sc), ("deg only", deg, None), ("deg+sum", deg, sc)):
+        def go(i):
+            lib.so3_angle_error(ctypes.c_void_p(a[i % 4].data_ptr()), ctypes.c_void_p(b[i % 4].data_ptr()),
+                                ctypes.c_void_p(dptr.data_ptr()) if dptr is not None else None,
+                                ctypes.c_void_p(sptr.data_ptr()) if sptr is not None else None,
+                                ctypes.c_void_p(fl.data_ptr()), 0, n, st)
+        for i in range(3): go(i)
+        torch.cuda.synchronize(); e0.record()
+        for i in range(20): go(i)
+        e1.record(); torch.cuda.synchronize()
+        print("K4 1M %-9s %.2f us/call (incl. memset + count launches)" % (name, e0.elapsed_time(e1) / 20 * 1e3))
+
+
+if __name__ == "__main__":
+    time_k4()
