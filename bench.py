@@ -109,10 +109,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SO3_BENCH_FORCE_DIST") == "1":    # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from poseestimation_amd import _lib

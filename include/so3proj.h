@@ -80,6 +80,14 @@ int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM
 int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum,
                           int64_t B, void *stream);
 
+/* Stand-alone Frobenius loss for a caller that already holds R_pred (3D-Pose/loss.py:7-11; copies at
+ * Comparison/main.py:12-16, UPNA/main.py:27-31, Iterative/loss.py:4-7):
+ *   loss_sum out 1 double: sum_b ||Rtrue_b - Rpred_b||_F (zeroed by the call; the caller divides by B)
+ *   dRpred   out optional B*9 float32: d(mean loss)/dRpred = (Rpred - Rtrue)/(B ||.||_F); d/dRtrue is its negative.
+ */
+int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B,
+                      void *stream);
+
 /* ---- K4: geodesic angle error ----------------------------------------------------------------------
  * theta_b = acos(clamp((tr(R1_b^T R2_b) - 1)/2, -1, 1)) evaluated in float64 on float32 data.
  * Replaces rotation_representation.py:230-242 (angle_error; copies at Comparison/main.py:19-31,

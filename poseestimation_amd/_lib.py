@@ -24,6 +24,7 @@ SYMBOLS = {
     "so3_project_bwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_frob_fwd_bwd_f32": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
     "so3_frob_fwd_bwd_bf16": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
+    "so3_frob_loss_f32": (_INT, [_P, _P, _P, _P, _I64, _P]),
     "so3_angle_error": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_kabsch_f32": (_INT, [_P, _P, _P, _P, _I64, _I32, _P]),

@@ -211,6 +211,42 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
     if (WANT_R) tile_out<false, VEC>(R, first, n, tile_t);
 }
 
+// ---- K3', stand-alone Frobenius loss (3D-Pose/loss.py:7-11) for callers that already hold R_pred -----
+// loss_sum += sum_b ||Rtrue_b - Rpred_b||_F ;  optional dRpred_b = (Rpred_b - Rtrue_b) / (B ||.||_F).
+// Element-wise over flat float4s is not possible (the norm is per 9-float row), so the same 256-row tile
+// staging as the other block kernels is used.
+template <bool VEC, bool WANT_GRAD>
+__global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ Rpred, const float *__restrict__ Rtrue,
+                                                      float *__restrict__ dRpred, double *__restrict__ loss_sum,
+                                                      int64_t B, float inv_b) {
+    __shared__ __attribute__((aligned(16))) float tile_p[kTileFloats];
+    __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
+    __shared__ double red[4];
+    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
+    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+    tile_in<false, VEC>(Rpred, first, n, tile_p);
+    tile_in<false, VEC>(Rtrue, first, n, tile_t);
+    __syncthreads();
+    float p[9], t[9], g[9];
+    const bool active = static_cast<int>(threadIdx.x) < n;
+    lane_get(tile_p, active, p);
+    lane_get(tile_t, active, t);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { g[i] = p[i] - t[i]; n2 = fmaf(g[i], g[i], n2); }
+    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+    const double total = block_sum(active ? static_cast<double>(nrm) : 0.0, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+    if (WANT_GRAD) {
+        const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;     // zero difference -> zero gradient
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] *= gs;
+        lane_put(tile_p, g);
+        __syncthreads();
+        tile_out<false, VEC>(dRpred, first, n, tile_p);
+    }
+}
+
 // ---- K4 -------------------------------------------------------------------------------------------
 template <bool VEC, bool WANT_DEG, bool WANT_SUM>
 __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict__ R1, const float *__restrict__ R2,
@@ -487,6 +523,24 @@ int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM
 }
 int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
     return frob<true>(M, Rtrue, R, dM, loss_sum, B, stream);
+}
+
+int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f32: B");
+    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f32: loss_sum is null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+    if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
+    const dim3 grid(grid_for(B)), block(kBlock);
+    const float inv_b = 1.0f / static_cast<float>(B);
+    const bool vec = aligned16(Rpred) && aligned16(Rtrue) && (dRpred == nullptr || aligned16(dRpred));
+#define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b)
+    if (vec) { if (dRpred) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (dRpred) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    return check_launch("so3_frob_loss_f32");
 }
 
 int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,

@@ -196,14 +196,41 @@ def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tens
 # --------------------------------------------------------------------------------------------
 # K3: loss
 # --------------------------------------------------------------------------------------------
+class _LossFrobenius(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r_pred, r_true):
+        dev = _require_device(r_pred, r_true)
+        p, t = _f32_blocks(r_pred.detach()), _f32_blocks(r_true.detach())
+        if p.shape != t.shape:
+            raise RuntimeError(f"loss_frobenius: shape mismatch {tuple(r_pred.shape)} vs {tuple(r_true.shape)}")
+        b = p.shape[0]
+        need_grad = r_pred.requires_grad or r_true.requires_grad
+        g = torch.empty_like(p) if need_grad else None
+        loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_frob_loss_f32(_ptr(p), _ptr(t), _ptr(g), _ptr(loss_sum), b, _stream(dev)), "so3_frob_loss_f32")
+        ctx.g = g
+        ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
+        return (loss_sum[0] / max(b, 1)).to(torch.float32)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_loss):
+        if ctx.g is None:
+            return None, None
+        sp, st, dp, dt = ctx.shapes
+        g = ctx.g * grad_loss
+        gp = g.to(dp).view(sp) if ctx.needs_input_grad[0] else None
+        gt = (-g).to(dt).view(st) if ctx.needs_input_grad[1] else None
+        return gp, gt
+
+
 def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
     """mean_b ||R_true - R_pred||_F (not squared), differentiable w.r.t. both arguments.
 
-    Stand-alone form for callers that already hold R_pred.  A training step should use
-    `frobenius_head`, which fuses head, loss and backward into one launch."""
-    _require_device(R_pred, R_true)
-    diff = R_true - R_pred
-    return diff.reshape(-1, 9).norm(dim=1).mean()
+    Stand-alone form for callers that already hold R_pred (one kernel for the loss and its gradient).
+    A training step should use `frobenius_head`, which fuses head, loss and backward into one launch."""
+    return _LossFrobenius.apply(R_pred, R_true)
 
 
 class _FrobeniusHead(torch.autograd.Function):

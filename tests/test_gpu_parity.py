@@ -360,3 +360,22 @@ def test_graph_capture_of_the_head(pa):
     graph.replay()
     torch.cuda.synchronize()
     assert orth_err(r.cpu().numpy()).max() < 1e-5 and sc[1].item() == 4096
+
+
+def test_loss_frobenius_standalone_matches_definition(rr):
+    """a3: mean_b ||R_true - R_pred||_F and both gradients against the 3-line definition (3D-Pose/loss.py:7-11)."""
+    gen = torch.Generator(device=DEV).manual_seed(21)
+    p = torch.randn(1000, 3, 3, device=DEV, generator=gen, requires_grad=True)
+    t = torch.randn(1000, 3, 3, device=DEV, generator=gen, requires_grad=True)
+    loss = rr.loss_frobenius(p, t)
+    (3.0 * loss).backward()
+    p2 = p.detach().clone().requires_grad_(True)
+    t2 = t.detach().clone().requires_grad_(True)
+    ref = (t2 - p2).reshape(-1, 9).norm(dim=1).mean()          # the definition, composed from torch ops
+    (3.0 * ref).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert (p.grad - p2.grad).abs().max().item() < 1e-8 and (t.grad - t2.grad).abs().max().item() < 1e-8
+    # a zero difference gives a zero gradient instead of the reference's NaN (documented)
+    q = torch.eye(3, device=DEV).repeat(4, 1, 1).requires_grad_(True)
+    rr.loss_frobenius(q, torch.eye(3, device=DEV).repeat(4, 1, 1)).backward()
+    assert torch.isfinite(q.grad).all() and q.grad.abs().max().item() == 0

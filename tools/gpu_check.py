@@ -123,3 +123,52 @@ def time_k4():
 
 if __name__ == "__main__":
     time_k4()
+
+
+def time_config4():
+    """Config #4: B = 512 bf16 head forward + Frobenius loss + backward, one fused call."""
+    import ctypes
+    dev = torch.device("cuda:0")
+    lib = pa._lib.load()
+    b = 512
+    x = torch.randn(b, 9, device=dev).bfloat16()
+    rt = rr.symmetric_orthogonalization(torch.randn(b, 9, device=dev))
+    r = torch.empty(b, 9, device=dev); dm = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
+    ls = torch.empty(1, dtype=torch.float64, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def go():
+        lib.so3_frob_fwd_bwd_bf16(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(rt.data_ptr()), ctypes.c_void_p(r.data_ptr()),
+                                  ctypes.c_void_p(dm.data_ptr()), ctypes.c_void_p(ls.data_ptr()), b, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10): go()
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(200): go()
+    e1.record(); torch.cuda.synchronize()
+    print("config4 fused C-ABI call (B=512, bf16): %.2f us/call back-to-back" % (e0.elapsed_time(e1) / 200 * 1e3))
+    # through the Python mirror incl. autograd bookkeeping
+    xg = x.clone().requires_grad_(True)
+    import time
+    for _ in range(5):
+        loss, _ = rr.frobenius_head(xg, rt); loss.backward(); xg.grad = None
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100):
+        loss, _ = rr.frobenius_head(xg, rt); loss.backward(); xg.grad = None
+    torch.cuda.synchronize()
+    print("config4 via Python mirror fwd+bwd: %.1f us/iter (host-bound)" % ((time.perf_counter() - t0) / 100 * 1e6))
+    # the reference's op chain on the same GPU, for scale (torch.linalg.svd on device)
+    from oracle import so3_oracle as so
+    xf = x.float().clone().requires_grad_(True)
+    try:
+        for _ in range(3):
+            l = so.loss_frobenius_torch(so.symmetric_orthogonalization_torch(xf), rt); l.backward(); xf.grad = None
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            l = so.loss_frobenius_torch(so.symmetric_orthogonalization_torch(xf), rt); l.backward(); xf.grad = None
+        torch.cuda.synchronize()
+        print("config4 reference ATen chain on the same GPU (torch.linalg.svd): %.1f us/iter" % ((time.perf_counter() - t0) / 20 * 1e6))
+    except Exception as exc:
+        print("reference chain on GPU failed:", exc)
+
+
+if __name__ == "__main__":
+    time_config4()
