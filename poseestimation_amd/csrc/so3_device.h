@@ -41,7 +41,7 @@ namespace so3 {
 // rows are below 1e-5 after three sweeps and all are at round-off (2e-7) after four (tools/proto_jacobi.py),
 // so about one wave round in twelve takes the extra sweep.
 constexpr int kSweeps = SO3_SWEEPS;
-constexpr float kResidualTol2 = 1e-10f;   // (1e-5)^2 on  gamma_ij^2 / (|a_i|^2 |a_j|^2)
+constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|^2 |a_1|^2)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
 constexpr float kTinyNorm2 = 1e-30f;
 constexpr float kTieBreak = 1.0f - 4e-6f;
@@ -193,13 +193,13 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         rotate(a1, a2);
     }
 
-    // 2b. convergence test, one combined inequality:  sum_ij gamma_ij^2 n_k  <=  tol^2 n0 n1 n2
+    // 2b. convergence test.  A cyclic sweep ends with rotation (1,2), which leaves gamma_12 = 0 and
+    // gamma_02 = -s_12 * gamma_01: the (0,1) residual dominates, so it alone is tested:
+    //     gamma_01^2  <=  tol^2 |a_0|^2 |a_1|^2 .
     T n0 = dot(a0, a0), n1 = dot(a1, a1), n2 = dot(a2, a2);
     if (ADAPT) {
-        const T g01 = dot(a0, a1), g02 = dot(a0, a2), g12 = dot(a1, a2);
-        const T lhs = R::fma(g01 * g01, n2, R::fma(g02 * g02, n1, g12 * g12 * n0));
-        const T rhs = n0 * n1 * n2 * R::splat(kResidualTol2);
-        if (wave_any(R::any(R::gt(lhs, rhs)))) {          // NaN / rank-deficient rows compare false
+        const T g01 = dot(a0, a1);
+        if (wave_any(R::any(R::gt(g01 * g01, n0 * n1 * R::splat(kResidualTol2))))) {   // NaN / zero rows compare false
             rotate(a0, a1);
             rotate(a0, a2);
             rotate(a1, a2);
@@ -274,20 +274,22 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     return o;
 }
 
-// R = U' V^T, row-major.
-template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd<T> &f, T (&r)[9]) {
-    const T ux[3] = {f.u1.x, f.u2.x, f.u3.x}, uy[3] = {f.u1.y, f.u2.y, f.u3.y}, uz[3] = {f.u1.z, f.u2.z, f.u3.z};
-    const V3<T> v[3] = {f.v1, f.v2, f.v3};
-    V3<T> r0 = scale<T>(v[0], ux[0]), r1 = scale<T>(v[0], uy[0]), r2 = scale<T>(v[0], uz[0]);
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-        r0 = axpy<T>(ux[k], v[k], r0);
-        r1 = axpy<T>(uy[k], v[k], r1);
-        r2 = axpy<T>(uz[k], v[k], r2);
-    }
+// R = U' V^T, row-major.  Rows 0 and 1 come from the frames (only the x,y components of u3 = u1 x u2 are
+// needed for them); row 2 of a rotation is row0 x row1.
+template <class T> __device__ __forceinline__ void rotation_rows(V3<T> u1, V3<T> u2, V3<T> v1, V3<T> v2, T (&r)[9]) {
+    typedef Tr<T> R;
+    const T u3x = R::fma(u1.y, u2.z, -(u1.z * u2.y));
+    const T u3y = R::fma(u1.z, u2.x, -(u1.x * u2.z));
+    const V3<T> v3 = cross<T>(v1, v2);
+    const V3<T> r0 = axpy<T>(u3x, v3, axpy<T>(u2.x, v2, scale<T>(v1, u1.x)));
+    const V3<T> r1 = axpy<T>(u3y, v3, axpy<T>(u2.y, v2, scale<T>(v1, u1.y)));
+    const V3<T> r2 = cross<T>(r0, r1);
     r[0] = r0.x; r[1] = r0.y; r[2] = r0.z;
     r[3] = r1.x; r[4] = r1.y; r[5] = r1.z;
     r[6] = r2.x; r[7] = r2.y; r[8] = r2.z;
+}
+template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd<T> &f, T (&r)[9]) {
+    rotation_rows<T>(f.u1, f.u2, f.v1, f.v2, r);
 }
 
 // sign(det M) evaluated in float64 (products of floats are exact in double) -> flip flag.

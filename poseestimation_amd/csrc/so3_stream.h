@@ -61,19 +61,21 @@ __device__ __forceinline__ void unit_store(rsrc_t rs, const f32x4 (&v)[3], int l
     for (int j = 0; j < 3; ++j)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStreamCpol);
 }
-// LDS side: float4 #lane, #lane+64, and #idx3 = lane+128 on lanes < 16 (lane elsewhere: a duplicate of
-// the first slot with the same data, so no branch here either).
-__device__ __forceinline__ void unit_to_lds(float *tile, const f32x4 (&v)[3], int lane, int idx3) {
+// LDS side: a unit occupies a slot of 192 float4 (3072 B): the 144 real ones plus padding, so that every
+// lane can write/read float4 #lane+128 without a branch or a select (lanes >= 16 touch only the padding:
+// zeros from their range-checked load on the way in, garbage that the range-checked store drops on the way out).
+constexpr int kUnitSlotFloats = 192 * 4;
+__device__ __forceinline__ void unit_to_lds(float *tile, const f32x4 (&v)[3], int lane) {
     f32x4 *t4 = reinterpret_cast<f32x4 *>(tile);
     t4[lane] = v[0];
     t4[lane + 64] = v[1];
-    t4[idx3] = lane < 16 ? v[2] : v[0];
+    t4[lane + 128] = v[2];
 }
-__device__ __forceinline__ void unit_from_lds(f32x4 (&v)[3], const float *tile, int lane, int idx3) {
+__device__ __forceinline__ void unit_from_lds(f32x4 (&v)[3], const float *tile, int lane) {
     const f32x4 *t4 = reinterpret_cast<const f32x4 *>(tile);
     v[0] = t4[lane];
     v[1] = t4[lane + 64];
-    v[2] = t4[idx3];
+    v[2] = t4[lane + 128];
 }
 
 template <int NPL> struct LaneT;
@@ -92,16 +94,15 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     typedef typename LaneT<NPL>::type T;
     typedef so3::Tr<T> Tr;
-    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][NPL][kUnitFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kWavesPerBlock][NPL][kUnitSlotFloats];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
-    float(*tile)[kUnitFloats] = lds[wave_in_block];
+    float(*tile)[kUnitSlotFloats] = lds[wave_in_block];
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWavesPerBlock;
     const int64_t nrounds = (nunits + NPL - 1) / NPL;
     int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + wave_in_block;
     if (t >= nrounds) return;
     const int64_t wave_id = t;
-    const int idx3 = lane < 16 ? lane + 128 : lane;
     f32x4 in[NPL][3];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -109,7 +110,7 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         unit_fetch(in[k], unit_rsrc(M, u < nunits ? u : t * NPL, true), lane);
     }
 #pragma unroll
-    for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane, idx3);
+    for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane);
     while (true) {
         wave_lds_fence();
         T m[9], r[9];
@@ -142,7 +143,7 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         wave_lds_fence();
         f32x4 o[NPL][3];
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) unit_from_lds(o[k], tile[k], lane, idx3);
+        for (int k = 0; k < NPL; ++k) unit_from_lds(o[k], tile[k], lane);
         wave_lds_fence();
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -160,7 +161,7 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         // The prefetched units land in LDS here, at the END of the body: the loads are older than this
         // round's stores, so the wait the compiler places is vmcnt(#stores), not a drain of the stores.
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane, idx3);
+        for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane);
         t = tn;
     }
     if (STAMP) {
@@ -182,11 +183,11 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
 
 // ---- K4, streaming form ---------------------------------------------------------------------------------
 // theta = acos(clamp((tr(R1^T R2) - 1)/2)) in float64 on float32 data (rotation_representation.py:230-242).
-// 1024-thread workgroups (16 waves, two per CU), each wave walks units w, w+W, ... with the same
+// 512-thread workgroups (8 waves, three per CU: 48 KB of LDS each), each wave walks units w, w+W, ... with the same
 // wave-private LDS staging as K1 and keeps a per-lane float64 partial sum; ONE atomicAdd per workgroup then
 // carries the fused (sum) reduction -- same-address float64 atomics cost ~12 ns each, so a per-tile atomic
 // (thousands per launch) would dominate the kernel.
-constexpr int kAngleBlock = 1024;
+constexpr int kAngleBlock = 512;
 constexpr int kAngleWaves = kAngleBlock / 64;
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -200,13 +201,12 @@ __global__ __launch_bounds__(kAngleBlock) void k_angle_error_stream(const float 
                                                                     double *__restrict__ out, double *__restrict__ sum_count,
                                                                     int32_t *__restrict__ range_flag, double unit_scale,
                                                                     int64_t nunits) {
-    __shared__ __attribute__((aligned(16))) float lds[kAngleWaves][2][kUnitFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kAngleWaves][2][kUnitSlotFloats];
     __shared__ double red[kAngleWaves];
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float(*tile)[kUnitFloats] = lds[wave_in_block];
+    float(*tile)[kUnitSlotFloats] = lds[wave_in_block];
     const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kAngleWaves;
-    const int idx3 = lane < 16 ? lane + 128 : lane;
     double acc = 0.0;
     bool any_bad = false;
     int64_t t = static_cast<int64_t>(blockIdx.x) * kAngleWaves + wave_in_block;
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(kAngleBlock) void k_angle_error_stream(const float 
         unit_fetch(in[0], unit_rsrc(R1, t, true), lane);
         unit_fetch(in[1], unit_rsrc(R2, t, true), lane);
         while (true) {
-            unit_to_lds(tile[0], in[0], lane, idx3);
-            unit_to_lds(tile[1], in[1], lane, idx3);
+            unit_to_lds(tile[0], in[0], lane);
+            unit_to_lds(tile[1], in[1], lane);
             wave_lds_fence();
             float a[9], b[9];
 #pragma unroll

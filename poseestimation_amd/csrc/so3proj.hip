@@ -557,7 +557,7 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
     const int64_t done = nunits * so3::kUnitRows;
     if (nunits > 0) {
         const int64_t want = (nunits + so3::kAngleWaves - 1) / so3::kAngleWaves;
-        const dim3 sgrid(static_cast<unsigned>(want < 512 ? want : 512)), sblock(so3::kAngleBlock);
+        const dim3 sgrid(static_cast<unsigned>(want < 768 ? want : 768)), sblock(so3::kAngleBlock);   // 3 workgroups per CU
 #define SLAUNCH(WD, WS) hipLaunchKernelGGL((so3::k_angle_error_stream<WD, WS>), sgrid, sblock, 0, s, R1, R2, deg, sum_count, range_flag, unit, nunits)
         if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH

@@ -86,12 +86,14 @@ int main() {
     }
     unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 4 * 8192 * 4));
     CHECK(hipDeviceSynchronize());
-    for (int k : {40, 200, 1000, 40}) {
+    for (int k : {40, 1000, 1000}) {
         g_launches = k;
         printf("--- %d timed launches per measurement\n", k);
-        run<2, 4, -1, false>(in, out, stamps);     // copy through the same path: the data-movement floor
+        run<2, 2, 3, true>(in, out, stamps);
         run<2, 3, 3, true>(in, out, stamps);
-        run<2, 3, 4, false>(in, out, stamps);
+        run<2, 4, 3, true>(in, out, stamps);
+        run<1, 8, 3, true>(in, out, stamps);
+        run<1, 6, 3, true>(in, out, stamps);
     }
     return 0;
 }
