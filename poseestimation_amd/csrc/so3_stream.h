@@ -90,7 +90,7 @@ template <int NPL, bool FLIP, int WPS, bool STAMP = false, int SWEEPS = kSweeps,
 __global__ __launch_bounds__(kStreamBlock) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, uint8_t *__restrict__ flip, int64_t nunits,
                           unsigned long long *__restrict__ stamps) {
-    unsigned long long t_real0 = 0, t_mem0 = 0;
+    unsigned long long t_real0 = 0, t_mem0 = 0, stall_cycles = 0, first_wait = 0;
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     typedef typename LaneT<NPL>::type T;
     typedef so3::Tr<T> Tr;
@@ -109,6 +109,7 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         const int64_t u = t * NPL + k;                      // a non-existent unit re-reads the round's first one
         unit_fetch(in[k], unit_rsrc(M, u < nunits ? u : t * NPL, true), lane);
     }
+    if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
 #pragma unroll
     for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane);
     while (true) {
@@ -160,21 +161,26 @@ void k_project_fwd_stream(const float *__restrict__ M, float *__restrict__ R, ui
         if (!more) break;
         // The prefetched units land in LDS here, at the END of the body: the loads are older than this
         // round's stores, so the wait the compiler places is vmcnt(#stores), not a drain of the stores.
+        unsigned long long w0 = 0;
+        if (STAMP) { __builtin_amdgcn_sched_barrier(0); w0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0x0F70 | 6); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) unit_to_lds(tile[k], in[k], lane);
+        if (STAMP) { __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
         t = tn;
     }
     if (STAMP) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
-            stamps[4 * wave_id + 0] = t_real0;
-            stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
-            stamps[4 * wave_id + 2] = t_mem0;
+            stamps[6 * wave_id + 0] = t_real0;
+            stamps[6 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+            stamps[6 * wave_id + 2] = t_mem0;
+            stamps[6 * wave_id + 4] = stall_cycles;          // cycles spent waiting for prefetched units
+            stamps[6 * wave_id + 5] = first_wait;            // cycles from wave start until its first unit arrived
             // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20): which XCD / SE / CU / SIMD ran this wave
             const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
             const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
             // cycles in bits 0..27, XCC id in 28..31, HW_ID in 32..63
-            stamps[4 * wave_id + 3] = ((__builtin_amdgcn_s_memtime() - t_mem0) & 0xFFFFFFFull)
+            stamps[6 * wave_id + 3] = ((__builtin_amdgcn_s_memtime() - t_mem0) & 0xFFFFFFFull)
                                       | (static_cast<unsigned long long>(xcc & 0xF) << 28) | (static_cast<unsigned long long>(hw) << 32);
         }
     }
