@@ -178,37 +178,45 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
     __shared__ __attribute__((aligned(16))) float tile_m[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
     __shared__ double red[4];
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
-    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
-    tile_in<BF16, VEC>(M, first, n, tile_m);
-    tile_in<false, VEC>(Rtrue, first, n, tile_t);
-    __syncthreads();
-    float m[9], t[9], r[9], g[9], dm[9];
-    const bool active = static_cast<int>(threadIdx.x) < n;
-    lane_get(tile_m, active, m);
-    lane_get(tile_t, active, t);
-    const auto f = so3::signed_svd<WANT_DM>(m);
-    so3::rotation_from(f, r);
-    float n2 = 0.f;
+    const int64_t ntiles = (B + kBlock - 1) / kBlock;
+    double acc = 0.0;                                  // per-lane partial of sum_b ||.||_F over this workgroup's tiles
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t first = tile * kBlock;
+        const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+        tile_in<BF16, VEC>(M, first, n, tile_m);
+        tile_in<false, VEC>(Rtrue, first, n, tile_t);
+        __syncthreads();
+        float m[9], t[9], r[9], g[9], dm[9];
+        const bool active = static_cast<int>(threadIdx.x) < n;
+        lane_get(tile_m, active, m);
+        lane_get(tile_t, active, t);
+        const auto f = so3::signed_svd<WANT_DM>(m);
+        so3::rotation_from(f, r);
+        float n2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        g[i] = r[i] - t[i];                       // d||Rtrue - R||/dR = (R - Rtrue)/||.||
-        n2 = fmaf(g[i], g[i], n2);
+        for (int i = 0; i < 9; ++i) {
+            g[i] = r[i] - t[i];                       // d||Rtrue - R||/dR = (R - Rtrue)/||.||
+            n2 = fmaf(g[i], g[i], n2);
+        }
+        const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+        const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;    // zero difference -> zero gradient
+        if (active) acc += static_cast<double>(nrm);
+        if (WANT_DM) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) g[i] *= gs;
+            so3::project_backward(f, g, dm);
+            lane_put(tile_m, dm);
+        }
+        if (WANT_R) lane_put(tile_t, r);
+        __syncthreads();
+        if (WANT_DM) tile_out<BF16, VEC>(dM, first, n, tile_m);
+        if (WANT_R) tile_out<false, VEC>(R, first, n, tile_t);
+        __syncthreads();                               // the tiles are reused by the next iteration
     }
-    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
-    const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;    // zero difference -> zero gradient
-    const double total = block_sum(active ? static_cast<double>(nrm) : 0.0, red);
+    // one float64 atomic per workgroup: same-address atomics cost ~12 ns each (one per 256-row tile made this
+    // kernel atomic-bound: 59 us per 1M rows)
+    const double total = block_sum(acc, red);
     if (threadIdx.x == 0) atomicAdd(loss_sum, total);
-    if (WANT_DM) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) g[i] *= gs;
-        so3::project_backward(f, g, dm);
-        lane_put(tile_m, dm);
-    }
-    if (WANT_R) lane_put(tile_t, r);
-    __syncthreads();
-    if (WANT_DM) tile_out<BF16, VEC>(dM, first, n, tile_m);
-    if (WANT_R) tile_out<false, VEC>(R, first, n, tile_t);
 }
 
 // ---- K3', stand-alone Frobenius loss (3D-Pose/loss.py:7-11) for callers that already hold R_pred -----
@@ -222,29 +230,36 @@ __global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ 
     __shared__ __attribute__((aligned(16))) float tile_p[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
     __shared__ double red[4];
-    const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
-    const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
-    tile_in<false, VEC>(Rpred, first, n, tile_p);
-    tile_in<false, VEC>(Rtrue, first, n, tile_t);
-    __syncthreads();
-    float p[9], t[9], g[9];
-    const bool active = static_cast<int>(threadIdx.x) < n;
-    lane_get(tile_p, active, p);
-    lane_get(tile_t, active, t);
-    float n2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { g[i] = p[i] - t[i]; n2 = fmaf(g[i], g[i], n2); }
-    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
-    const double total = block_sum(active ? static_cast<double>(nrm) : 0.0, red);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
-    if (WANT_GRAD) {
-        const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;     // zero difference -> zero gradient
-#pragma unroll
-        for (int i = 0; i < 9; ++i) g[i] *= gs;
-        lane_put(tile_p, g);
+    const int64_t ntiles = (B + kBlock - 1) / kBlock;
+    double acc = 0.0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t first = tile * kBlock;
+        const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
+        tile_in<false, VEC>(Rpred, first, n, tile_p);
+        tile_in<false, VEC>(Rtrue, first, n, tile_t);
         __syncthreads();
-        tile_out<false, VEC>(dRpred, first, n, tile_p);
+        float p[9], t[9], g[9];
+        const bool active = static_cast<int>(threadIdx.x) < n;
+        lane_get(tile_p, active, p);
+        lane_get(tile_t, active, t);
+        float n2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { g[i] = p[i] - t[i]; n2 = fmaf(g[i], g[i], n2); }
+        const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+        if (active) acc += static_cast<double>(nrm);
+        __syncthreads();
+        if (WANT_GRAD) {
+            const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;     // zero difference -> zero gradient
+#pragma unroll
+            for (int i = 0; i < 9; ++i) g[i] *= gs;
+            lane_put(tile_p, g);
+            __syncthreads();
+            tile_out<false, VEC>(dRpred, first, n, tile_p);
+            __syncthreads();
+        }
     }
+    const double total = block_sum(acc, red);          // one atomic per workgroup
+    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
 }
 
 // ---- K4 -------------------------------------------------------------------------------------------
@@ -423,7 +438,8 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
-    const dim3 grid(grid_for(B)), block(kBlock);
+    const unsigned tiles = grid_for(B);
+    const dim3 grid(tiles < 2048u ? tiles : 2048u), block(kBlock);     // persistent: <= 8 workgroups per CU
     const float inv_b = 1.0f / static_cast<float>(B);
     bool vec = aligned16(Rtrue) && (R == nullptr || aligned16(R));
     if (!BF16) vec = vec && aligned16(M) && (dM == nullptr || aligned16(dM));
@@ -533,7 +549,8 @@ int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, dou
     if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
-    const dim3 grid(grid_for(B)), block(kBlock);
+    const unsigned tiles = grid_for(B);
+    const dim3 grid(tiles < 2048u ? tiles : 2048u), block(kBlock);
     const float inv_b = 1.0f / static_cast<float>(B);
     const bool vec = aligned16(Rpred) && aligned16(Rtrue) && (dRpred == nullptr || aligned16(dRpred));
 #define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Times every C-ABI entry point at the BASELINE.json configs (secondary kernels; bench.py is the headline).
+Each call is launched back-to-back on rotating buffers; reported per call with the algorithmic bytes it moves."""
+import ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from poseestimation_amd import _lib
+from poseestimation_amd import rotation_representation as rr
+
+P = ctypes.c_void_p
+dev = torch.device("cuda:0")
+lib = _lib.load()
+st = P(torch.cuda.current_stream().cuda_stream)
+NB = 6
+
+
+def timeit(name, fn, bytes_per_call, iters=60, warm=5):
+    for i in range(warm): fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters): fn(i)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    print("%-58s %9.2f us/call  %7.0f GB/s (%4.1f%% of 8 TB/s)" % (name, us, bytes_per_call / us * 1e-3, bytes_per_call / us * 1e-3 / 80))
+
+
+def main():
+    n = 1_000_000
+    x = [torch.randn(n, 9, device=dev) for _ in range(NB)]
+    xb = [t.bfloat16() for t in x]
+    g = [torch.randn(n, 9, device=dev) for _ in range(NB)]
+    r = [torch.empty(n, 9, device=dev) for _ in range(NB)]
+    dm = [torch.empty(n, 9, device=dev) for _ in range(NB)]
+    dmb = [torch.empty(n, 9, device=dev, dtype=torch.bfloat16) for _ in range(NB)]
+    rt = [rr.symmetric_orthogonalization(torch.randn(n, 9, device=dev)).reshape(n, 9) for _ in range(NB)]
+    flip = torch.empty(n, dtype=torch.uint8, device=dev)
+    ls = torch.empty(1, dtype=torch.float64, device=dev)
+    deg = torch.empty(n, dtype=torch.float64, device=dev)
+    th = torch.empty(n, dtype=torch.float32, device=dev)
+    sc = torch.empty(2, dtype=torch.float64, device=dev)
+    fl = torch.empty(1, dtype=torch.int32, device=dev)
+    p = lambda t: P(t.data_ptr())
+    print("--- 1M rows (config #2 shape) ---")
+    timeit("K1 so3_project_fwd_f32", lambda i: lib.so3_project_fwd_f32(p(x[i % NB]), p(r[i % NB]), None, n, st), 72 * n)
+    timeit("K1 so3_project_fwd_f32 + flip flags", lambda i: lib.so3_project_fwd_f32(p(x[i % NB]), p(r[i % NB]), p(flip), n, st), 73 * n)
+    timeit("K1 so3_project_fwd_bf16 (bf16 in, f32 out)", lambda i: lib.so3_project_fwd_bf16(p(xb[i % NB]), p(r[i % NB]), None, n, st), 54 * n)
+    timeit("K2 so3_project_bwd_f32", lambda i: lib.so3_project_bwd_f32(p(x[i % NB]), p(g[i % NB]), p(dm[i % NB]), n, st), 108 * n)
+    timeit("K2 so3_project_bwd_bf16", lambda i: lib.so3_project_bwd_bf16(p(xb[i % NB]), p(g[i % NB]), p(dmb[i % NB]), n, st), 72 * n)
+    timeit("K3 so3_frob_fwd_bwd_f32 (R + dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), n, st), 144 * n)
+    timeit("K3 so3_frob_fwd_bwd_f32 (dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), n, st), 108 * n)
+    timeit("K3' so3_frob_loss_f32 (loss + dRpred)", lambda i: lib.so3_frob_loss_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), n, st), 108 * n)
+    timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
+    timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
+    timeit("K4' so3_geodesic_f32", lambda i: lib.so3_geodesic_f32(p(r[i % NB]), p(rt[i % NB]), p(th), n, st), 76 * n)
+    del x, xb, g, r, dm, dmb, rt
+    torch.cuda.empty_cache()
+    print("--- config #3: 65536 clouds x 1024 points ---")
+    b, npts = 65536, 1024
+    pc = [torch.rand(b, npts, 3, device=dev) - 0.5 for _ in range(2)]
+    qc = [torch.rand(b, npts, 3, device=dev) - 0.5 for _ in range(2)]
+    rk = torch.empty(b, 9, device=dev)
+    timeit("K5 so3_kabsch_f32", lambda i: lib.so3_kabsch_f32(p(pc[i % 2]), p(qc[i % 2]), p(rk), None, b, npts, st), b * (2 * npts * 12 + 36), iters=10, warm=2)
+    del pc, qc
+    torch.cuda.empty_cache()
+    print("--- config #4: B = 512, bf16 storage, fused head + loss + backward ---")
+    b = 512
+    x4 = torch.randn(b, 9, device=dev).bfloat16(); r4 = torch.empty(b, 9, device=dev); d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
+    t4 = rr.symmetric_orthogonalization(torch.randn(b, 9, device=dev))
+    timeit("K3 so3_frob_fwd_bwd_bf16 (B=512)", lambda i: lib.so3_frob_fwd_bwd_bf16(p(x4), p(t4), p(r4), p(d4), p(ls), b, st), b * (18 + 36 + 36 + 18), iters=300)
+    print("--- config #1: B = 256 ---")
+    x1 = torch.randn(256, 9, device=dev); r1 = torch.empty(256, 9, device=dev)
+    timeit("K1 so3_project_fwd_f32 (B=256)", lambda i: lib.so3_project_fwd_f32(p(x1), p(r1), None, 256, st), 256 * 72, iters=300)
+
+
+if __name__ == "__main__":
+    main()
