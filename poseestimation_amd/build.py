@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libso3proj.so")
 SOURCES = ["so3proj.hip"]
-HEADERS = ["so3_device.h", "so3_stream.h", os.path.join("..", "..", "include", "so3proj.h")]
+HEADERS = ["so3_device.h", "so3_rows.h", os.path.join("..", "..", "include", "so3proj.h")]
 # -fno-slp-vectorize: hipcc's SLP pass packs the 3-vector arithmetic into v_pk_fma_f32/v_pk_mul_f32,
 # which on gfx950 issue at half the rate of the scalar forms (tools/ubench/valu_rates.hip: same
 # FLOP/s) and cost ~250 extra v_mov_b32 per lane to build the register pairs.

@@ -1,0 +1,441 @@
+// so3_rows.h -- the row-streaming engine every large-batch kernel of libso3proj.so runs on, and the
+// operations (K1..K4) plugged into it.  Also instantiated by tools/ubench/k1_anatomy.hip (STAMP = true).
+//
+// The batch is cut into UNITS of 64 rows (64 x 9 elements: 2304 B for f32, 1152 B for bf16).  Persistent
+// waves, no workgroup barrier on the data path: in one ROUND a wave takes NPL consecutive units (lane l
+// owns row l of each) from up to two input arrays, computes, and writes up to two output arrays; wave w takes
+// rounds w, w+W, w+2W, ...  A unit travels
+//     HBM --buffer_load_dwordx4 nt--> VGPR --ds_write_b128--> LDS --ds_read_b32/u16 (stride 9)--> lane
+// and back the same way.  Design points (measurements in DESIGN.md):
+//   * NPL = 2 packs two independent matrices into the halves of v_pk_* operands (so3_device.h): a Jacobi
+//     sweep is a dependent chain and dependent scalar VALU issues at about half rate.
+//   * The NEXT round's loads are issued before the current round's arithmetic and land in LDS at the END of
+//     the loop body: they are older than the round's stores, so the wait is vmcnt(#stores), never a drain.
+//   * Unit I/O is raw buffer instructions with a PER-UNIT descriptor (num_records = unit bytes, or 0 for a
+//     unit that does not exist / a prefetch past the end): partial float4 slots, odd tails and the dangling
+//     prefetch are dropped by the hardware range check instead of exec-masked branches, which keeps the
+//     compiler's vmcnt bookkeeping exact and costs no traffic.
+//   * LDS is private to a wave (a slot per unit and array, padded so every lane can touch float4 #lane+128);
+//     DS operations of one wave complete in issue order, so no s_barrier is needed.
+//   * Every streamed access is non-temporal: each byte is touched once.
+//   * Reductions (loss, sum of angles) stay in a per-lane float64 register until the wave retires; one atomic
+//     per WORKGROUP then publishes them (same-address float64 atomics cost ~12 ns each).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "so3_device.h"
+
+namespace so3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr int kUnitRows = 64;
+constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data format
+#ifndef SO3_STREAM_CPOL
+#define SO3_STREAM_CPOL 2                        // cache policy of the streamed loads/stores: 2 = nt (non-temporal)
+#endif
+constexpr int kStreamCpol = SO3_STREAM_CPOL;     // a plain 36 MB -> 36 MB copy: 14.8 us default policy, 13.1 us nt
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    const __bf16 h = static_cast<__bf16>(f);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
+// ---- one array's unit: geometry and movers; EB = element bytes (4: float32, 2: bfloat16, 0: array absent) ----
+template <int EB> struct UnitIO {
+    static constexpr int kBytes = kUnitRows * 9 * EB;            // 2304 / 1152
+    static constexpr int kVec4 = kBytes / 16;                    // 144 / 72
+    static constexpr int kLoads = (kVec4 + 63) / 64;             // 3 / 2 float4 per lane (last one partial)
+    static constexpr int kSlotBytes = kLoads * 64 * 16;          // 3072 / 2048: LDS slot incl. padding
+
+    // `unit` is wave-uniform (SGPR) by construction
+    static __device__ __forceinline__ rsrc_t rsrc(const void *base, int64_t unit, bool exists) {
+        char *p = static_cast<char *>(const_cast<void *>(base)) + unit * kBytes;
+        return __builtin_amdgcn_make_buffer_rsrc(p, 0, exists ? kBytes : 0, kRsrcFlags);
+    }
+    static __device__ __forceinline__ void fetch(f32x4 (&v)[kLoads], rsrc_t rs, int lane) {
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j)
+            v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * j) * 16, 0, kStreamCpol));
+    }
+    static __device__ __forceinline__ void store(rsrc_t rs, const f32x4 (&v)[kLoads], int lane) {
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStreamCpol);
+    }
+    static __device__ __forceinline__ void to_lds(char *slot, const f32x4 (&v)[kLoads], int lane) {
+        f32x4 *t4 = reinterpret_cast<f32x4 *>(slot);
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) t4[lane + 64 * j] = v[j];
+    }
+    static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
+        const f32x4 *t4 = reinterpret_cast<const f32x4 *>(slot);
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j) v[j] = t4[lane + 64 * j];
+    }
+    // component k of the lane's row <-> LDS slot, as float
+    template <class T> static __device__ __forceinline__ void read_row(const char *slot, int lane, int k, T (&m)[9]) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            float v;
+            if (EB == 4) v = reinterpret_cast<const float *>(slot)[lane * 9 + i];
+            else v = bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(slot)[lane * 9 + i]);
+            Tr<T>::set(m[i], k, v);
+        }
+    }
+    template <class T> static __device__ __forceinline__ void write_row(char *slot, int lane, int k, const T (&m)[9]) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float v = Tr<T>::get(m[i], k);
+            if (EB == 4) reinterpret_cast<float *>(slot)[lane * 9 + i] = v;
+            else reinterpret_cast<uint16_t *>(slot)[lane * 9 + i] = f32_to_bf16_bits(v);
+        }
+    }
+};
+template <> struct UnitIO<0> {
+    static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0;
+};
+
+// Per-row side outputs (flip flags, angles): one element per row, contiguous across the lanes of a unit.
+template <int BYTES> __device__ __forceinline__ rsrc_t row_rsrc(void *base, int64_t unit, bool exists) {
+    char *p = static_cast<char *>(base) + unit * (kUnitRows * BYTES);
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, exists ? kUnitRows * BYTES : 0, kRsrcFlags);
+}
+
+template <int NPL> struct LaneT;
+template <> struct LaneT<1> { typedef float type; };
+template <> struct LaneT<2> { typedef f32x2 type; };
+
+// What an operation sees of the current round.
+template <int NPL> struct RowCtx {
+    int64_t unit[NPL];      // unit index of component k (wave-uniform)
+    bool exists[NPL];       // false only for the phantom second unit of an odd tail
+    int lane;
+    double acc;             // per-lane float64 partial of the operation's reduction
+    bool flag;              // per-lane sticky flag (K4: cosine out of range)
+};
+
+// ---- the engine ----------------------------------------------------------------------------------------
+// Op provides: kIn0, kIn1, kOut0, kOut1 (element bytes, 0 = absent), pointers in0, in1, out0, out1,
+//   template <class T, int NPL> void compute(const T (&a)[9], const T (&b)[9], T (&o0)[9], T (&o1)[9], RowCtx<NPL> &)
+//   void finish(double block_total, bool any_flag)      -- called by thread 0 of each workgroup at the end
+//   kReduce: whether acc/flag are used.
+// WPS = resident waves per SIMD the register budget is sized for (the host launches 256 * WPS * 256 / BLOCK
+// workgroups).  STAMP (diagnostic builds only): per wave {s_memrealtime entry, exit, s_memtime entry,
+// cycles | XCC << 28 | HW_ID << 32, cycles waiting for prefetched units, cycles until the first unit arrived}.
+template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
+void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
+    typedef typename LaneT<NPL>::type T;
+    typedef UnitIO<Op::kIn0> I0;
+    typedef UnitIO<Op::kIn1> I1;
+    typedef UnitIO<Op::kOut0> O0;
+    typedef UnitIO<Op::kOut1> O1;
+    constexpr int kWaves = BLOCK / 64;
+    // LDS slot of one unit: the input slots side by side; outputs are staged over them once the rows are in registers
+    constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes;
+    constexpr int kOutBytes = O0::kSlotBytes + O1::kSlotBytes;
+    constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
+    __shared__ __attribute__((aligned(16))) char lds[kWaves][NPL][kSlot];
+    __shared__ double red[kWaves];
+    __shared__ int red_flag[kWaves];
+
+    unsigned long long t_real0 = 0, t_mem0 = 0, stall_cycles = 0, first_wait = 0;
+    if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
+    char(*slot)[kSlot] = lds[wave_in_block];
+    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWaves;
+    const int64_t nrounds = (nunits + NPL - 1) / NPL;
+    int64_t t = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
+    const int64_t wave_id = t;
+    RowCtx<NPL> ctx;
+    ctx.lane = lane;
+    ctx.acc = 0.0;
+    ctx.flag = false;
+    if (t < nrounds) {
+        f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int64_t u = t * NPL + k;                  // a phantom unit re-reads the round's first one
+            const int64_t ue = u < nunits ? u : t * NPL;
+            I0::fetch(in0[k], I0::rsrc(op.in0, ue, true), lane);
+            if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, true), lane);
+        }
+        if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            I0::to_lds(slot[k], in0[k], lane);
+            if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
+        }
+        while (true) {
+            wave_lds_fence();
+            T a[9], b[9], o0[9], o1[9];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                I0::read_row(slot[k], lane, k, a);
+                if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, b);
+            }
+            wave_lds_fence();
+            const int64_t tn = t + nwaves;
+            const bool more = tn < nrounds;
+            const int64_t tf = more ? tn : t;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {                 // prefetch: in flight during the arithmetic below.
+                const int64_t u = tf * NPL + k;             // After the last round the descriptor is empty: the
+                const int64_t ue = u < nunits ? u : tf * NPL;   // loads return 0 and cost no traffic.
+                I0::fetch(in0[k], I0::rsrc(op.in0, ue, more), lane);
+                if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, more), lane);
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                ctx.unit[k] = t * NPL + k;
+                ctx.exists[k] = ctx.unit[k] < nunits;       // wave-uniform
+            }
+            op.template compute<T, NPL>(a, b, o0, o1, ctx);
+            if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, o0);
+                    if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, o1);
+                }
+                wave_lds_fence();
+                f32x4 v0[NPL][O0::kLoads], v1[NPL][O1::kLoads];
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    if constexpr (Op::kOut0 != 0) O0::from_lds(v0[k], slot[k], lane);
+                    if constexpr (Op::kOut1 != 0) O1::from_lds(v1[k], slot[k] + O0::kSlotBytes, lane);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {             // a phantom unit's stores are dropped (empty descriptor)
+                    const int64_t ue = ctx.exists[k] ? ctx.unit[k] : 0;
+                    if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, ue, ctx.exists[k]), v0[k], lane);
+                    if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, ue, ctx.exists[k]), v1[k], lane);
+                }
+            }
+            if (!more) break;
+            // The prefetched units land in LDS here, at the END of the body: the loads are older than this
+            // round's stores, so the wait the compiler places is vmcnt(#stores), not a drain of the stores.
+            unsigned long long w0 = 0;
+            if (STAMP) {
+                __builtin_amdgcn_sched_barrier(0);
+                w0 = __builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                I0::to_lds(slot[k], in0[k], lane);
+                if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
+            }
+            if (STAMP) { __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
+            t = tn;
+        }
+    }
+    if (Op::kReduce) {
+        double v = ctx.acc;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        const bool any_flag = __any(ctx.flag);
+        if (lane == 0) { red[wave_in_block] = v; red_flag[wave_in_block] = any_flag ? 1 : 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double total = 0.0;
+            int f = 0;
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) { total += red[w]; f |= red_flag[w]; }
+            op.finish(total, f != 0);
+        }
+    }
+    if (STAMP && wave_id < nrounds) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) {
+            stamps[6 * wave_id + 0] = t_real0;
+            stamps[6 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
+            stamps[6 * wave_id + 2] = t_mem0;
+            // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20): which XCD / SE / CU / SIMD ran this wave
+            const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+            stamps[6 * wave_id + 3] = ((__builtin_amdgcn_s_memtime() - t_mem0) & 0xFFFFFFFull)
+                                      | (static_cast<unsigned long long>(xcc & 0xF) << 28) | (static_cast<unsigned long long>(hw) << 32);
+            stamps[6 * wave_id + 4] = stall_cycles;
+            stamps[6 * wave_id + 5] = first_wait;
+        }
+    }
+}
+
+// ---- the operations --------------------------------------------------------------------------------------
+struct OpBase {
+    const void *in0 = nullptr, *in1 = nullptr;
+    void *out0 = nullptr, *out1 = nullptr;
+    static constexpr bool kReduce = false;
+    __device__ __forceinline__ void finish(double, bool) const {}
+};
+
+// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206).  SWEEPS < 0: copy (diagnostic).
+template <int IN_BYTES, bool FLIP, int SWEEPS = kSweeps, bool ADAPT = true>
+struct OpProject : OpBase {
+    static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    uint8_t *flip = nullptr;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&m)[9], const T (&)[9], T (&r)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+        if constexpr (SWEEPS < 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) r[i] = m[i];
+        } else {
+            const auto f = signed_svd<false, T, SWEEPS, ADAPT>(m);
+            rotation_from(f, r);
+        }
+        if (FLIP) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                float mk_[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) mk_[i] = Tr<T>::get(m[i], k);
+                const unsigned char bit = det_negative(mk_) ? 1 : 0;
+                __builtin_amdgcn_raw_buffer_store_b8(bit, row_rsrc<1>(flip, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane, 0, 0);
+            }
+        }
+    }
+};
+
+// K2: dM = U' Bm V^T for upstream G (autograd of K1).
+template <int M_BYTES>
+struct OpProjectBwd : OpBase {
+    static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&m)[9], const T (&g)[9], T (&dm)[9], T (&)[9], RowCtx<NPL> &) const {
+        const auto f = signed_svd<true, T>(m);
+        project_backward(f, g, dm);
+    }
+};
+
+// K3: head + Frobenius loss + backward in one pass (3D-Pose/main.py:60,85,90).  out0 = dM, out1 = R (each optional).
+template <int M_BYTES, bool WANT_DM, bool WANT_R>
+struct OpFrobHead : OpBase {
+    static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_DM ? M_BYTES : 0, kOut1 = WANT_R ? 4 : 0;
+    static constexpr bool kReduce = true;
+    double *loss_sum = nullptr;
+    float inv_b = 0.f;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&m)[9], const T (&t)[9], T (&dm)[9], T (&r)[9], RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
+        const auto f = signed_svd<WANT_DM, T>(m);
+        rotation_from(f, r);
+        T g[9];
+        T n2 = R::splat(0.f);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            g[i] = r[i] - t[i];                           // d||Rtrue - R||/dR = (R - Rtrue)/||.||
+            n2 = R::fma(g[i], g[i], n2);
+        }
+        const T inv = R::rsq(R::max(n2, R::splat(1e-37f)));
+        const T nrm = n2 * inv;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (ctx.exists[k]) ctx.acc += static_cast<double>(R::get(nrm, k));
+        if (WANT_DM) {
+            const T gs = R::sel(R::gt(n2, R::splat(0.f)), inv * R::splat(inv_b), R::splat(0.f));   // zero difference -> zero gradient
+#pragma unroll
+            for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
+            project_backward(f, g, dm);
+        }
+    }
+    __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
+};
+
+// K3': stand-alone Frobenius loss (3D-Pose/loss.py:7-11).  out0 = d(mean loss)/dRpred (optional).
+template <bool WANT_GRAD>
+struct OpFrobLoss : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = WANT_GRAD ? 4 : 0, kOut1 = 0;
+    static constexpr bool kReduce = true;
+    double *loss_sum = nullptr;
+    float inv_b = 0.f;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&p)[9], const T (&t)[9], T (&g)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
+        T n2 = R::splat(0.f);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { g[i] = p[i] - t[i]; n2 = R::fma(g[i], g[i], n2); }
+        const T inv = R::rsq(R::max(n2, R::splat(1e-37f)));
+        const T nrm = n2 * inv;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (ctx.exists[k]) ctx.acc += static_cast<double>(R::get(nrm, k));
+        const T gs = R::sel(R::gt(n2, R::splat(0.f)), inv * R::splat(inv_b), R::splat(0.f));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
+    }
+    __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
+};
+
+// K4: theta = acos(clamp((tr(R1^T R2) - 1)/2)) in float64 on float32 data (rotation_representation.py:230-242).
+template <bool WANT_DEG, bool WANT_SUM>
+struct OpAngle : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 0, kOut1 = 0;
+    static constexpr bool kReduce = true;
+    double *deg = nullptr, *sum_count = nullptr;
+    int32_t *range_flag = nullptr;
+    double unit_scale = 1.0;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&a)[9], const T (&b)[9], T (&)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            double tr = 0.0;                                 // tr(R1^T R2) = sum_ij R1_ij R2_ij, float64
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(Tr<T>::get(a[i], k)), static_cast<double>(Tr<T>::get(b[i], k)), tr);
+            const double c_raw = (tr - 1.0) * 0.5;
+            if (ctx.exists[k]) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);   // NaN compares false, as torch.any(...) does
+            double c = fmin(fmax(c_raw, -1.0), 1.0);         // torch.clamp ...
+            if (c_raw != c_raw) c = c_raw;                   // ... which keeps NaN (fmin/fmax drop it)
+            const double ang = acos(c) * unit_scale;
+            if (WANT_DEG) {
+                const u32x2 bits = __builtin_bit_cast(u32x2, ang);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc<8>(deg, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane * 8, 0, 0);
+            }
+            if (WANT_SUM && ctx.exists[k]) ctx.acc += ang;
+        }
+    }
+    __device__ __forceinline__ void finish(double total, bool any_flag) const {
+        if (WANT_SUM) atomicAdd(sum_count, total);
+        if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
+    }
+};
+
+// K4': float32 radians, tr(m1 m2^T), hard clamp (rotation_representation.py:209-227).
+struct OpGeodesic : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 0, kOut1 = 0;
+    float *theta = nullptr;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&a)[9], const T (&b)[9], T (&)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
+        // diagonal of m1 m2^T, summed in the reference's order: m00 + m11 + m22
+        const T d0 = R::fma(a[2], b[2], R::fma(a[1], b[1], a[0] * b[0]));
+        const T d1 = R::fma(a[5], b[5], R::fma(a[4], b[4], a[3] * b[3]));
+        const T d2 = R::fma(a[8], b[8], R::fma(a[7], b[7], a[6] * b[6]));
+        const T cs = (d0 + d1 + d2 - R::splat(1.f)) * R::splat(0.5f);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            float c = R::get(cs, k);
+            c = (c > 1.f) ? 1.f : c;     // torch.min / torch.max with a constant: NaN stays NaN
+            c = (c < -1.f) ? -1.f : c;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acosf(c)), row_rsrc<4>(theta, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]),
+                                                  ctx.lane * 4, 0, 0);
+        }
+    }
+};
+
+}  // namespace so3

@@ -1,28 +1,23 @@
-// so3proj.hip -- kernels and C ABI of libso3proj.so (gfx950 only).  See include/so3proj.h.
+// so3proj.hip -- C ABI of libso3proj.so (gfx950 only) and the small-batch kernels.  See include/so3proj.h.
 //
-// Data movement common to K1-K4: one lane owns one 3x3 block, but a lane-per-row global access of
-// 36-byte records is 9 strided dword accesses.  Instead a 256-thread workgroup owns a contiguous
-// tile of 256 blocks (9216 B), moves it with coalesced 16-byte accesses (576 float4 per tile)
-// through LDS, and each lane picks its nine floats out of LDS at a 9-dword stride (odd stride ->
-// conflict-free for ds_read_b32 / ds_write_b32).
+// Large, 16-byte-aligned batches run on the row-streaming engine of so3_rows.h (persistent waves, packed
+// two-matrices-per-lane arithmetic, branch-free buffer I/O).  What is left -- a remainder of < 64 rows,
+// pointers that are not 16-byte aligned, and the Kabsch kernel -- lives here: 256-thread workgroups own a
+// contiguous tile of 256 rows (9216 B), move it with coalesced accesses through LDS, and each lane picks its
+// nine floats out of LDS at a 9-dword stride (odd stride -> conflict-free ds_read_b32 / ds_write_b32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <initializer_list>
 
 #include "../../include/so3proj.h"
 #include "so3_device.h"
-#include "so3_stream.h"
+#include "so3_rows.h"
 
 namespace {
 
 
-#ifndef SO3_STREAM_NPL
-#define SO3_STREAM_NPL 2                    // matrices per lane in the streaming K1 kernel (1 or 2)
-#endif
-#ifndef SO3_STREAM_WAVES_PER_SIMD
-#define SO3_STREAM_WAVES_PER_SIMD 3         // persistent waves per SIMD launched by the streaming kernel
-#endif
 
 constexpr int kBlock = 256;                 // lanes (= 3x3 blocks) per workgroup tile
 constexpr int kTileFloats = kBlock * 9;     // 2304 floats = 9216 B
@@ -424,11 +419,89 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
 }
 
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
+inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); return t < 2048u ? t : 2048u; }
 
 #define SO3_CHECK_ARGS(cond, name) \
     do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
 #define SO3_MAX_B (INT64_C(2147483647) * kBlock)
 
+// Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads.
+template <int NPL, int WPS, int BLOCK, class Op>
+void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
+    constexpr int kWaves = BLOCK / 64;
+    const int64_t rounds = (nunits + NPL - 1) / NPL;
+    const int64_t want = (rounds + kWaves - 1) / kWaves;
+    const int64_t cap = 256LL * 4 * WPS / kWaves;              // 256 CUs x 4 SIMDs x WPS wave slots
+    const dim3 grid(static_cast<unsigned>(want < cap ? want : cap)), block(BLOCK);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), grid, block, 0, s, op, nunits, nullptr);
+}
+
+// Rows [0, 64*nunits) go to the engine when every pointer is 16-byte aligned; the rest to the tile kernels.
+inline int64_t stream_units(int64_t B, std::initializer_list<const void *> ptrs) {
+    for (const void *p : ptrs)
+        if (p != nullptr && !aligned16(p)) return 0;
+    return B / so3::kUnitRows;
+}
+
+template <class T> inline T *advance(T *p, int64_t elems) { return p ? p + elems : nullptr; }
+inline const void *advance_bytes(const void *p, int64_t bytes) { return p ? static_cast<const char *>(p) + bytes : nullptr; }
+inline void *advance_bytes(void *p, int64_t bytes) { return p ? static_cast<char *>(p) + bytes : nullptr; }
+
+// ---- K1 --------------------------------------------------------------------------------------------
+template <bool BF16>
+int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && R != nullptr, "so3_project_fwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int EB = BF16 ? 2 : 4;
+    const int64_t nunits = stream_units(B, {M, R});
+    if (nunits > 0) {
+        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256>(op, nunits, s); }
+        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256>(op, nunits, s); }
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        const void *Mt = advance_bytes(M, done * 9 * EB);
+        float *Rt = R + done * 9;
+        uint8_t *ft = advance(flip, done);
+        const bool vec = (BF16 || aligned16(Mt)) && aligned16(Rt);      // for bf16 input VEC only governs the R store
+        const dim3 grid(grid_for(rest)), block(kBlock);
+#define LAUNCH(VE, FL) hipLaunchKernelGGL((k_project_fwd<BF16, VE, FL>), grid, block, 0, s, Mt, Rt, ft, rest)
+        if (vec) { if (flip) LAUNCH(true, true); else LAUNCH(true, false); }
+        else { if (flip) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    }
+    return check_launch("so3_project_fwd");
+}
+
+// ---- K2 --------------------------------------------------------------------------------------------
+template <bool BF16>
+int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_bwd: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && G != nullptr && dM != nullptr, "so3_project_bwd: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int EB = BF16 ? 2 : 4;
+    const int64_t nunits = stream_units(B, {M, G, dM});
+    if (nunits > 0) {
+        so3::OpProjectBwd<EB> op; op.in0 = M; op.in1 = G; op.out0 = dM;
+        launch_rows<2, 2, 256>(op, nunits, s);
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        const void *Mt = advance_bytes(M, done * 9 * EB);
+        const float *Gt = G + done * 9;
+        void *dt = advance_bytes(dM, done * 9 * EB);
+        const bool vec = aligned16(Gt) && (BF16 || (aligned16(Mt) && aligned16(dt)));
+        const dim3 grid(grid_for(rest)), block(kBlock);
+        if (vec) hipLaunchKernelGGL((k_project_bwd<BF16, true>), grid, block, 0, s, Mt, Gt, dt, rest);
+        else hipLaunchKernelGGL((k_project_bwd<BF16, false>), grid, block, 0, s, Mt, Gt, dt, rest);
+    }
+    return check_launch("so3_project_bwd");
+}
+
+// ---- K3 --------------------------------------------------------------------------------------------
 template <bool BF16>
 int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
@@ -438,16 +511,30 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
-    const unsigned tiles = grid_for(B);
-    const dim3 grid(tiles < 2048u ? tiles : 2048u), block(kBlock);     // persistent: <= 8 workgroups per CU
+    constexpr int EB = BF16 ? 2 : 4;
     const float inv_b = 1.0f / static_cast<float>(B);
-    bool vec = aligned16(Rtrue) && (R == nullptr || aligned16(R));
-    if (!BF16) vec = vec && aligned16(M) && (dM == nullptr || aligned16(dM));
-#define LAUNCH(VE, WR, WD) hipLaunchKernelGGL((k_frob_fwd_bwd<BF16, VE, WR, WD>), grid, block, 0, s, M, Rtrue, R, dM, loss_sum, B, inv_b)
+    const int64_t nunits = stream_units(B, {M, Rtrue, R, dM});
+    if (nunits > 0) {
+#define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
+                             op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<2, 2, 512>(op, nunits, s); } while (0)
+        if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
+#undef SLAUNCH
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        const void *Mt = advance_bytes(M, done * 9 * EB);
+        const float *Tt = Rtrue + done * 9;
+        float *Rt = advance(R, done * 9);
+        void *dt = advance_bytes(dM, done * 9 * EB);
+        bool vec = aligned16(Tt) && (Rt == nullptr || aligned16(Rt));
+        if (!BF16) vec = vec && aligned16(Mt) && (dt == nullptr || aligned16(dt));
+        const dim3 grid(persistent_grid(rest)), block(kBlock);
+#define LAUNCH(VE, WR, WD) hipLaunchKernelGGL((k_frob_fwd_bwd<BF16, VE, WR, WD>), grid, block, 0, s, Mt, Tt, Rt, dt, loss_sum, rest, inv_b)
 #define PICK(VE) do { if (R && dM) LAUNCH(VE, true, true); else if (R) LAUNCH(VE, true, false); else if (dM) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
-    if (vec) PICK(true); else PICK(false);
+        if (vec) PICK(true); else PICK(false);
 #undef PICK
 #undef LAUNCH
+    }
     return check_launch("so3_frob_fwd_bwd");
 }
 
@@ -461,79 +548,18 @@ extern "C" {
 int so3_version(void) { return SO3PROJ_VERSION; }
 const char *so3_last_error(void) { return g_err; }
 
-
-// Streaming launch geometry: one resident wave slot per (CU, SIMD, slot), tiles dealt round-robin.
-static unsigned stream_grid(int64_t ntiles /* wave rounds */, int waves_per_simd) {
-    const int64_t max_blocks = 256LL * waves_per_simd;                 // 256 CUs x (4 SIMDs x slots / 4 waves per block)
-    const int64_t want = (ntiles + so3::kWavesPerBlock - 1) / so3::kWavesPerBlock;
-    return static_cast<unsigned>(want < max_blocks ? want : max_blocks);
-}
-
-static int project_fwd(bool bf16, const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
-    if (B == 0) return 0;
-    SO3_CHECK_ARGS(M != nullptr && R != nullptr, "so3_project_fwd: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 block(kBlock);
-    const bool vec = (bf16 || aligned16(M)) && aligned16(R);   // for bf16 input VEC only governs the R store
-    constexpr int kNpl = SO3_STREAM_NPL;                       // matrices per lane in the streaming kernel
-    if (!bf16 && vec && B >= so3::kUnitRows) {
-        // full 64-row units stream through the persistent kernel; a < 64-row remainder goes to the block-tile kernel
-        const int64_t nunits = B / so3::kUnitRows;
-        const dim3 sgrid(stream_grid((nunits + kNpl - 1) / kNpl, SO3_STREAM_WAVES_PER_SIMD));
-        const float *Mf = static_cast<const float *>(M);
-        if (flip) hipLaunchKernelGGL((so3::k_project_fwd_stream<kNpl, true, SO3_STREAM_WAVES_PER_SIMD>), sgrid, block, 0, s, Mf, R, flip, nunits, nullptr);
-        else hipLaunchKernelGGL((so3::k_project_fwd_stream<kNpl, false, SO3_STREAM_WAVES_PER_SIMD>), sgrid, block, 0, s, Mf, R, flip, nunits, nullptr);
-        const int64_t done = nunits * so3::kUnitRows;
-        if (done < B) {
-            const void *Mt = Mf + done * 9;
-            float *Rt = R + done * 9;
-            uint8_t *ft = flip ? flip + done : nullptr;
-            const int64_t rest = B - done;
-            if (flip) hipLaunchKernelGGL((k_project_fwd<false, false, true>), dim3(1), block, 0, s, Mt, Rt, ft, rest);
-            else hipLaunchKernelGGL((k_project_fwd<false, false, false>), dim3(1), block, 0, s, Mt, Rt, ft, rest);
-        }
-        return check_launch("so3_project_fwd");
-    }
-    const dim3 grid(grid_for(B));
-#define LAUNCH(BF, VE, FL) hipLaunchKernelGGL((k_project_fwd<BF, VE, FL>), grid, block, 0, s, M, R, flip, B)
-#define PICK(BF) do { if (vec) { if (flip) LAUNCH(BF, true, true); else LAUNCH(BF, true, false); } \
-                      else { if (flip) LAUNCH(BF, false, true); else LAUNCH(BF, false, false); } } while (0)
-    if (bf16) PICK(true); else PICK(false);
-#undef PICK
-#undef LAUNCH
-    return check_launch("so3_project_fwd");
-}
-
 int so3_project_fwd_f32(const float *M, float *R, uint8_t *flip, int64_t B, void *stream) {
-    return project_fwd(false, M, R, flip, B, stream);
+    return project_fwd<false>(M, R, flip, B, stream);
 }
 int so3_project_fwd_bf16(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
-    return project_fwd(true, M, R, flip, B, stream);
-}
-
-static int project_bwd(bool bf16, const void *M, const float *G, void *dM, int64_t B, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_bwd: B");
-    if (B == 0) return 0;
-    SO3_CHECK_ARGS(M != nullptr && G != nullptr && dM != nullptr, "so3_project_bwd: null pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(B)), block(kBlock);
-    if (bf16) {
-        if (aligned16(G)) hipLaunchKernelGGL((k_project_bwd<true, true>), grid, block, 0, s, M, G, dM, B);
-        else hipLaunchKernelGGL((k_project_bwd<true, false>), grid, block, 0, s, M, G, dM, B);
-    } else {
-        if (aligned16(M) && aligned16(G) && aligned16(dM)) hipLaunchKernelGGL((k_project_bwd<false, true>), grid, block, 0, s, M, G, dM, B);
-        else hipLaunchKernelGGL((k_project_bwd<false, false>), grid, block, 0, s, M, G, dM, B);
-    }
-    return check_launch("so3_project_bwd");
+    return project_fwd<true>(M, R, flip, B, stream);
 }
 int so3_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B, void *stream) {
-    return project_bwd(false, M, G, dM, B, stream);
+    return project_bwd<false>(M, G, dM, B, stream);
 }
 int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, void *stream) {
-    return project_bwd(true, M, G, dM, B, stream);
+    return project_bwd<true>(M, G, dM, B, stream);
 }
-
 int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
     return frob<false>(M, Rtrue, R, dM, loss_sum, B, stream);
 }
@@ -549,14 +575,23 @@ int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, dou
     if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
-    const unsigned tiles = grid_for(B);
-    const dim3 grid(tiles < 2048u ? tiles : 2048u), block(kBlock);
     const float inv_b = 1.0f / static_cast<float>(B);
-    const bool vec = aligned16(Rpred) && aligned16(Rtrue) && (dRpred == nullptr || aligned16(dRpred));
-#define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b)
-    if (vec) { if (dRpred) LAUNCH(true, true); else LAUNCH(true, false); }
-    else { if (dRpred) LAUNCH(false, true); else LAUNCH(false, false); }
+    const int64_t nunits = stream_units(B, {Rpred, Rtrue, dRpred});
+    if (nunits > 0) {
+        if (dRpred) { so3::OpFrobLoss<true> op; op.in0 = Rpred; op.in1 = Rtrue; op.out0 = dRpred; op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<1, 6, 512>(op, nunits, s); }
+        else { so3::OpFrobLoss<false> op; op.in0 = Rpred; op.in1 = Rtrue; op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<1, 6, 512>(op, nunits, s); }
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        const float *Pt = Rpred + done * 9, *Tt = Rtrue + done * 9;
+        float *gt = advance(dRpred, done * 9);
+        const bool vec = aligned16(Pt) && aligned16(Tt) && (gt == nullptr || aligned16(gt));
+        const dim3 grid(persistent_grid(rest)), block(kBlock);
+#define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Pt, Tt, gt, loss_sum, rest, inv_b)
+        if (vec) { if (dRpred) LAUNCH(true, true); else LAUNCH(true, false); }
+        else { if (dRpred) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
+    }
     return check_launch("so3_frob_loss_f32");
 }
 
@@ -566,26 +601,26 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
     hipStream_t s = static_cast<hipStream_t>(stream);
     // one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
     if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
-    if (B == 0) return 0;
+    if (B == 0) return check_launch("so3_angle_error");
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
-    const bool vec = aligned16(R1) && aligned16(R2);
-    const int64_t nunits = vec ? B / so3::kUnitRows : 0;       // full 64-row units take the streaming kernel
-    const int64_t done = nunits * so3::kUnitRows;
+    const int64_t nunits = stream_units(B, {R1, R2, deg});
     if (nunits > 0) {
-        const int64_t want = (nunits + so3::kAngleWaves - 1) / so3::kAngleWaves;
-        const dim3 sgrid(static_cast<unsigned>(want < 768 ? want : 768)), sblock(so3::kAngleBlock);   // 3 workgroups per CU
-#define SLAUNCH(WD, WS) hipLaunchKernelGGL((so3::k_angle_error_stream<WD, WS>), sgrid, sblock, 0, s, R1, R2, deg, sum_count, range_flag, unit, nunits)
+#define SLAUNCH(WD, WS) do { so3::OpAngle<WD, WS> op; op.in0 = R1; op.in1 = R2; op.deg = deg; op.sum_count = sum_count; \
+                             op.range_flag = range_flag; op.unit_scale = unit; launch_rows<1, 6, 512>(op, nunits, s); } while (0)
         if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
-    if (done < B) {                                            // remainder (< 64 rows) or unaligned input
-        const int64_t rest = B - done;
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {                                            // remainder (< 64 rows) or unaligned input
         const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
-        double *dg = deg ? deg + done : nullptr;
+        double *dg = advance(deg, done);
+        const bool vec = aligned16(A1) && aligned16(A2);
         const dim3 grid(grid_for(rest)), block(kBlock);
-#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_error<false, WD, WS>), grid, block, 0, s, A1, A2, dg, sum_count, range_flag, unit, rest)
-        if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
+#define LAUNCH(VE, WD, WS) hipLaunchKernelGGL((k_angle_error<VE, WD, WS>), grid, block, 0, s, A1, A2, dg, sum_count, range_flag, unit, rest)
+#define PICK(VE) do { if (deg && sum_count) LAUNCH(VE, true, true); else if (deg) LAUNCH(VE, true, false); else if (sum_count) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
+        if (vec) PICK(true); else PICK(false);
+#undef PICK
 #undef LAUNCH
     }
     return check_launch("so3_angle_error");
@@ -596,9 +631,18 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && theta != nullptr, "so3_geodesic_f32: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid(grid_for(B)), block(kBlock);
-    if (aligned16(R1) && aligned16(R2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, R1, R2, theta, B);
-    else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, R1, R2, theta, B);
+    const int64_t nunits = stream_units(B, {R1, R2, theta});
+    if (nunits > 0) {
+        so3::OpGeodesic op; op.in0 = R1; op.in1 = R2; op.theta = theta;
+        launch_rows<2, 4, 256>(op, nunits, s);
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
+        const dim3 grid(grid_for(rest)), block(kBlock);
+        if (aligned16(A1) && aligned16(A2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, A1, A2, theta + done, rest);
+        else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, theta + done, rest);
+    }
     return check_launch("so3_geodesic_f32");
 }
 

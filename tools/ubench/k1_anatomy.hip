@@ -1,5 +1,5 @@
 // k1_anatomy: stand-alone timing / in-kernel-stamp tool for the streaming K1 kernel.
-// Instantiates the SAME kernel template the library ships (csrc/so3_stream.h) in several
+// Instantiates the SAME kernel template the library ships (csrc/so3_rows.h) in several
 // geometries, times each with hipEvents over rotating buffers, and (STAMP build of the same
 // template) reports per-wave lifetimes and the shader clock from s_memtime / s_memrealtime.
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -o k1_anatomy k1_anatomy.hip
@@ -9,7 +9,7 @@
 #include <stdlib.h>
 #include <vector>
 
-#include "../../poseestimation_amd/csrc/so3_stream.h"
+#include "../../poseestimation_amd/csrc/so3_rows.h"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -34,18 +34,20 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
     const int64_t want = (rounds + 3) / 4;
     const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * WPS);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    typedef so3::OpProject<4, false, SWEEPS, ADAPT> Op;
+    auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, false>), dim3(blocks), dim3(256), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
     const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, false, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[i % NBUF], out[i % NBUF], nullptr, nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, false>), dim3(blocks), dim3(256), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
-    hipLaunchKernelGGL((so3::k_project_fwd_stream<NPL, false, WPS, true, SWEEPS, ADAPT>), dim3(blocks), dim3(256), 0, 0, in[0], out[0], nullptr, nunits, stamps_d);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, true>), dim3(blocks), dim3(256), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
     const int64_t nw = std::min<int64_t>((int64_t)blocks * 4, rounds);
     std::vector<unsigned long long> st6(6 * nw); std::vector<unsigned long long> st(4 * nw);
