@@ -230,7 +230,7 @@ def main():
                        "submission": "eager launches" if args.eager else "one hipGraph of K kernel launches, replayed"},
             "mean_angle_error_deg": mean_angle,
             "mean_angle_error_delta_vs_ref_deg": delta,
-            "roofline": {"bound": "hbm", "kernel": "so3::k_project_fwd_stream<2,false,3>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "so3::k_rows<OpProject<4,false>,NPL=2,WPS=3,256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},

@@ -27,29 +27,30 @@ __global__ void fill(float *p, int64_t n, unsigned seed) {
     }
 }
 
-template <int NPL, int WPS, int SWEEPS, bool ADAPT>
+template <int NPL, int WPS, int SWEEPS, bool ADAPT, int BLOCK = 256>
 void run(float **in, float **out, unsigned long long *stamps_d) {
     const int64_t nunits = ROWS / 64;
     const int64_t rounds = (nunits + NPL - 1) / NPL;
-    const int64_t want = (rounds + 3) / 4;
-    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * WPS);
+    constexpr int kW = BLOCK / 64;
+    const int64_t want = (rounds + kW - 1) / kW;
+    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     typedef so3::OpProject<4, false, SWEEPS, ADAPT> Op;
     auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, false>), dim3(blocks), dim3(256), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
     const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, false>), dim3(blocks), dim3(256), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, 256, true>), dim3(blocks), dim3(256), 0, 0, mk(0), nunits, stamps_d);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
-    const int64_t nw = std::min<int64_t>((int64_t)blocks * 4, rounds);
+    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, rounds);
     std::vector<unsigned long long> st6(6 * nw); std::vector<unsigned long long> st(4 * nw);
     CHECK(hipMemcpy(st6.data(), stamps_d, st6.size() * 8, hipMemcpyDeviceToHost));
     double stall = 0, fw = 0;
@@ -68,7 +69,7 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
         FILE *fh = fopen(name, "w");
         if (fh) {
             fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc\n");
-            const int64_t nwv = (int64_t)blocks * 4;
+            const int64_t nwv = (int64_t)blocks * kW;
             for (int64_t w = 0; w < nw; ++w) {
                 const int64_t nr = (rounds - w + nwv - 1) / nwv;
                 fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu\n", (long long)w, (long long)nr, (double)(st[4 * w] - r0) * 0.01,
@@ -77,9 +78,9 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
             fclose(fh);
         }
     }
-    printf("NPL=%d WPS=%d sweeps=%d%s blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("NPL=%d WPS=%d sweeps=%d%s block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
 }
 
@@ -91,13 +92,14 @@ int main() {
     }
     unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 6 * 8192 * 4));
     CHECK(hipDeviceSynchronize());
-    for (int k : {40, 200}) {
+    for (int k : {40, 200, 200}) {
         g_launches = k;
         printf("--- %d timed launches per measurement\n", k);
-        run<2, 3, -1, false>(in, out, stamps);
-        run<2, 3, 3, true>(in, out, stamps);
-        run<2, 4, 3, true>(in, out, stamps);
-        run<1, 8, 3, true>(in, out, stamps);
+        run<2, 3, 3, true, 256>(in, out, stamps);
+        run<2, 3, 3, true, 192>(in, out, stamps);
+        run<2, 3, 3, true, 384>(in, out, stamps);
+        run<2, 3, 3, true, 768>(in, out, stamps);
+        run<2, 3, -1, false, 768>(in, out, stamps);
     }
     return 0;
 }
