@@ -107,6 +107,16 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
  * point_cloud/main.py:43-57). */
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream);
 
+/* ---- next row: the 6D Gram-Schmidt head and its backward -------------------------
+ * x = a/|a|, z = (x x b)/|x x b|, y = z x x, R = [x y z] as columns; (a, b) = the two halves of each 6-vector.
+ * Replaces rotation_representation.py:21-36 (compute_rotation_matrix_from_ortho6d; duplicate at :174-189),
+ * the reference's main comparison head (transform_output['6D'], Comparison/models.py:19).
+ *   X in B*6 float32;  R out B*9 float32;  G in B*9 float32 (dL/dR);  dX out B*6 float32.
+ * No epsilon in the norms, as in the reference: a zero or parallel pair gives Inf/NaN.
+ */
+int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream);
+int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+
 /* ---- K5: fused Kabsch (config #3) ------------------------------------------------------------------
  * H_b = sum_i q_bi p_bi^T (= bmm(Q^T, P)),  R_b = proj_SO(3)(H_b) = argmin_R sum_i |R p_bi - q_bi|^2.
  * No centring: the reference's pairing rule q = R p has no translation (point_cloud/main.py:173-181).

@@ -22,6 +22,7 @@ Reference lines followed (all under /root/reference):
   angle_error                          rotation_representation.py:230-242
   loss_frobenius                       3D-Pose/loss.py:7-11
   rotation sampler (Kabsch pairs)      point_cloud/prepare.py:21-49, point_cloud/main.py:173-181
+  6D Gram-Schmidt head (next row f2)   rotation_representation.py:21-36
 """
 from __future__ import annotations
 
@@ -157,6 +158,37 @@ def kabsch_np(p, q):
     """argmin_R sum_i |R p_i - q_i|^2 over SO(3) = proj(H) (no centring, as the pairing rule
     point_cloud/main.py:173-181 has no translation)."""
     return symmetric_orthogonalization_np(cross_covariance_np(p, q))
+
+
+def ortho6d_np(poses):
+    """6D head: x = a/|a|, z = (x x b)/|.|, y = z x x, columns (x, y, z)  (rotation_representation.py:21-36)."""
+    p = np.asarray(poses, np.float64)
+    a, b = p[..., 0:3], p[..., 3:6]                                  # :29-30
+    x = a / np.linalg.norm(a, axis=-1, keepdims=True)                # :31
+    z = np.cross(x, b)                                               # :32
+    z = z / np.linalg.norm(z, axis=-1, keepdims=True)                # :33
+    y = np.cross(z, x)                                               # :34
+    return np.stack((x, y, z), -1)                                   # :35
+
+
+def ortho6d_backward_np(poses, g):
+    """dL/dposes for the 6D head given G = dL/dR (closed form; checked against the reference's autograd)."""
+    p = np.asarray(poses, np.float64).reshape(-1, 6)
+    g = np.asarray(g, np.float64).reshape(-1, 3, 3)
+    a, b = p[:, 0:3], p[:, 3:6]
+    na = np.linalg.norm(a, axis=1, keepdims=True)
+    x = a / na
+    w = np.cross(x, b)
+    nw = np.linalg.norm(w, axis=1, keepdims=True)
+    z = w / nw
+    gx, gy, gz = g[:, :, 0], g[:, :, 1], g[:, :, 2]
+    gzt = gz + np.cross(x, gy)                                       # y = z x x
+    gxt = gx + np.cross(gy, z)
+    gw = (gzt - z * (z * gzt).sum(1, keepdims=True)) / nw            # z = w/|w|
+    gxt = gxt + np.cross(b, gw)                                      # w = x x b
+    gb = np.cross(gw, x)
+    ga = (gxt - x * (x * gxt).sum(1, keepdims=True)) / na            # x = a/|a|
+    return np.concatenate((ga, gb), 1)
 
 
 # --------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@ henrikgruner/PoseEstimation's rotation_representation.py).  See DESIGN.md / INTE
 from .rotation_representation import (  # noqa: F401
     angle_error,
     compute_geodesic_distance_from_two_matrices,
+    compute_rotation_matrix_from_ortho6d,
     frobenius_head,
     kabsch_rotation,
     loss_frobenius,
@@ -14,6 +15,7 @@ __all__ = [
     "symmetric_orthogonalization",
     "angle_error",
     "compute_geodesic_distance_from_two_matrices",
+    "compute_rotation_matrix_from_ortho6d",
     "loss_frobenius",
     "frobenius_head",
     "kabsch_rotation",

@@ -53,12 +53,15 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return u;
 }
 
-// ---- one array's unit: geometry and movers; EB = element bytes (4: float32, 2: bfloat16, 0: array absent) ----
-template <int EB> struct UnitIO {
-    static constexpr int kBytes = kUnitRows * 9 * EB;            // 2304 / 1152
-    static constexpr int kVec4 = kBytes / 16;                    // 144 / 72
-    static constexpr int kLoads = (kVec4 + 63) / 64;             // 3 / 2 float4 per lane (last one partial)
-    static constexpr int kSlotBytes = kLoads * 64 * 16;          // 3072 / 2048: LDS slot incl. padding
+// ---- one array's unit: geometry and movers ---------------------------------------------------------------
+// EB = element bytes (4: float32, 2: bfloat16, 0: array absent), N = elements per row (9 for 3x3 blocks, 6 for
+// the 6D head's input).  An odd N keeps the stride-N LDS accesses conflict-free; N = 6 is 2-way conflicted.
+template <int EB, int N = 9> struct UnitIO {
+    static constexpr int kBytes = kUnitRows * N * EB;            // 2304 (f32 x 9) / 1152 (bf16 x 9) / 1536 (f32 x 6)
+    static constexpr int kVec4 = kBytes / 16;                    // 144 / 72 / 96
+    static constexpr int kLoads = (kVec4 + 63) / 64;             // 3 / 2 / 2 float4 per lane (last one partial)
+    static constexpr int kSlotBytes = kLoads * 64 * 16;          // 3072 / 2048 / 2048: LDS slot incl. padding
+    static_assert(kBytes % 16 == 0, "a unit must be a whole number of float4");
 
     // `unit` is wave-uniform (SGPR) by construction
     static __device__ __forceinline__ rsrc_t rsrc(const void *base, int64_t unit, bool exists) {
@@ -86,25 +89,25 @@ template <int EB> struct UnitIO {
         for (int j = 0; j < kLoads; ++j) v[j] = t4[lane + 64 * j];
     }
     // component k of the lane's row <-> LDS slot, as float
-    template <class T> static __device__ __forceinline__ void read_row(const char *slot, int lane, int k, T (&m)[9]) {
+    template <class T> static __device__ __forceinline__ void read_row(const char *slot, int lane, int k, T (&m)[N]) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < N; ++i) {
             float v;
-            if (EB == 4) v = reinterpret_cast<const float *>(slot)[lane * 9 + i];
-            else v = bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(slot)[lane * 9 + i]);
+            if (EB == 4) v = reinterpret_cast<const float *>(slot)[lane * N + i];
+            else v = bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(slot)[lane * N + i]);
             Tr<T>::set(m[i], k, v);
         }
     }
-    template <class T> static __device__ __forceinline__ void write_row(char *slot, int lane, int k, const T (&m)[9]) {
+    template <class T> static __device__ __forceinline__ void write_row(char *slot, int lane, int k, const T (&m)[N]) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < N; ++i) {
             const float v = Tr<T>::get(m[i], k);
-            if (EB == 4) reinterpret_cast<float *>(slot)[lane * 9 + i] = v;
-            else reinterpret_cast<uint16_t *>(slot)[lane * 9 + i] = f32_to_bf16_bits(v);
+            if (EB == 4) reinterpret_cast<float *>(slot)[lane * N + i] = v;
+            else reinterpret_cast<uint16_t *>(slot)[lane * N + i] = f32_to_bf16_bits(v);
         }
     }
 };
-template <> struct UnitIO<0> {
+template <int N> struct UnitIO<0, N> {
     static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0;
 };
 
@@ -129,7 +132,8 @@ template <int NPL> struct RowCtx {
 
 // ---- the engine ----------------------------------------------------------------------------------------
 // Op provides: kIn0, kIn1, kOut0, kOut1 (element bytes, 0 = absent), pointers in0, in1, out0, out1,
-//   template <class T, int NPL> void compute(const T (&a)[9], const T (&b)[9], T (&o0)[9], T (&o1)[9], RowCtx<NPL> &)
+//   kIn0N .. kOut1N (elements per row, 9 unless overridden),
+//   template <class T, int NPL> void compute(const T (&a)[kIn0N], const T (&b)[kIn1N], T (&o0)[kOut0N], T (&o1)[kOut1N], RowCtx<NPL> &)
 //   void finish(double block_total, bool any_flag)      -- called by thread 0 of each workgroup at the end
 //   kReduce: whether acc/flag are used.
 // WPS = resident waves per SIMD the register budget is sized for (the host launches 256 * WPS * 256 / BLOCK
@@ -139,10 +143,10 @@ template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
-    typedef UnitIO<Op::kIn0> I0;
-    typedef UnitIO<Op::kIn1> I1;
-    typedef UnitIO<Op::kOut0> O0;
-    typedef UnitIO<Op::kOut1> O1;
+    typedef UnitIO<Op::kIn0, Op::kIn0N> I0;
+    typedef UnitIO<Op::kIn1, Op::kIn1N> I1;
+    typedef UnitIO<Op::kOut0, Op::kOut0N> O0;
+    typedef UnitIO<Op::kOut1, Op::kOut1N> O1;
     constexpr int kWaves = BLOCK / 64;
     // LDS slot of one unit: the input slots side by side; outputs are staged over them once the rows are in registers
     constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes;
@@ -182,7 +186,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         }
         while (true) {
             wave_lds_fence();
-            T a[9], b[9], o0[9], o1[9];
+            T a[Op::kIn0N], b[Op::kIn1N], o0[Op::kOut0N], o1[Op::kOut1N];
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 I0::read_row(slot[k], lane, k, a);
@@ -279,6 +283,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 
 // ---- the operations --------------------------------------------------------------------------------------
 struct OpBase {
+    static constexpr int kIn0N = 9, kIn1N = 9, kOut0N = 9, kOut1N = 9;     // elements per row of each array
     const void *in0 = nullptr, *in1 = nullptr;
     void *out0 = nullptr, *out1 = nullptr;
     static constexpr bool kReduce = false;
@@ -435,6 +440,54 @@ struct OpGeodesic : OpBase {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acosf(c)), row_rsrc<4>(theta, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]),
                                                   ctx.lane * 4, 0, 0);
         }
+    }
+};
+
+// ---- next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36) --------------------------------
+// x = a/|a|,  z = (x x b)/|x x b|,  y = z x x,  R = [x y z] (columns); a, b = the two halves of the 6-vector.
+struct OpOrtho6d : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 6;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&p)[6], const T (&)[9], T (&r)[9], T (&)[9], RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
+        const V3<T> x = scale<T>(a, R::rsq(dot(a, a)));
+        const V3<T> w = cross<T>(x, b);
+        const V3<T> z = scale<T>(w, R::rsq(dot(w, w)));
+        const V3<T> y = cross<T>(z, x);
+        r[0] = x.x; r[1] = y.x; r[2] = z.x;
+        r[3] = x.y; r[4] = y.y; r[5] = z.y;
+        r[6] = x.z; r[7] = y.z; r[8] = z.z;
+    }
+};
+
+// Its backward: in0 = poses (B,6), in1 = G = dL/dR (B,9), out0 = dL/dposes (B,6).
+struct OpOrtho6dBwd : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 6, kOut0N = 6;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(const T (&p)[6], const T (&g)[9], T (&dp)[6], T (&)[9], RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
+        const T ia = R::rsq(dot(a, a));
+        const V3<T> x = scale<T>(a, ia);
+        const V3<T> w = cross<T>(x, b);
+        const T iw = R::rsq(dot(w, w));
+        const V3<T> z = scale<T>(w, iw);
+        const V3<T> gx = mk<T>(g[0], g[3], g[6]), gy = mk<T>(g[1], g[4], g[7]), gz = mk<T>(g[2], g[5], g[8]);   // columns of G
+        // y = z x x :  gz += x x gy ,  gx += gy x z
+        const V3<T> gzt = axpy<T>(R::splat(1.f), cross<T>(x, gy), gz);
+        V3<T> gxt = axpy<T>(R::splat(1.f), cross<T>(gy, z), gx);
+        // z = w/|w| :  gw = (gz - z (z.gz)) / |w|
+        const V3<T> gw = scale<T>(axpy<T>(-dot(z, gzt), z, gzt), iw);
+        // w = x x b :  gx += b x gw ,  gb = gw x x
+        gxt = axpy<T>(R::splat(1.f), cross<T>(b, gw), gxt);
+        const V3<T> gb = cross<T>(gw, x);
+        // x = a/|a| :  ga = (gx - x (x.gx)) / |a|
+        const V3<T> ga = scale<T>(axpy<T>(-dot(x, gxt), x, gxt), ia);
+        dp[0] = ga.x; dp[1] = ga.y; dp[2] = ga.z;
+        dp[3] = gb.x; dp[4] = gb.y; dp[5] = gb.z;
     }
 };
 

@@ -418,6 +418,31 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
     }
 }
 
+// ---- 6D head, one row per thread: remainder (< 64 rows) and unaligned input of the streaming kernels ----------
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict__ X, const float *__restrict__ G,
+                                                         float *__restrict__ out, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= B) return;
+    float p[6], g[9], r[9], dp[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) p[i] = X[row * 6 + i];
+    so3::RowCtx<1> ctx{};
+    if (BWD) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = G[row * 9 + i];
+        so3::OpOrtho6dBwd op;
+        op.compute<float, 1>(p, g, dp, r, ctx);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) out[row * 6 + i] = dp[i];
+    } else {
+        so3::OpOrtho6d op;
+        op.compute<float, 1>(p, g, r, g, ctx);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[row * 9 + i] = r[i];
+    }
+}
+
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
 inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); return t < 2048u ? t : 2048u; }
 
@@ -644,6 +669,30 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
         else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, theta + done, rest);
     }
     return check_launch("so3_geodesic_f32");
+}
+
+int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_ortho6d_fwd_f32: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(X != nullptr && R != nullptr, "so3_ortho6d_fwd_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nunits = stream_units(B, {X, R});
+    if (nunits > 0) { so3::OpOrtho6d op; op.in0 = X; op.out0 = R; launch_rows<2, 4, 256>(op, nunits, s); }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) hipLaunchKernelGGL((k_ortho6d_rows<false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, X + done * 6, nullptr, R + done * 9, rest);
+    return check_launch("so3_ortho6d_fwd_f32");
+}
+
+int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_ortho6d_bwd_f32: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(X != nullptr && G != nullptr && dX != nullptr, "so3_ortho6d_bwd_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nunits = stream_units(B, {X, G, dX});
+    if (nunits > 0) { so3::OpOrtho6dBwd op; op.in0 = X; op.in1 = G; op.out0 = dX; launch_rows<2, 4, 256>(op, nunits, s); }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) hipLaunchKernelGGL((k_ortho6d_rows<true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, X + done * 6, G + done * 9, dX + done * 6, rest);
+    return check_launch("so3_ortho6d_bwd_f32");
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {

@@ -299,6 +299,42 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
     return (r, h) if return_h else r
 
 
+# --------------------------------------------------------------------------------------------
+# next row f2: the 6D Gram-Schmidt head
+# --------------------------------------------------------------------------------------------
+class _Ortho6d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, poses):
+        dev = _require_device(poses)
+        if poses.shape[-1] != 6:
+            raise AssertionError("compute_rotation_matrix_from_ortho6d expects (..., 6) poses")   # reference: assert, :28
+        x = poses.detach().reshape(-1, 6).contiguous().float()
+        b = x.shape[0]
+        r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_ortho6d_fwd_f32(_ptr(x), _ptr(r), b, _stream(dev)), "so3_ortho6d_fwd_f32")
+        ctx.save_for_backward(x)
+        ctx.in_shape, ctx.in_dtype = poses.shape, poses.dtype
+        return r.view(*poses.shape[:-1], 3, 3)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_r):
+        (x,) = ctx.saved_tensors
+        dev = x.device
+        g = grad_r.reshape(-1, 9).contiguous().float()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_ortho6d_bwd_f32(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_ortho6d_bwd_f32")
+        return dx.to(ctx.in_dtype).view(ctx.in_shape)
+
+
+def compute_rotation_matrix_from_ortho6d(poses: torch.Tensor) -> torch.Tensor:
+    """6D (two 3-vectors) -> rotation by Gram-Schmidt, columns (x, y, z); rotation_representation.py:21-36.
+    poses: (..., 6); returns (..., 3, 3) float32, differentiable."""
+    return _Ortho6d.apply(poses)
+
+
 # Head dispatch table, keyed like the reference's (rotation_representation.py:323-324;
-# Comparison/models.py:18-19; 3D-Pose/main.py:46).  Only the SVD head is in scope.
-transform_output = {"SVD": (9, symmetric_orthogonalization)}
+# Comparison/models.py:18-19; 3D-Pose/main.py:46).  The SVD head is the scope of SURVEY.md section 8; '6D' is its next row f2.
+transform_output = {"SVD": (9, symmetric_orthogonalization), "6D": (6, compute_rotation_matrix_from_ortho6d)}

@@ -379,3 +379,35 @@ def test_loss_frobenius_standalone_matches_definition(rr):
     q = torch.eye(3, device=DEV).repeat(4, 1, 1).requires_grad_(True)
     rr.loss_frobenius(q, torch.eye(3, device=DEV).repeat(4, 1, 1)).backward()
     assert torch.isfinite(q.grad).all() and q.grad.abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36)
+# ------------------------------------------------------------------------------------------------
+def test_g7_ortho6d_head_forward_backward(rr, pa):
+    from oracle import so3_oracle as so
+    g = load_golden("g7_ortho6d.npz")
+    p = dev(g["p"]).requires_grad_(True)
+    r = rr.compute_rotation_matrix_from_ortho6d(p)
+    assert tuple(r.shape) == (300, 3, 3)
+    assert np.abs(r.detach().cpu().numpy() - g["r_f64"]).max() < 2e-6
+    assert np.abs(r.detach().cpu().numpy() - g["r"]).max() < 2e-6        # vs the reference's float32 output
+    r.backward(dev(g["g"]))
+    ref = g["dp_f64"]
+    rel = np.abs(p.grad.cpu().numpy() - ref).max(1) / (1e-3 + np.abs(ref).max(1))
+    assert np.median(rel) < 1e-6 and rel.max() < 2e-4
+    # shape rule (..., 6) -> (..., 3, 3), dispatch table, ragged sizes through the remainder kernel
+    rs = rr.compute_rotation_matrix_from_ortho6d(dev(g["p_shaped"]))
+    assert tuple(rs.shape) == (2, 5, 3, 3) and np.abs(rs.cpu().numpy() - g["r_shaped"]).max() < 2e-6
+    assert pa.transform_output["6D"][0] == 6 and pa.transform_output["6D"][1] is rr.compute_rotation_matrix_from_ortho6d
+    with pytest.raises(AssertionError):
+        rr.compute_rotation_matrix_from_ortho6d(torch.zeros(4, 9, device=DEV))
+    for b in (1, 63, 64, 65, 1000, 100_003):
+        x = torch.randn(b, 6, device=DEV)
+        out = rr.compute_rotation_matrix_from_ortho6d(x).cpu().numpy()
+        assert np.abs(out - so.ortho6d_np(x.cpu().numpy())).max() < 5e-6
+        assert orth_err(out).max() < 1e-5
+    big = torch.randn(1_000_000, 6, device=DEV, requires_grad=True)
+    rb = rr.compute_rotation_matrix_from_ortho6d(big)
+    rb.backward(torch.randn(1_000_000, 3, 3, device=DEV))
+    assert torch.isfinite(big.grad).all() and (torch.linalg.det(rb.detach().double()) - 1).abs().max().item() < 1e-5

@@ -163,3 +163,16 @@ def test_rotation_sampler_matches_reference_formula():
     r = so.sample_rotations_axis_angle_np(np.random.default_rng(0), 1000)
     assert orth_err(r).max() < 1e-12 and np.abs(np.linalg.det(r) - 1).max() < 1e-12
     assert orth_err(g["r_gt"]).max() < 1e-5
+
+
+def test_g7_ortho6d_oracle():
+    """Next row f2: the 6D head restatement and its closed-form backward against the reference + autograd."""
+    g = load_golden("g7_ortho6d.npz")
+    r = so.ortho6d_np(g["p"])
+    assert np.abs(r - g["r_f64"]).max() < 1e-12
+    assert np.abs(r - g["r"]).max() < 2e-5
+    dp = so.ortho6d_backward_np(g["p"], g["g"])
+    assert np.abs(dp - g["dp_f64"]).max() < 1e-9 * max(1.0, np.abs(g["dp_f64"]).max())
+    assert so.ortho6d_np(g["p_shaped"]).shape == (2, 5, 3, 3)
+    assert np.abs(so.ortho6d_np(g["p_shaped"]) - g["r_shaped"]).max() < 2e-5
+    assert orth_err(g["r"]).max() < 1e-5

@@ -67,7 +67,25 @@ def save(name, **arrays):
     print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
 
 
+def g7_ortho6d():
+    """Next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36), forward + autograd backward."""
+    torch.manual_seed(6)
+    p = torch.randn(300, 6, requires_grad=True)
+    g = torch.randn(300, 3, 3)
+    r = rr.compute_rotation_matrix_from_ortho6d(p)
+    r.backward(g)
+    pd = p.detach().double().requires_grad_(True)
+    rd = rr.compute_rotation_matrix_from_ortho6d(pd)
+    rd.backward(g.double())
+    shaped = torch.randn(2, 5, 6)
+    save("g7_ortho6d.npz", p=p.detach(), r=r.detach(), g=g, dp=p.grad, r_f64=rd.detach(), dp_f64=pd.grad,
+         p_shaped=shaped, r_shaped=rr.compute_rotation_matrix_from_ortho6d(shaped))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":        # regenerate one fixture without touching the others
+        return g7_ortho6d()
+    g7_ortho6d()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
