@@ -151,19 +151,28 @@ def main():
     # of Python's per-launch jitter.  --eager launches each step from the interpreter instead.
     graph = None
     if not args.eager:
-        torch.cuda.synchronize()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                st = ctypes.c_void_p(side.cuda_stream)
-                for i in range(args.steps):
-                    step(i)
-        stream = side
-        torch.cuda.synchronize()
-        graph.replay()                         # one untimed replay: graph upload / first-touch effects
-        torch.cuda.synchronize()
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                # thread_local: the RCCL watchdog thread of a multi-rank job may query events while we capture
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+                    st = ctypes.c_void_p(side.cuda_stream)
+                    for i in range(args.steps):
+                        step(i)
+            stream = side
+            torch.cuda.synchronize()
+            graph.replay()                     # one untimed replay: graph upload / first-touch effects
+            torch.cuda.synchronize()
+        except Exception as exc:               # submission mode only: the same kernels are then launched eagerly
+            print(f"[bench] hipGraph capture failed ({exc!r}); falling back to eager launches", file=sys.stderr)
+            graph = None
+            args.eager = True
+            stream = torch.cuda.current_stream()
+            st = ctypes.c_void_p(stream.cuda_stream)
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if dist is not None:
         dist.barrier()
