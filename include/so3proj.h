@@ -27,6 +27,7 @@
 #ifndef SO3PROJ_H_
 #define SO3PROJ_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +117,20 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
  */
 int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream);
 int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+
+/* ---- next row: per-class evaluation statistics on K4's angles ----------------------
+ * Replaces the host-side numpy block of 3D-Pose/test_per_class.py:174-216 (np.mean / np.median / np.std / np.max
+ * and the accuracy thresholds (x < 30|15|7.5).sum()/len(x)), which the reference feeds one sample at a time.
+ *   deg       in  B float64 angles (degrees), e.g. so3_angle_error's per-row output
+ *   cls       in  optional B int32 class ids in [0, ncls) (NULL: one class); rows with other ids are ignored
+ *   stats     out ncls x 8 doubles: count, mean, std (population, as np.std), max, median (EXACT: radix select
+ *                 on the float64 bits, the two middle elements averaged as np.median does), acc<30, acc<15, acc<7.5
+ *   workspace     caller-owned scratch of so3_angle_stats_workspace_bytes() bytes (contents undefined before/after)
+ * ncls <= 64.  A class containing a NaN angle reports NaN for mean/std/max/median, as numpy does.
+ */
+size_t so3_angle_stats_workspace_bytes(void);
+int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double *stats, void *workspace,
+                    int64_t B, void *stream);
 
 /* ---- K5: fused Kabsch (config #3) ------------------------------------------------------------------
  * H_b = sum_i q_bi p_bi^T (= bmm(Q^T, P)),  R_b = proj_SO(3)(H_b) = argmin_R sum_i |R p_bi - q_bi|^2.

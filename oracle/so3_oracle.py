@@ -23,6 +23,7 @@ Reference lines followed (all under /root/reference):
   loss_frobenius                       3D-Pose/loss.py:7-11
   rotation sampler (Kabsch pairs)      point_cloud/prepare.py:21-49, point_cloud/main.py:173-181
   6D Gram-Schmidt head (next row f2)   rotation_representation.py:21-36
+  per-class statistics (next row f3)   3D-Pose/test_per_class.py:174-175,206-216
 """
 from __future__ import annotations
 
@@ -158,6 +159,24 @@ def kabsch_np(p, q):
     """argmin_R sum_i |R p_i - q_i|^2 over SO(3) = proj(H) (no centring, as the pairing rule
     point_cloud/main.py:173-181 has no translation)."""
     return symmetric_orthogonalization_np(cross_covariance_np(p, q))
+
+
+def angle_statistics_np(angles, class_ids=None, num_classes=1):
+    """Per-class evaluation statistics exactly as 3D-Pose/test_per_class.py:174-175,206-216 computes them with
+    numpy on the host: np.mean, np.median, np.std (population), np.max, and (x < t).sum()/len(x) for t = 30, 15, 7.5."""
+    a = np.asarray(angles, np.float64).reshape(-1)
+    c = np.zeros(a.shape[0], np.int64) if class_ids is None else np.asarray(class_ids).reshape(-1)
+    out = {k: np.full(num_classes, np.nan) for k in ("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")}
+    for k in range(num_classes):
+        x = a[c == k]
+        out["count"][k] = len(x)
+        if len(x) == 0:
+            continue
+        out["mean"][k], out["median"][k], out["std"][k], out["max"][k] = np.mean(x), np.median(x), np.std(x), np.max(x)   # :174-175
+        out["acc30"][k] = (x < 30).sum() / len(x)       # :214
+        out["acc15"][k] = (x < 15).sum() / len(x)       # :215
+        out["acc7.5"][k] = (x < 7.5).sum() / len(x)     # :216
+    return out
 
 
 def ortho6d_np(poses):

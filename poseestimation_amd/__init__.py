@@ -2,6 +2,7 @@
 henrikgruner/PoseEstimation's rotation_representation.py).  See DESIGN.md / INTEGRATION.md."""
 from .rotation_representation import (  # noqa: F401
     angle_error,
+    angle_error_statistics,
     compute_geodesic_distance_from_two_matrices,
     compute_rotation_matrix_from_ortho6d,
     frobenius_head,
@@ -14,6 +15,7 @@ from .rotation_representation import (  # noqa: F401
 __all__ = [
     "symmetric_orthogonalization",
     "angle_error",
+    "angle_error_statistics",
     "compute_geodesic_distance_from_two_matrices",
     "compute_rotation_matrix_from_ortho6d",
     "loss_frobenius",

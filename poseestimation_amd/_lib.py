@@ -29,6 +29,8 @@ SYMBOLS = {
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_ortho6d_fwd_f32": (_INT, [_P, _P, _I64, _P]),
     "so3_ortho6d_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_angle_stats_workspace_bytes": (ctypes.c_size_t, []),
+    "so3_angle_stats": (_INT, [_P, _P, _I32, _P, _P, _I64, _P]),
     "so3_kabsch_f32": (_INT, [_P, _P, _P, _P, _I64, _I32, _P]),
 }
 

@@ -443,6 +443,105 @@ __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict
     }
 }
 
+// ---- next row f3: per-class evaluation statistics of K4's angles (3D-Pose/test_per_class.py:174-216) ----------
+// One reduction pass (count, sum, sum of squares, max, three accuracy thresholds) and an EXACT median by radix
+// select on the float64 bit patterns (non-negative doubles order like their bits): 8 passes of 8 bits, each a
+// histogram kernel over the rows still matching the selected prefix plus a one-workgroup scan that picks the
+// digit.  Two selections run side by side (the lower and upper middle element; numpy averages them).
+constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
+constexpr int kMaxClasses = 64;
+struct StatWork {                                  // layout of the caller's workspace
+    double acc[kMaxClasses][8];                    // count, sum, sumsq, max, n30, n15, n7.5, nan_count
+    unsigned long long prefix[2][kMaxClasses];     // selected high bits so far (lower / upper middle)
+    long long krem[2][kMaxClasses];                // rank still to find inside the prefix
+    unsigned int hist[2][kMaxClasses][256];
+};
+
+__global__ void k_stats_init(StatWork *w, int ncls) {
+    for (int i = threadIdx.x; i < ncls * 8; i += blockDim.x) w->acc[i / 8][i % 8] = 0.0;     // angles are >= 0: 0 is the identity of max too
+    for (int i = threadIdx.x; i < 2 * kMaxClasses; i += blockDim.x) { w->prefix[i / kMaxClasses][i % kMaxClasses] = 0; w->krem[i / kMaxClasses][i % kMaxClasses] = 0; }
+    for (int i = threadIdx.x; i < 2 * kMaxClasses * 256; i += blockDim.x) (&w->hist[0][0][0])[i] = 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_reduce(const double *__restrict__ deg, const int32_t *__restrict__ cls,
+                                                         int ncls, StatWork *w, int64_t B) {
+    __shared__ double sacc[kMaxClasses][8];
+    for (int i = threadIdx.x; i < ncls * 8; i += kBlock) sacc[i / 8][i % 8] = 0.0;
+    __syncthreads();
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < B; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double a = deg[i];
+        const int c = cls ? cls[i] : 0;
+        if (c < 0 || c >= ncls) continue;
+        atomicAdd(&sacc[c][0], 1.0);
+        if (a != a) { atomicAdd(&sacc[c][7], 1.0); continue; }
+        atomicAdd(&sacc[c][1], a);
+        atomicAdd(&sacc[c][2], a * a);
+        atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][3]), static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)));
+        if (a < 30.0) atomicAdd(&sacc[c][4], 1.0);
+        if (a < 15.0) atomicAdd(&sacc[c][5], 1.0);
+        if (a < 7.5) atomicAdd(&sacc[c][6], 1.0);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncls * 8; i += kBlock) {
+        const int c = i / 8, f = i % 8;
+        if (f == 3) atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][3]), static_cast<unsigned long long>(__double_as_longlong(sacc[c][3])));
+        else if (sacc[c][f] != 0.0) atomicAdd(&w->acc[c][f], sacc[c][f]);
+    }
+}
+
+__global__ void k_stats_ranks(StatWork *w, int ncls) {      // middle ranks among the non-NaN rows of each class
+    const int c = threadIdx.x;
+    if (c >= ncls) return;
+    const long long n = static_cast<long long>(w->acc[c][0] - w->acc[c][7]);
+    w->krem[0][c] = n > 0 ? (n - 1) / 2 : 0;
+    w->krem[1][c] = n > 0 ? n / 2 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_stats_hist(const double *__restrict__ deg, const int32_t *__restrict__ cls,
+                                                       int ncls, StatWork *w, int64_t B, int shift) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < B; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+        const double a = deg[i];
+        const int c = cls ? cls[i] : 0;
+        if (c < 0 || c >= ncls || a != a) continue;
+        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a));
+        const unsigned long long hi = shift >= 56 ? 0ull : key >> (shift + 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (hi == w->prefix[t][c]) atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
+    }
+}
+
+__global__ void k_stats_scan(StatWork *w, int ncls) {      // pick the digit holding rank krem; extend the prefix
+    const int c = threadIdx.x % kMaxClasses, t = threadIdx.x / kMaxClasses;
+    if (c >= ncls || t >= 2) return;
+    long long k = w->krem[t][c];
+    unsigned int d = 0;
+    for (; d < 255; ++d) {
+        const unsigned int h = w->hist[t][c][d];
+        if (k < static_cast<long long>(h)) break;
+        k -= h;
+    }
+    w->krem[t][c] = k;
+    w->prefix[t][c] = (w->prefix[t][c] << 8) | d;
+    for (int i = 0; i < 256; ++i) w->hist[t][c][i] = 0;
+}
+
+__global__ void k_stats_final(const StatWork *w, int ncls, double *__restrict__ stats) {
+    const int c = threadIdx.x;
+    if (c >= ncls) return;
+    const double n = w->acc[c][0], nan = w->acc[c][7], m = n - nan;
+    double *o = stats + c * kStatFields;
+    const double mean = w->acc[c][1] / m;
+    o[0] = n;
+    o[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000ll) : mean;
+    const double var = w->acc[c][2] / m - mean * mean;
+    o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
+    o[3] = nan > 0 ? o[1] : w->acc[c][3];
+    const double lo = __longlong_as_double(static_cast<long long>(w->prefix[0][c])), hi = __longlong_as_double(static_cast<long long>(w->prefix[1][c]));
+    o[4] = (nan > 0 || m <= 0) ? __longlong_as_double(0x7ff8000000000000ll) : 0.5 * (lo + hi);
+    o[5] = w->acc[c][4] / n; o[6] = w->acc[c][5] / n; o[7] = w->acc[c][6] / n;   // (x < t).sum() / len(x)
+}
+
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
 inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); return t < 2048u ? t : 2048u; }
 
@@ -693,6 +792,25 @@ int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, vo
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) hipLaunchKernelGGL((k_ortho6d_rows<true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, X + done * 6, G + done * 9, dX + done * 6, rest);
     return check_launch("so3_ortho6d_bwd_f32");
+}
+
+size_t so3_angle_stats_workspace_bytes(void) { return sizeof(StatWork); }
+
+int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double *stats, void *workspace, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && ncls >= 1 && ncls <= kMaxClasses, "so3_angle_stats: B / ncls (1..64)");
+    SO3_CHECK_ARGS(stats != nullptr && workspace != nullptr && (B == 0 || deg != nullptr), "so3_angle_stats: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    StatWork *w = static_cast<StatWork *>(workspace);
+    k_stats_init<<<1, 1024, 0, s>>>(w, ncls);
+    const unsigned grid = persistent_grid(B > 0 ? B : 1);
+    if (B > 0) k_stats_reduce<<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B);
+    k_stats_ranks<<<1, kMaxClasses, 0, s>>>(w, ncls);
+    for (int shift = 56; shift >= 0 && B > 0; shift -= 8) {
+        k_stats_hist<<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
+        k_stats_scan<<<1, 2 * kMaxClasses, 0, s>>>(w, ncls);
+    }
+    k_stats_final<<<1, kMaxClasses, 0, s>>>(w, ncls, stats);
+    return check_launch("so3_angle_stats");
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {

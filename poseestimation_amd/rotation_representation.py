@@ -300,6 +300,34 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
 
 
 # --------------------------------------------------------------------------------------------
+# next row f3: per-class evaluation statistics
+# --------------------------------------------------------------------------------------------
+STAT_FIELDS = ("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")
+
+
+def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None, num_classes: int = 1) -> dict:
+    """Device-side replacement of the numpy block in 3D-Pose/test_per_class.py:174-216.
+
+    angles: (B,) degrees (e.g. `angle_error(...)`); class_ids: optional (B,) integer ids in [0, num_classes).
+    Returns {"count","mean","std","max","median","acc30","acc15","acc7.5"} -> (num_classes,) float64 tensors;
+    median is exact (radix select), std is numpy's population std, acc* are (x < t).sum()/len(x)."""
+    dev = _require_device(angles)
+    a = angles.detach().reshape(-1).contiguous().double()
+    c = None
+    if class_ids is not None:
+        _require_device(class_ids)
+        c = class_ids.detach().reshape(-1).contiguous().to(torch.int32)
+        if c.numel() != a.numel():
+            raise RuntimeError("angle_error_statistics: angles and class_ids differ in length")
+    lib = _lib.load()
+    stats = torch.empty((num_classes, len(STAT_FIELDS)), dtype=torch.float64, device=dev)
+    work = torch.empty((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), _stream(dev)), "so3_angle_stats")
+    return {name: stats[:, i] for i, name in enumerate(STAT_FIELDS)}
+
+
+# --------------------------------------------------------------------------------------------
 # next row f2: the 6D Gram-Schmidt head
 # --------------------------------------------------------------------------------------------
 class _Ortho6d(torch.autograd.Function):

@@ -411,3 +411,40 @@ def test_g7_ortho6d_head_forward_backward(rr, pa):
     rb = rr.compute_rotation_matrix_from_ortho6d(big)
     rb.backward(torch.randn(1_000_000, 3, 3, device=DEV))
     assert torch.isfinite(big.grad).all() and (torch.linalg.det(rb.detach().double()) - 1).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# next row f3: per-class evaluation statistics (3D-Pose/test_per_class.py:174-216)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,ncls", [(1, 1), (2, 1), (1000, 1), (1001, 3), (250_000, 10), (1_000_000, 10)])
+def test_angle_error_statistics_match_numpy(rr, n, ncls):
+    from oracle import so3_oracle as so
+    rng = np.random.default_rng(n + ncls)
+    ang = np.abs(rng.standard_normal(n)) * 25.0
+    ang[rng.integers(0, n, max(1, n // 50))] = 0.0                      # ties and exact zeros
+    ang = np.minimum(ang, 180.0)
+    cls = rng.integers(0, ncls, n) if ncls > 1 else None
+    got = rr.angle_error_statistics(dev(ang, torch.float64), None if cls is None else dev(cls, torch.int32), ncls)
+    ref = so.angle_statistics_np(ang, cls, ncls)
+    for k in ("count", "max", "median", "acc30", "acc15", "acc7.5"):    # exact quantities
+        assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
+    assert np.abs(got["mean"].cpu().numpy() - ref["mean"]).max() < 1e-10
+    assert np.abs(got["std"].cpu().numpy() - ref["std"]).max() < 1e-8
+
+
+def test_angle_error_statistics_end_to_end_and_nan(rr):
+    """K1 -> K4 -> statistics without leaving the device, against the oracle chain; NaN propagates like numpy."""
+    from oracle import so3_oracle as so
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    r1 = rr.symmetric_orthogonalization(torch.randn(50_000, 9, device=DEV, generator=gen))
+    r2 = rr.symmetric_orthogonalization(torch.randn(50_000, 9, device=DEV, generator=gen))
+    cls = torch.randint(0, 10, (50_000,), device=DEV, generator=gen)
+    deg = rr.angle_error(r1, r2)
+    got = rr.angle_error_statistics(deg, cls, 10)
+    ref = so.angle_statistics_np(deg.cpu().numpy(), cls.cpu().numpy(), 10)
+    assert np.array_equal(got["median"].cpu().numpy(), ref["median"])
+    assert np.abs(got["mean"].cpu().numpy() - ref["mean"]).max() < 1e-10
+    bad = deg.clone()
+    bad[123] = float("nan")
+    s = rr.angle_error_statistics(bad, None, 1)
+    assert torch.isnan(s["median"]).all() and torch.isnan(s["mean"]).all() and s["count"].item() == 50_000
