@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rows", type=int, default=ROWS_DEFAULT, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the brief timing of configs #3 and #4")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying one hipGraph of K launches")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU baseline sample")
     return ap.parse_args()
@@ -94,6 +95,48 @@ def cpu_baseline(rows: int):
     return {"value": rows / best, "unit": "projections/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{rows} rows of the same Gaussian workload, torch.linalg.svd-based restatement of "
                       f"rotation_representation.py:199-205 (oracle/so3_oracle.py), best of {reps}, {cpu_name}"}
+
+
+def secondary_configs(lib, dev):
+    """The other BASELINE.json configs, timed briefly on rank 0 at N = 1 (reported beside the headline)."""
+    P = ctypes.c_void_p
+    st = P(torch.cuda.current_stream().cuda_stream)
+    out = {}
+
+    def timed(fn, iters, warm=3):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e3          # us per call
+
+    # config #3: 65 536 clouds x 1024 points, fused cross-covariance + projection (K5); two buffer sets (3.2 GB)
+    b, n = 65536, 1024
+    pc = [torch.rand(b, n, 3, device=dev) - 0.5 for _ in range(2)]
+    qc = [torch.rand(b, n, 3, device=dev) - 0.5 for _ in range(2)]
+    rk = torch.empty(b, 9, device=dev)
+    us = timed(lambda i: lib.so3_kabsch_f32(P(pc[i % 2].data_ptr()), P(qc[i % 2].data_ptr()), P(rk.data_ptr()), None, b, n, st), 8, 2)
+    bytes_ = b * (2 * n * 12 + 36)
+    out["config3_kabsch_65536x1024"] = {"us_per_call": us, "clouds_per_s": b / us * 1e6, "achieved_GBps": bytes_ / us * 1e-3,
+                                        "frac_of_8TBps": bytes_ / us * 1e-3 / HBM_PEAK_GBS, "bytes_per_cloud_algorithmic": 2 * n * 12 + 36}
+    del pc, qc
+    # config #4: B = 512, bf16 storage, head + Frobenius loss + backward in ONE C-ABI call (K3)
+    b = 512
+    x4 = torch.randn(b, 9, device=dev).bfloat16()
+    t4 = torch.empty(b, 9, device=dev)
+    lib.so3_project_fwd_f32(P(torch.randn(b, 9, device=dev).data_ptr()), P(t4.data_ptr()), None, b, st)
+    r4 = torch.empty(b, 9, device=dev)
+    d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
+    ls = torch.empty(1, dtype=torch.float64, device=dev)
+    us = timed(lambda i: lib.so3_frob_fwd_bwd_bf16(P(x4.data_ptr()), P(t4.data_ptr()), P(r4.data_ptr()), P(d4.data_ptr()), P(ls.data_ptr()), b, st), 300, 10)
+    out["config4_head_loss_backward_b512_bf16"] = {"us_per_fused_call": us, "note": "launch-latency-bound (9 KB); one memset + one kernel"}
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -244,6 +287,10 @@ def main():
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},
         }
+        if world == 1 and not args.no_secondary:
+            del xs, outs
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_configs(lib, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
         print(json.dumps(out), flush=True)
