@@ -352,49 +352,46 @@ __device__ __forceinline__ float wave_allsum(float v) {
     return v;
 }
 
-struct P3 {
-    float x, y, z;
-};
-
-constexpr int kKabschUnroll = 4;
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+constexpr int kKabschUnroll = 8;           // 8 x 2 x 768 B = 12 KB of loads in flight per wave
 
 __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, const float *__restrict__ Q,
                                                    float *__restrict__ R, float *__restrict__ H, int64_t B, int32_t N,
                                                    int clouds_per_wave) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) >> 6;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);         // SGPR: cloud indices stay scalar
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
     const int64_t c0 = wave * clouds_per_wave;
     if (c0 >= B) return;
     const int nc = static_cast<int>(min<int64_t>(clouds_per_wave, B - c0));
     float h[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) h[i] = (i & 3) == 0 ? 1.f : 0.f;
+    const unsigned cloud_bytes = static_cast<unsigned>(N) * 12u;
     for (int j = 0; j < nc; ++j) {
-        const P3 *__restrict__ p = reinterpret_cast<const P3 *>(P) + (c0 + j) * N;
-        const P3 *__restrict__ q = reinterpret_cast<const P3 *>(Q) + (c0 + j) * N;
+        // One buffer descriptor per cloud (num_records = N*12 B): lanes past the last point read zeros, which add
+        // nothing to the sums, so the point loop needs no tail and no exec-masked branch.  Streamed once: nt.
+        const so3::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        const so3::rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Q) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
         float acc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) acc[i] = 0.f;
-        int i0 = lane;
-        for (; i0 + 64 * (kKabschUnroll - 1) < N; i0 += 64 * kKabschUnroll) {
-            P3 pp[kKabschUnroll], qq[kKabschUnroll];
+        for (int i0 = 0; i0 < N; i0 += 64 * kKabschUnroll) {
+            u32x3 pp[kKabschUnroll], qq[kKabschUnroll];
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
-                pp[u] = p[i0 + 64 * u];
-                qq[u] = q[i0 + 64 * u];
+                const int off = (i0 + 64 * u + lane) * 12;
+                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, off, 0, so3::kStreamCpol);
+                qq[u] = __builtin_amdgcn_raw_buffer_load_b96(rq, off, 0, so3::kStreamCpol);
             }
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
-                acc[0] = fmaf(qq[u].x, pp[u].x, acc[0]); acc[1] = fmaf(qq[u].x, pp[u].y, acc[1]); acc[2] = fmaf(qq[u].x, pp[u].z, acc[2]);
-                acc[3] = fmaf(qq[u].y, pp[u].x, acc[3]); acc[4] = fmaf(qq[u].y, pp[u].y, acc[4]); acc[5] = fmaf(qq[u].y, pp[u].z, acc[5]);
-                acc[6] = fmaf(qq[u].z, pp[u].x, acc[6]); acc[7] = fmaf(qq[u].z, pp[u].y, acc[7]); acc[8] = fmaf(qq[u].z, pp[u].z, acc[8]);
+                const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
+                const float qx = __uint_as_float(qq[u].x), qy = __uint_as_float(qq[u].y), qz = __uint_as_float(qq[u].z);
+                acc[0] = fmaf(qx, px, acc[0]); acc[1] = fmaf(qx, py, acc[1]); acc[2] = fmaf(qx, pz, acc[2]);
+                acc[3] = fmaf(qy, px, acc[3]); acc[4] = fmaf(qy, py, acc[4]); acc[5] = fmaf(qy, pz, acc[5]);
+                acc[6] = fmaf(qz, px, acc[6]); acc[7] = fmaf(qz, py, acc[7]); acc[8] = fmaf(qz, pz, acc[8]);
             }
-        }
-        for (; i0 < N; i0 += 64) {
-            const P3 pp = p[i0], qq = q[i0];
-            acc[0] = fmaf(qq.x, pp.x, acc[0]); acc[1] = fmaf(qq.x, pp.y, acc[1]); acc[2] = fmaf(qq.x, pp.z, acc[2]);
-            acc[3] = fmaf(qq.y, pp.x, acc[3]); acc[4] = fmaf(qq.y, pp.y, acc[4]); acc[5] = fmaf(qq.y, pp.z, acc[5]);
-            acc[6] = fmaf(qq.z, pp.x, acc[6]); acc[7] = fmaf(qq.z, pp.y, acc[7]); acc[8] = fmaf(qq.z, pp.z, acc[8]);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -814,7 +811,7 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 40) && N >= 0, "so3_kabsch_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 40) && N >= 0 && N <= 300000000, "so3_kabsch_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R != nullptr && (N == 0 || (P != nullptr && Q != nullptr)), "so3_kabsch_f32: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
