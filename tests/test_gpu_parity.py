@@ -448,3 +448,74 @@ def test_angle_error_statistics_end_to_end_and_nan(rr):
     bad[123] = float("nan")
     s = rr.angle_error_statistics(bad, None, 1)
     assert torch.isnan(s["median"]).all() and torch.isnan(s["mean"]).all() and s["count"].item() == 50_000
+
+
+# ------------------------------------------------------------------------------------------------
+# robustness: host threads, large batches, every dtype path of the engine at a non-trivial size
+# ------------------------------------------------------------------------------------------------
+def test_reentrant_from_two_host_threads(rr, c_oracle):
+    """No global mutable state: two host threads on their own streams get their own correct answers."""
+    import threading
+    xs = [torch.randn(200_000, 9, device=DEV, generator=torch.Generator(device=DEV).manual_seed(s)) for s in (1, 2)]
+    outs = [None, None]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(5):
+                outs[i] = rr.symmetric_orthogonalization(xs[i])
+        st.synchronize()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        ref = c_oracle.project(xs[i].cpu().numpy())
+        assert np.quantile(np.abs(outs[i].cpu().numpy() - ref), 0.999) < 3e-6
+
+
+def test_config5_shard_size_sixteen_million_rows(rr):
+    """Config #5's global batch (16M rows) on one GPU: properties that do not need the oracle at this size."""
+    n = 16_000_000
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    r, flip = rr.symmetric_orthogonalization_with_flip(x)
+    det_neg = torch.linalg.det(x.view(-1, 3, 3).double()) < 0
+    assert int((flip != det_neg).sum()) == 0                                   # flip == (det M < 0), all 16M rows
+    rtr = torch.bmm(r.transpose(1, 2), r)
+    assert (rtr - torch.eye(3, device=DEV)).flatten(1).norm(dim=1).max().item() < 1e-5
+    del rtr
+    assert (rr.symmetric_orthogonalization(r) - r).abs().max().item() < 3e-6    # idempotence
+    sc = rr.angle_error_sum_count(r, r)
+    assert sc[1].item() == n and sc[0].item() / n < 0.05                        # ~0 degrees up to acos noise
+
+
+def test_engine_dtype_paths_at_size(rr, c_oracle):
+    """bf16 in / bf16 gradients and the flip variant through the streaming engine (not the remainder kernels)."""
+    n = 100_000 + 37                                                           # 1562 units + a 69-row remainder
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    xb = x.bfloat16()
+    ref = c_oracle.project(xb.float().cpu().numpy())
+    r = rr.symmetric_orthogonalization(xb)
+    assert np.quantile(np.abs(r.cpu().numpy() - ref), 0.999) < 3e-6
+    g = torch.randn(n, 3, 3, device=DEV, generator=gen)
+    xg = xb.clone().requires_grad_(True)
+    rr.symmetric_orthogonalization(xg).backward(g)
+    gref = c_oracle.project_bwd(xb.float().cpu().numpy(), g.cpu().numpy()).reshape(n, 9)
+    rel = np.abs(xg.grad.float().cpu().numpy() - gref).max(1) / (1e-3 + np.abs(gref).max(1))
+    assert xg.grad.dtype == torch.bfloat16 and np.median(rel) < 4e-3           # bf16 rounding of the gradient
+    xf = xb.float().requires_grad_(True)
+    rr.symmetric_orthogonalization(xf).backward(g)
+    rel = np.abs(xf.grad.cpu().numpy() - gref).max(1) / (1e-3 + np.abs(gref).max(1))
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.99) < 2e-4
+    rt = rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen))
+    xl = xb.float().requires_grad_(True)
+    loss, rf = rr.frobenius_head(xl, rt)
+    loss.backward()
+    xu = xb.float().requires_grad_(True)
+    lu = rr.loss_frobenius(rt, rr.symmetric_orthogonalization(xu))
+    lu.backward()
+    assert abs(loss.item() - lu.item()) < 2e-6 and (xl.grad - xu.grad).abs().max().item() < 1e-7
+    assert (rf - r).abs().max().item() < 1e-6
