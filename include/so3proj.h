@@ -108,6 +108,21 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
  * point_cloud/main.py:43-57). */
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream);
 
+/* ---- next row: the SE(3) pose update fused after the head ------------------------
+ * Replaces calculate_T_pred, Iterative/utility.py:90-128 (the head at :105, einsum at :124, the translation
+ * update at :116-121 and the 4x4 assembly the reference's `combine`, :63-71, intends):
+ *   dR = proj(out[:, :9]);  R_new = dR R_k;  z_new = vz z_k;  x_new = (vx/fx + x_k/z_k) z_new;  y likewise;
+ *   T_pred = [[R_new, (x_new, y_new, z_new)^T], [0, 0, 0, 1]].
+ *   out12 in B*12 float32 (network output);  Tinit in B*16 float32 (row-major 4x4);  Tpred out B*16 float32;
+ *   fx, fy: focal lengths in pixels (get_scene_parameters, utility.py:73-88: 50 / (36/320) = 444.44).
+ * The backward gives dL/dout12 for upstream G = dL/dTpred (B*16); T_init is treated as a constant, as the
+ * reference's loop detaches it (Iterative/main.py:97).
+ */
+int so3_se3_update_f32(const float *out12, const float *Tinit, float *Tpred, float fx, float fy, int64_t B,
+                       void *stream);
+int so3_se3_update_bwd_f32(const float *out12, const float *Tinit, const float *G, float *dout12, float fx,
+                           float fy, int64_t B, void *stream);
+
 /* ---- next row: the 6D Gram-Schmidt head and its backward -------------------------
  * x = a/|a|, z = (x x b)/|x x b|, y = z x x, R = [x y z] as columns; (a, b) = the two halves of each 6-vector.
  * Replaces rotation_representation.py:21-36 (compute_rotation_matrix_from_ortho6d; duplicate at :174-189),

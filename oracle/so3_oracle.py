@@ -24,6 +24,7 @@ Reference lines followed (all under /root/reference):
   rotation sampler (Kabsch pairs)      point_cloud/prepare.py:21-49, point_cloud/main.py:173-181
   6D Gram-Schmidt head (next row f2)   rotation_representation.py:21-36
   per-class statistics (next row f3)   3D-Pose/test_per_class.py:174-175,206-216
+  SE(3) pose update (next row f1)      Iterative/utility.py:63-128
 """
 from __future__ import annotations
 
@@ -159,6 +160,41 @@ def kabsch_np(p, q):
     """argmin_R sum_i |R p_i - q_i|^2 over SO(3) = proj(H) (no centring, as the pairing rule
     point_cloud/main.py:173-181 has no translation)."""
     return symmetric_orthogonalization_np(cross_covariance_np(p, q))
+
+
+def se3_update_np(model_output, t_init, fx=50 / (36 / 320), fy=50 / (36 / 320)):
+    """calculate_T_pred (Iterative/utility.py:90-128) in float64; focal lengths from get_scene_parameters (:73-88)."""
+    o = np.asarray(model_output, np.float64)
+    t = np.asarray(t_init, np.float64).reshape(-1, 4, 4)
+    dr = symmetric_orthogonalization_np(o[:, :9])                    # :105
+    vx, vy, vz = o[:, 9], o[:, 10], o[:, 11]                         # :106-108
+    r_k = t[:, :3, :3]                                               # :110
+    z_k, x_k, y_k = t[:, 2, 3], t[:, 0, 3], t[:, 1, 3]               # :114,118,119
+    z_new = vz * z_k                                                 # :116
+    x_new = (vx / fx + x_k / z_k) * z_new                            # :120
+    y_new = (vy / fy + y_k / z_k) * z_new                            # :121
+    tp = np.ones((o.shape[0], 4, 4))                                 # combine, :63-71 (as intended)
+    tp[:, :3, :3] = np.einsum("bij,bjk->bik", dr, r_k)               # :124
+    tp[:, 0, 3], tp[:, 1, 3], tp[:, 2, 3] = x_new, y_new, z_new
+    tp[:, 3, :3] = 0
+    return tp
+
+
+def se3_update_backward_np(model_output, t_init, g, fx=50 / (36 / 320), fy=50 / (36 / 320)):
+    """dL/dmodel_output[:, :12] for upstream G = dL/dT_pred (T_init constant); checked against the reference's autograd."""
+    o = np.asarray(model_output, np.float64)
+    t = np.asarray(t_init, np.float64).reshape(-1, 4, 4)
+    g = np.asarray(g, np.float64).reshape(-1, 4, 4)
+    gdr = np.einsum("bik,bjk->bij", g[:, :3, :3], t[:, :3, :3])      # G_R R_k^T
+    d = np.zeros((o.shape[0], 12))
+    d[:, :9] = projection_backward_np(o[:, :9], gdr).reshape(-1, 9)
+    z_k, x_k, y_k = t[:, 2, 3], t[:, 0, 3], t[:, 1, 3]
+    z_new = o[:, 11] * z_k
+    ax, ay = o[:, 9] / fx + x_k / z_k, o[:, 10] / fy + y_k / z_k
+    d[:, 9] = g[:, 0, 3] * z_new / fx
+    d[:, 10] = g[:, 1, 3] * z_new / fy
+    d[:, 11] = z_k * (g[:, 2, 3] + g[:, 0, 3] * ax + g[:, 1, 3] * ay)
+    return d
 
 
 def angle_statistics_np(angles, class_ids=None, num_classes=1):

@@ -3,6 +3,7 @@ henrikgruner/PoseEstimation's rotation_representation.py).  See DESIGN.md / INTE
 from .rotation_representation import (  # noqa: F401
     angle_error,
     angle_error_statistics,
+    calculate_T_pred,
     compute_geodesic_distance_from_two_matrices,
     compute_rotation_matrix_from_ortho6d,
     frobenius_head,
@@ -16,6 +17,7 @@ __all__ = [
     "symmetric_orthogonalization",
     "angle_error",
     "angle_error_statistics",
+    "calculate_T_pred",
     "compute_geodesic_distance_from_two_matrices",
     "compute_rotation_matrix_from_ortho6d",
     "loss_frobenius",

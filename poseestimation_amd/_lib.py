@@ -27,6 +27,8 @@ SYMBOLS = {
     "so3_frob_loss_f32": (_INT, [_P, _P, _P, _P, _I64, _P]),
     "so3_angle_error": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_se3_update_f32": (_INT, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),
+    "so3_se3_update_bwd_f32": (_INT, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),
     "so3_ortho6d_fwd_f32": (_INT, [_P, _P, _I64, _P]),
     "so3_ortho6d_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_angle_stats_workspace_bytes": (ctypes.c_size_t, []),

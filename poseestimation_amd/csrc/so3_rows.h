@@ -121,6 +121,12 @@ template <int NPL> struct LaneT;
 template <> struct LaneT<1> { typedef float type; };
 template <> struct LaneT<2> { typedef f32x2 type; };
 
+// The rows of the current round as an operation sees them: up to three inputs, up to two outputs.
+template <class T, class Op> struct Rows {
+    T a[Op::kIn0N], b[Op::kIn1N], c[Op::kIn2N];
+    T o0[Op::kOut0N], o1[Op::kOut1N];
+};
+
 // What an operation sees of the current round.
 template <int NPL> struct RowCtx {
     int64_t unit[NPL];      // unit index of component k (wave-uniform)
@@ -131,9 +137,9 @@ template <int NPL> struct RowCtx {
 };
 
 // ---- the engine ----------------------------------------------------------------------------------------
-// Op provides: kIn0, kIn1, kOut0, kOut1 (element bytes, 0 = absent), pointers in0, in1, out0, out1,
+// Op provides: kIn0, kIn1, kIn2, kOut0, kOut1 (element bytes, 0 = absent), pointers in0, in1, in2, out0, out1,
 //   kIn0N .. kOut1N (elements per row, 9 unless overridden),
-//   template <class T, int NPL> void compute(const T (&a)[kIn0N], const T (&b)[kIn1N], T (&o0)[kOut0N], T (&o1)[kOut1N], RowCtx<NPL> &)
+//   template <class T, int NPL> void compute(Rows<T, Op> &rows, RowCtx<NPL> &)      reads rows.a/b/c, writes rows.o0/o1
 //   void finish(double block_total, bool any_flag)      -- called by thread 0 of each workgroup at the end
 //   kReduce: whether acc/flag are used.
 // WPS = resident waves per SIMD the register budget is sized for (the host launches 256 * WPS * 256 / BLOCK
@@ -145,11 +151,12 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
     typedef UnitIO<Op::kIn0, Op::kIn0N> I0;
     typedef UnitIO<Op::kIn1, Op::kIn1N> I1;
+    typedef UnitIO<Op::kIn2, Op::kIn2N> I2;
     typedef UnitIO<Op::kOut0, Op::kOut0N> O0;
     typedef UnitIO<Op::kOut1, Op::kOut1N> O1;
     constexpr int kWaves = BLOCK / 64;
     // LDS slot of one unit: the input slots side by side; outputs are staged over them once the rows are in registers
-    constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes;
+    constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes + I2::kSlotBytes;
     constexpr int kOutBytes = O0::kSlotBytes + O1::kSlotBytes;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     __shared__ __attribute__((aligned(16))) char lds[kWaves][NPL][kSlot];
@@ -170,27 +177,30 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.acc = 0.0;
     ctx.flag = false;
     if (t < nrounds) {
-        f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads];
+        f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads], in2[NPL][I2::kLoads];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const int64_t u = t * NPL + k;                  // a phantom unit re-reads the round's first one
             const int64_t ue = u < nunits ? u : t * NPL;
             I0::fetch(in0[k], I0::rsrc(op.in0, ue, true), lane);
             if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, true), lane);
+            if constexpr (Op::kIn2 != 0) I2::fetch(in2[k], I2::rsrc(op.in2, ue, true), lane);
         }
         if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             I0::to_lds(slot[k], in0[k], lane);
             if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
+            if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, in2[k], lane);
         }
         while (true) {
             wave_lds_fence();
-            T a[Op::kIn0N], b[Op::kIn1N], o0[Op::kOut0N], o1[Op::kOut1N];
+            Rows<T, Op> rows;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                I0::read_row(slot[k], lane, k, a);
-                if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, b);
+                I0::read_row(slot[k], lane, k, rows.a);
+                if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, rows.b);
+                if constexpr (Op::kIn2 != 0) I2::read_row(slot[k] + I0::kSlotBytes + I1::kSlotBytes, lane, k, rows.c);
             }
             wave_lds_fence();
             const int64_t tn = t + nwaves;
@@ -202,18 +212,19 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 const int64_t ue = u < nunits ? u : tf * NPL;   // loads return 0 and cost no traffic.
                 I0::fetch(in0[k], I0::rsrc(op.in0, ue, more), lane);
                 if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, more), lane);
+                if constexpr (Op::kIn2 != 0) I2::fetch(in2[k], I2::rsrc(op.in2, ue, more), lane);
             }
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 ctx.unit[k] = t * NPL + k;
                 ctx.exists[k] = ctx.unit[k] < nunits;       // wave-uniform
             }
-            op.template compute<T, NPL>(a, b, o0, o1, ctx);
+            op.template compute<T, NPL>(rows, ctx);
             if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
-                    if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, o0);
-                    if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, o1);
+                    if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, rows.o0);
+                    if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, rows.o1);
                 }
                 wave_lds_fence();
                 f32x4 v0[NPL][O0::kLoads], v1[NPL][O1::kLoads];
@@ -244,6 +255,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             for (int k = 0; k < NPL; ++k) {
                 I0::to_lds(slot[k], in0[k], lane);
                 if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
+                if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, in2[k], lane);
             }
             if (STAMP) { __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
             t = tn;
@@ -283,8 +295,9 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 
 // ---- the operations --------------------------------------------------------------------------------------
 struct OpBase {
-    static constexpr int kIn0N = 9, kIn1N = 9, kOut0N = 9, kOut1N = 9;     // elements per row of each array
-    const void *in0 = nullptr, *in1 = nullptr;
+    static constexpr int kIn2 = 0;                                         // most operations have at most two inputs
+    static constexpr int kIn0N = 9, kIn1N = 9, kIn2N = 9, kOut0N = 9, kOut1N = 9;     // elements per row of each array
+    const void *in0 = nullptr, *in1 = nullptr, *in2 = nullptr;
     void *out0 = nullptr, *out1 = nullptr;
     static constexpr bool kReduce = false;
     __device__ __forceinline__ void finish(double, bool) const {}
@@ -296,7 +309,9 @@ struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     uint8_t *flip = nullptr;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&m)[9], const T (&)[9], T (&r)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+    __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
+        const T (&m)[9] = rows.a;
+        T (&r)[9] = rows.o0;
         if constexpr (SWEEPS < 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) r[i] = m[i];
@@ -322,9 +337,9 @@ template <int M_BYTES>
 struct OpProjectBwd : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&m)[9], const T (&g)[9], T (&dm)[9], T (&)[9], RowCtx<NPL> &) const {
-        const auto f = signed_svd<true, T>(m);
-        project_backward(f, g, dm);
+    __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &) const {
+        const auto f = signed_svd<true, T>(rows.a);
+        project_backward(f, rows.b, rows.o0);
     }
 };
 
@@ -336,8 +351,12 @@ struct OpFrobHead : OpBase {
     double *loss_sum = nullptr;
     float inv_b = 0.f;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&m)[9], const T (&t)[9], T (&dm)[9], T (&r)[9], RowCtx<NPL> &ctx) const {
+    __device__ __forceinline__ void compute(Rows<T, OpFrobHead> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
+        const T (&m)[9] = rows.a;
+        const T (&t)[9] = rows.b;
+        T (&dm)[9] = rows.o0;
+        T (&r)[9] = rows.o1;
         const auto f = signed_svd<WANT_DM, T>(m);
         rotation_from(f, r);
         T g[9];
@@ -370,8 +389,11 @@ struct OpFrobLoss : OpBase {
     double *loss_sum = nullptr;
     float inv_b = 0.f;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&p)[9], const T (&t)[9], T (&g)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+    __device__ __forceinline__ void compute(Rows<T, OpFrobLoss> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
+        const T (&p)[9] = rows.a;
+        const T (&t)[9] = rows.b;
+        T (&g)[9] = rows.o0;
         T n2 = R::splat(0.f);
 #pragma unroll
         for (int i = 0; i < 9; ++i) { g[i] = p[i] - t[i]; n2 = R::fma(g[i], g[i], n2); }
@@ -396,7 +418,9 @@ struct OpAngle : OpBase {
     int32_t *range_flag = nullptr;
     double unit_scale = 1.0;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&a)[9], const T (&b)[9], T (&)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+    __device__ __forceinline__ void compute(Rows<T, OpAngle> &rows, RowCtx<NPL> &ctx) const {
+        const T (&a)[9] = rows.a;
+        const T (&b)[9] = rows.b;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             double tr = 0.0;                                 // tr(R1^T R2) = sum_ij R1_ij R2_ij, float64
@@ -425,8 +449,10 @@ struct OpGeodesic : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 0, kOut1 = 0;
     float *theta = nullptr;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&a)[9], const T (&b)[9], T (&)[9], T (&)[9], RowCtx<NPL> &ctx) const {
+    __device__ __forceinline__ void compute(Rows<T, OpGeodesic> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
+        const T (&a)[9] = rows.a;
+        const T (&b)[9] = rows.b;
         // diagonal of m1 m2^T, summed in the reference's order: m00 + m11 + m22
         const T d0 = R::fma(a[2], b[2], R::fma(a[1], b[1], a[0] * b[0]));
         const T d1 = R::fma(a[5], b[5], R::fma(a[4], b[4], a[3] * b[3]));
@@ -449,8 +475,10 @@ struct OpOrtho6d : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     static constexpr int kIn0N = 6;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&p)[6], const T (&)[9], T (&r)[9], T (&)[9], RowCtx<NPL> &) const {
+    __device__ __forceinline__ void compute(Rows<T, OpOrtho6d> &rows, RowCtx<NPL> &) const {
         typedef Tr<T> R;
+        const T (&p)[6] = rows.a;
+        T (&r)[9] = rows.o0;
         const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
         const V3<T> x = scale<T>(a, R::rsq(dot(a, a)));
         const V3<T> w = cross<T>(x, b);
@@ -467,8 +495,11 @@ struct OpOrtho6dBwd : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 4, kOut1 = 0;
     static constexpr int kIn0N = 6, kOut0N = 6;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(const T (&p)[6], const T (&g)[9], T (&dp)[6], T (&)[9], RowCtx<NPL> &) const {
+    __device__ __forceinline__ void compute(Rows<T, OpOrtho6dBwd> &rows, RowCtx<NPL> &) const {
         typedef Tr<T> R;
+        const T (&p)[6] = rows.a;
+        const T (&g)[9] = rows.b;
+        T (&dp)[6] = rows.o0;
         const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
         const T ia = R::rsq(dot(a, a));
         const V3<T> x = scale<T>(a, ia);
@@ -488,6 +519,73 @@ struct OpOrtho6dBwd : OpBase {
         const V3<T> ga = scale<T>(axpy<T>(-dot(x, gxt), x, gxt), ia);
         dp[0] = ga.x; dp[1] = ga.y; dp[2] = ga.z;
         dp[3] = gb.x; dp[4] = gb.y; dp[5] = gb.z;
+    }
+};
+
+// ---- next row f1: the SE(3) update of Iterative/utility.py:90-128 (calculate_T_pred), fused after the head -----
+// in0 = network output (B,12): nine numbers for the rotation head, then (vx, vy, vz);  in1 = T_init (B,4,4).
+//   dR = proj(out[:, :9]);  R_new = dR R_k;  z_new = vz z_k;  x_new = (vx/fx + x_k/z_k) z_new;  y likewise;
+//   T_pred = [[R_new, t_new], [0 0 0 1]]      (what the reference's `combine`, utility.py:63-71, intends).
+struct OpSe3Update : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 12, kIn1N = 16, kOut0N = 16;
+    float inv_fx = 0.f, inv_fy = 0.f;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpSe3Update> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&o)[12] = rows.a;
+        const T (&ti)[16] = rows.b;
+        T (&tp)[16] = rows.o0;
+        T m[9], dr[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = o[i];
+        const auto f = signed_svd<false, T>(m);               // utility.py:105
+        rotation_from(f, dr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)                       // R_new = dR R_k  (:124)
+                tp[4 * i + j] = R::fma(dr[3 * i + 2], ti[8 + j], R::fma(dr[3 * i + 1], ti[4 + j], dr[3 * i] * ti[j]));
+        const T zk = ti[11], iz = R::rcp(zk);
+        const T zn = o[11] * zk;                              // :116
+        tp[3] = R::fma(o[9], R::splat(inv_fx), ti[3] * iz) * zn;    // :120
+        tp[7] = R::fma(o[10], R::splat(inv_fy), ti[7] * iz) * zn;   // :121
+        tp[11] = zn;
+        tp[12] = R::splat(0.f); tp[13] = R::splat(0.f); tp[14] = R::splat(0.f);
+        tp[15] = R::splat(1.f);
+    }
+};
+
+// Its backward w.r.t. the network output: in0 = output (B,12), in1 = T_init (B,16), in2 = G = dL/dT_pred (B,16).
+struct OpSe3UpdateBwd : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 4, kIn2 = 4, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 12, kIn1N = 16, kIn2N = 16, kOut0N = 12;
+    float inv_fx = 0.f, inv_fy = 0.f;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpSe3UpdateBwd> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&o)[12] = rows.a;
+        const T (&ti)[16] = rows.b;
+        const T (&g)[16] = rows.c;
+        T (&d)[12] = rows.o0;
+        T m[9], gdr[9], dm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = o[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)                       // dL/d(dR) = G_R R_k^T
+                gdr[3 * i + j] = R::fma(g[4 * i + 2], ti[4 * j + 2], R::fma(g[4 * i + 1], ti[4 * j + 1], g[4 * i] * ti[4 * j]));
+        const auto f = signed_svd<true, T>(m);
+        project_backward(f, gdr, dm);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d[i] = dm[i];
+        const T zk = ti[11], iz = R::rcp(zk);
+        const T zn = o[11] * zk;
+        const T ax = R::fma(o[9], R::splat(inv_fx), ti[3] * iz), ay = R::fma(o[10], R::splat(inv_fy), ti[7] * iz);
+        d[9] = g[3] * zn * R::splat(inv_fx);
+        d[10] = g[7] * zn * R::splat(inv_fy);
+        d[11] = zk * R::fma(g[7], ay, R::fma(g[3], ax, g[11]));
     }
 };
 

@@ -421,22 +421,56 @@ __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict
                                                          float *__restrict__ out, int64_t B) {
     const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
     if (row >= B) return;
-    float p[6], g[9], r[9], dp[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) p[i] = X[row * 6 + i];
     so3::RowCtx<1> ctx{};
     if (BWD) {
+        so3::Rows<float, so3::OpOrtho6dBwd> rows;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) g[i] = G[row * 9 + i];
+        for (int i = 0; i < 6; ++i) rows.a[i] = X[row * 6 + i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rows.b[i] = G[row * 9 + i];
         so3::OpOrtho6dBwd op;
-        op.compute<float, 1>(p, g, dp, r, ctx);
+        op.compute<float, 1>(rows, ctx);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) out[row * 6 + i] = dp[i];
+        for (int i = 0; i < 6; ++i) out[row * 6 + i] = rows.o0[i];
     } else {
-        so3::OpOrtho6d op;
-        op.compute<float, 1>(p, g, r, g, ctx);
+        so3::Rows<float, so3::OpOrtho6d> rows;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) out[row * 9 + i] = r[i];
+        for (int i = 0; i < 6; ++i) rows.a[i] = X[row * 6 + i];
+        so3::OpOrtho6d op;
+        op.compute<float, 1>(rows, ctx);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[row * 9 + i] = rows.o0[i];
+    }
+}
+
+// ---- SE(3) update, one row per thread: remainder and unaligned input of the streaming kernels -----------------
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ out12, const float *__restrict__ Tinit,
+                                                     const float *__restrict__ G, float *__restrict__ res, float inv_fx,
+                                                     float inv_fy, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= B) return;
+    so3::RowCtx<1> ctx{};
+    if (BWD) {
+        so3::Rows<float, so3::OpSe3UpdateBwd> rows;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rows.a[i] = out12[row * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { rows.b[i] = Tinit[row * 16 + i]; rows.c[i] = G[row * 16 + i]; }
+        so3::OpSe3UpdateBwd op; op.inv_fx = inv_fx; op.inv_fy = inv_fy;
+        op.compute<float, 1>(rows, ctx);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) res[row * 12 + i] = rows.o0[i];
+    } else {
+        so3::Rows<float, so3::OpSe3Update> rows;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rows.a[i] = out12[row * 12 + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rows.b[i] = Tinit[row * 16 + i];
+        so3::OpSe3Update op; op.inv_fx = inv_fx; op.inv_fy = inv_fy;
+        op.compute<float, 1>(rows, ctx);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) res[row * 16 + i] = rows.o0[i];
     }
 }
 
@@ -808,6 +842,30 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     }
     k_stats_final<<<1, kMaxClasses, 0, s>>>(w, ncls, stats);
     return check_launch("so3_angle_stats");
+}
+
+int so3_se3_update_f32(const float *out12, const float *Tinit, float *Tpred, float fx, float fy, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B && fx != 0.f && fy != 0.f, "so3_se3_update_f32: B / fx / fy");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(out12 != nullptr && Tinit != nullptr && Tpred != nullptr, "so3_se3_update_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nunits = stream_units(B, {out12, Tinit, Tpred});
+    if (nunits > 0) { so3::OpSe3Update op; op.in0 = out12; op.in1 = Tinit; op.out0 = Tpred; op.inv_fx = 1.f / fx; op.inv_fy = 1.f / fy; launch_rows<2, 2, 256>(op, nunits, s); }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) hipLaunchKernelGGL((k_se3_rows<false>), dim3(grid_for(rest)), dim3(kBlock), 0, s, out12 + done * 12, Tinit + done * 16, nullptr, Tpred + done * 16, 1.f / fx, 1.f / fy, rest);
+    return check_launch("so3_se3_update_f32");
+}
+
+int so3_se3_update_bwd_f32(const float *out12, const float *Tinit, const float *G, float *dout12, float fx, float fy, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B && fx != 0.f && fy != 0.f, "so3_se3_update_bwd_f32: B / fx / fy");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(out12 != nullptr && Tinit != nullptr && G != nullptr && dout12 != nullptr, "so3_se3_update_bwd_f32: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t nunits = stream_units(B, {out12, Tinit, G, dout12});
+    if (nunits > 0) { so3::OpSe3UpdateBwd op; op.in0 = out12; op.in1 = Tinit; op.in2 = G; op.out0 = dout12; op.inv_fx = 1.f / fx; op.inv_fy = 1.f / fy; launch_rows<1, 3, 256>(op, nunits, s); }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) hipLaunchKernelGGL((k_se3_rows<true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, out12 + done * 12, Tinit + done * 16, G + done * 16, dout12 + done * 12, 1.f / fx, 1.f / fy, rest);
+    return check_launch("so3_se3_update_bwd_f32");
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {

@@ -300,6 +300,59 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
 
 
 # --------------------------------------------------------------------------------------------
+# next row f1: the SE(3) pose update of the iterative refiner
+# --------------------------------------------------------------------------------------------
+def get_scene_parameters():
+    """Focal lengths in pixels, as Iterative/utility.py:73-88: 50 mm lens, 36 mm sensor, 320 px."""
+    sw, img_res, flen = 36, 320, 50
+    fx = fy = flen / (sw / img_res)
+    return fx, fy
+
+
+class _Se3Update(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model_output, t_init, fx, fy):
+        dev = _require_device(model_output, t_init)
+        if model_output.dim() != 2 or model_output.shape[1] < 12 or tuple(t_init.shape[1:]) != (4, 4):
+            raise RuntimeError("calculate_T_pred expects model_output (B, >=12) and T_init (B, 4, 4)")
+        o = model_output.detach()[:, :12].contiguous().float()
+        t = t_init.detach().reshape(-1, 16).contiguous().float()
+        b = o.shape[0]
+        tp = torch.empty((b, 4, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_se3_update_f32(_ptr(o), _ptr(t), _ptr(tp), fx, fy, b, _stream(dev)), "so3_se3_update_f32")
+        ctx.save_for_backward(o, t)
+        ctx.meta = (model_output.shape, model_output.dtype, fx, fy)
+        return tp
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_t):
+        o, t = ctx.saved_tensors
+        shape, dtype, fx, fy = ctx.meta
+        dev = o.device
+        g = grad_t.reshape(-1, 16).contiguous().float()
+        d = torch.empty_like(o)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_se3_update_bwd_f32(_ptr(o), _ptr(t), _ptr(g), _ptr(d), fx, fy, o.shape[0], _stream(dev)), "so3_se3_update_bwd_f32")
+        full = torch.zeros(shape, dtype=torch.float32, device=dev)
+        full[:, :12] = d
+        return full.to(dtype), None, None, None
+
+
+def calculate_T_pred(model_output: torch.Tensor, T_init: torch.Tensor, device=None, rot_repr: str = "SVD") -> torch.Tensor:
+    """SE(3) update of the iterative refiner (Iterative/utility.py:90-128), one fused launch.
+
+    model_output: (B,12) = 9 numbers for the SVD head + (vx, vy, vz); T_init: (B,4,4).  Returns T_pred (B,4,4)
+    float32, differentiable w.r.t. model_output (T_init is a constant, as the reference's loop detaches it).
+    `device` is accepted for signature compatibility and ignored (the result lives where the inputs do)."""
+    if rot_repr != "SVD":
+        raise NotImplementedError("calculate_T_pred: only the SVD head is implemented natively")
+    fx, fy = get_scene_parameters()
+    return _Se3Update.apply(model_output, T_init, float(fx), float(fy))
+
+
+# --------------------------------------------------------------------------------------------
 # next row f3: per-class evaluation statistics
 # --------------------------------------------------------------------------------------------
 STAT_FIELDS = ("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")

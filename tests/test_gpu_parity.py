@@ -519,3 +519,36 @@ def test_engine_dtype_paths_at_size(rr, c_oracle):
     lu.backward()
     assert abs(loss.item() - lu.item()) < 2e-6 and (xl.grad - xu.grad).abs().max().item() < 1e-7
     assert (rf - r).abs().max().item() < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# next row f1: the SE(3) pose update of the iterative refiner (Iterative/utility.py:90-128)
+# ------------------------------------------------------------------------------------------------
+def test_g8_se3_update_forward_backward(rr):
+    from oracle import so3_oracle as so
+    g = load_golden("g8_se3_update.npz")
+    out = dev(g["out"]).requires_grad_(True)
+    tp = rr.calculate_T_pred(out, dev(g["t_init"]), DEV)
+    assert tuple(tp.shape) == (200, 4, 4)
+    assert np.abs(tp.detach().cpu().numpy() - g["t_pred"]).max() < 1e-5                       # vs the reference (float32)
+    assert np.abs(tp.detach().cpu().numpy() - so.se3_update_np(g["out"], g["t_init"])).max() < 5e-6
+    tp.backward(dev(g["g"]))
+    ref = so.se3_update_backward_np(g["out"], g["t_init"], g["g"])
+    rel = np.abs(out.grad.cpu().numpy() - ref).max(1) / (1e-3 + np.abs(ref).max(1))
+    rel_ref = np.abs(g["dout"] - ref).max(1) / (1e-3 + np.abs(ref).max(1))                    # the reference's float32 autograd
+    assert np.median(rel) < 1e-6 and rel.max() < 1e-4 and np.median(rel) <= 2 * np.median(rel_ref) + 1e-7
+    # ragged sizes (remainder kernel), extra network outputs beyond 12 columns get zero gradient
+    rng = np.random.default_rng(0)
+    for b in (1, 65, 1000, 100_003):
+        o = rng.standard_normal((b, 14)).astype(np.float32)
+        o[:, 11] = 1.0 + 0.1 * o[:, 11]
+        t = np.zeros((b, 4, 4), np.float32)
+        t[:, :3, :3] = so.symmetric_orthogonalization_np(rng.standard_normal((b, 9)))
+        t[:, :3, 3] = [0, 0, 2.5] + 0.3 * rng.standard_normal((b, 3))
+        t[:, 3, 3] = 1
+        od = dev(o).requires_grad_(True)
+        res = rr.calculate_T_pred(od, dev(t), DEV)
+        ref_t = so.se3_update_np(o[:, :12], t)
+        assert np.quantile(np.abs(res.detach().cpu().numpy() - ref_t), 0.999) < 5e-6
+        res.sum().backward()
+        assert od.grad[:, 12:].abs().max().item() == 0 and torch.isfinite(od.grad).all()

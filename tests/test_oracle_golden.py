@@ -176,3 +176,15 @@ def test_g7_ortho6d_oracle():
     assert so.ortho6d_np(g["p_shaped"]).shape == (2, 5, 3, 3)
     assert np.abs(so.ortho6d_np(g["p_shaped"]) - g["r_shaped"]).max() < 2e-5
     assert orth_err(g["r"]).max() < 1e-5
+
+
+def test_g8_se3_update_oracle():
+    """Next row f1: calculate_T_pred restated (float64) against the reference function's float32 output and autograd."""
+    g = load_golden("g8_se3_update.npz")
+    assert abs(float(g["fx"]) - 50 / (36 / 320)) < 1e-9 and float(g["fx"]) == float(g["fy"])
+    tp = so.se3_update_np(g["out"], g["t_init"])
+    assert np.abs(tp - g["t_pred"]).max() < 2e-5
+    assert np.abs(tp[:, 3] - np.array([0, 0, 0, 1.0])).max() == 0
+    d = so.se3_update_backward_np(g["out"], g["t_init"], g["g"])
+    rel = np.abs(d - g["dout"]).max(1) / (1e-3 + np.abs(g["dout"]).max(1))
+    assert np.median(rel) < 2e-6 and rel.max() < 1e-4

@@ -82,10 +82,46 @@ def g7_ortho6d():
          p_shaped=shaped, r_shaped=rr.compute_rotation_matrix_from_ortho6d(shaped))
 
 
+def g8_se3_update():
+    """Next row f1: calculate_T_pred (Iterative/utility.py:90-128) forward + autograd backward.
+
+    The reference's helper `combine` (utility.py:63-71) reads two names that are not in its scope
+    (`model_output`, `R_new`) and raises NameError as committed; the function compiled from the reference file is
+    therefore run with a `combine` that does what that helper plainly intends (ones(B,4,4); [:3,:3]=R; column 3 =
+    (tx,ty,tz); [3,:3]=0).  Everything else -- head, focal lengths, translation update, einsum -- is the
+    reference's own code."""
+    def combine(R, tx, ty, tz, device="cpu"):
+        T = torch.ones((R.shape[0], 4, 4))
+        T[:, :3, :3] = R
+        T[:, 0, 3], T[:, 1, 3], T[:, 2, 3] = tx, ty, tz
+        T[:, 3, :3] = 0
+        return T
+    calc, scene = functions_from(os.path.join(REF, "Iterative", "utility.py"), ["calculate_T_pred", "get_scene_parameters"])
+    calc.__globals__.update(symmetric_orthogonalization=rr.symmetric_orthogonalization, combine=combine, get_scene_parameters=scene)
+    torch.manual_seed(8)
+    b = 200
+    out = torch.randn(b, 12)
+    out[:, 9:11] *= 20.0                                   # pixel-scale offsets
+    out[:, 11] = 1.0 + 0.1 * torch.randn(b)                 # depth ratio near 1
+    t_init = torch.zeros(b, 4, 4)
+    t_init[:, :3, :3] = rr.symmetric_orthogonalization(torch.randn(b, 9))
+    t_init[:, :3, 3] = torch.tensor([0.0, 0.0, 2.5]) + 0.3 * torch.randn(b, 3)
+    t_init[:, 3, 3] = 1.0
+    g = torch.randn(b, 4, 4)
+    o = out.clone().requires_grad_(True)
+    tp = calc(o, t_init, "cpu")
+    tp.backward(g)
+    # (no float64 run: the reference casts R_k with .float(), utility.py:123, so a double input raises)
+    save("g8_se3_update.npz", out=out, t_init=t_init, g=g, t_pred=tp.detach(), dout=o.grad, fx=scene()[0], fy=scene()[1])
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g7":        # regenerate one fixture without touching the others
         return g7_ortho6d()
+    if len(sys.argv) > 1 and sys.argv[1] == "g8":
+        return g8_se3_update()
     g7_ortho6d()
+    g8_se3_update()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
