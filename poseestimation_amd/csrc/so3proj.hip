@@ -528,8 +528,17 @@ __global__ void k_stats_ranks(StatWork *w, int ncls) {      // middle ranks amon
     w->krem[1][c] = n > 0 ? n / 2 : 0;
 }
 
+// LDS: workgroup-private histograms first (early passes put almost every row into one or two digits -- the
+// exponent bytes -- and a million same-address global atomics would serialise), then one flush per bin.
+constexpr int kStatLdsClasses = 16;
+template <bool LDS>
 __global__ __launch_bounds__(kBlock) void k_stats_hist(const double *__restrict__ deg, const int32_t *__restrict__ cls,
                                                        int ncls, StatWork *w, int64_t B, int shift) {
+    __shared__ unsigned int sh[LDS ? 2 : 1][LDS ? kStatLdsClasses : 1][LDS ? 256 : 1];
+    if (LDS) {
+        for (int i = threadIdx.x; i < 2 * kStatLdsClasses * 256; i += kBlock) (&sh[0][0][0])[i] = 0;
+        __syncthreads();
+    }
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < B; i += static_cast<int64_t>(gridDim.x) * kBlock) {
         const double a = deg[i];
         const int c = cls ? cls[i] : 0;
@@ -538,7 +547,18 @@ __global__ __launch_bounds__(kBlock) void k_stats_hist(const double *__restrict_
         const unsigned long long hi = shift >= 56 ? 0ull : key >> (shift + 8);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            if (hi == w->prefix[t][c]) atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
+            if (hi == w->prefix[t][c]) {
+                if (LDS) atomicAdd(&sh[t][c][(key >> shift) & 0xFF], 1u);
+                else atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
+            }
+    }
+    if (LDS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * ncls * 256; i += kBlock) {
+            const int t = i / (ncls * 256), c = (i / 256) % ncls, d = i % 256;
+            const unsigned int v = sh[t][c][d];
+            if (v) atomicAdd(&w->hist[t][c][d], v);
+        }
     }
 }
 
@@ -837,7 +857,8 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     if (B > 0) k_stats_reduce<<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B);
     k_stats_ranks<<<1, kMaxClasses, 0, s>>>(w, ncls);
     for (int shift = 56; shift >= 0 && B > 0; shift -= 8) {
-        k_stats_hist<<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
+        if (ncls <= kStatLdsClasses) k_stats_hist<true><<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
+        else k_stats_hist<false><<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
         k_stats_scan<<<1, 2 * kMaxClasses, 0, s>>>(w, ncls);
     }
     k_stats_final<<<1, kMaxClasses, 0, s>>>(w, ncls, stats);

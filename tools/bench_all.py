@@ -53,6 +53,24 @@ def main():
     timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
     timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
     timeit("K4' so3_geodesic_f32", lambda i: lib.so3_geodesic_f32(p(r[i % NB]), p(rt[i % NB]), p(th), n, st), 76 * n)
+    print("--- next rows (f1, f2, f3) at 1M rows ---")
+    x6 = [torch.randn(n, 6, device=dev) for _ in range(NB)]
+    d6 = torch.empty(n, 6, device=dev)
+    timeit("f2 so3_ortho6d_fwd_f32", lambda i: lib.so3_ortho6d_fwd_f32(p(x6[i % NB]), p(r[i % NB]), n, st), 60 * n)
+    timeit("f2 so3_ortho6d_bwd_f32", lambda i: lib.so3_ortho6d_bwd_f32(p(x6[i % NB]), p(g[i % NB]), p(d6), n, st), 84 * n)
+    del x6, d6
+    o12 = [torch.randn(n, 12, device=dev) for _ in range(3)]
+    ti = [torch.eye(4, device=dev).repeat(n, 1, 1).contiguous() + 0.1 * torch.randn(n, 4, 4, device=dev) for _ in range(3)]
+    tp = torch.empty(n, 16, device=dev); g16 = torch.randn(n, 16, device=dev); do12 = torch.empty(n, 12, device=dev)
+    fx = ctypes.c_float(444.444)
+    timeit("f1 so3_se3_update_f32", lambda i: lib.so3_se3_update_f32(p(o12[i % 3]), p(ti[i % 3]), p(tp), fx, fx, n, st), 176 * n)
+    timeit("f1 so3_se3_update_bwd_f32", lambda i: lib.so3_se3_update_bwd_f32(p(o12[i % 3]), p(ti[i % 3]), p(g16), p(do12), fx, fx, n, st), 224 * n)
+    del o12, ti, tp, g16, do12
+    cls = torch.randint(0, 10, (n,), device=dev, dtype=torch.int32)
+    lib.so3_angle_error(p(r[0]), p(rt[0]), p(deg), None, p(fl), 0, n, st)
+    stats = torch.empty(10, 8, dtype=torch.float64, device=dev)
+    work = torch.empty(lib.so3_angle_stats_workspace_bytes(), dtype=torch.uint8, device=dev)
+    timeit("f3 so3_angle_stats (10 classes, exact median)", lambda i: lib.so3_angle_stats(p(deg), p(cls), 10, p(stats), p(work), n, st), 12 * n, iters=20)
     del x, xb, g, r, dm, dmb, rt
     torch.cuda.empty_cache()
     print("--- config #3: 65536 clouds x 1024 points ---")
