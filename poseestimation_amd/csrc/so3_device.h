@@ -33,6 +33,9 @@
 
 namespace so3 {
 
+#ifndef SO3_REUSE_NORMS
+#define SO3_REUSE_NORMS 0   // 1 breaks orthogonality for s2/s1 < 1e-2 (tools/illcond_check.py): kept off
+#endif
 #ifndef SO3_SWEEPS
 #define SO3_SWEEPS 3
 #endif
@@ -218,18 +221,31 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     const V3<T> z = sel<T>(z2, a2, sel<T>(z0, a0, a1));
     const T nx = R::sel(z2, n0, R::sel(z0, n1, n2));
 
-    V3<T> u1 = scale<T>(x, R::rsq(nx));
+    const T inx = R::rsq(nx);
+    V3<T> u1 = scale<T>(x, inx);
     V3<T> w = axpy<T>(-dot(u1, y), u1, y);
     T nw = dot(w, w);
-    V3<T> u2 = scale<T>(w, R::rsq(nw));
+    const T inw = R::rsq(nw);
+    V3<T> u2 = scale<T>(w, inw);
     const V3<T> mr0 = mk<T>(m[0], m[1], m[2]), mr1 = mk<T>(m[3], m[4], m[5]), mr2 = mk<T>(m[6], m[7], m[8]);
     V3<T> t1 = axpy<T>(u1.z, mr2, axpy<T>(u1.y, mr1, scale<T>(mr0, u1.x)));     // M^T u1 = s1 v1
     V3<T> t2 = axpy<T>(u2.z, mr2, axpy<T>(u2.y, mr1, scale<T>(mr0, u2.x)));     // M^T u2 = s2 v2
+#if SO3_REUSE_NORMS
+    // |M^T u1| = s1 = |x| and |GS(M^T u2)| = s2 = |w| up to the SQUARE of the sweep residual (u1 = x/|x| exactly;
+    // a residual eps tilts it by eps towards u2, which changes |M^T u1|^2 by eps^2 s2^2): reuse 1/|x| and 1/|w|
+    // instead of two more dot products and rsq per matrix.
+    T nt1 = nx;
+    V3<T> v1 = scale<T>(t1, inx);
+    V3<T> r2 = axpy<T>(-dot(v1, t2), v1, t2);
+    T nr2 = nw;
+    V3<T> v2 = scale<T>(r2, inw);
+#else
     T nt1 = dot(t1, t1);
     V3<T> v1 = scale<T>(t1, R::rsq(nt1));
     V3<T> r2 = axpy<T>(-dot(v1, t2), v1, t2);
     T nr2 = dot(r2, r2);
     V3<T> v2 = scale<T>(r2, R::rsq(nr2));
+#endif
 
     // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.
     // (`<=` comparisons are false for NaN, so NaN input flows through the fast path to NaN output.)

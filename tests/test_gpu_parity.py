@@ -552,3 +552,22 @@ def test_g8_se3_update_forward_backward(rr):
         assert np.quantile(np.abs(res.detach().cpu().numpy() - ref_t), 0.999) < 5e-6
         res.sum().backward()
         assert od.grad[:, 12:].abs().max().item() == 0 and torch.isfinite(od.grad).all()
+
+
+def test_orthogonality_holds_for_ill_conditioned_input(rr):
+    """s = (1, 10^-k2, +-10^-k3), k2 in [0,7]: R stays a rotation to 1e-5 however badly M is conditioned
+    (the final Gram-Schmidt steps, not the sweeps, guarantee it); see tools/illcond_check.py."""
+    from oracle import so3_oracle as so
+    rng = np.random.default_rng(0)
+    n = 200_000
+    u = so.symmetric_orthogonalization_np(rng.standard_normal((n, 9)))
+    v = so.symmetric_orthogonalization_np(rng.standard_normal((n, 9)))
+    k2 = rng.uniform(0, 7, n)
+    k3 = k2 + rng.uniform(0, 3, n)
+    s = np.stack([np.ones(n), 10.0 ** -k2, np.where(rng.random(n) < 0.5, -1.0, 1.0) * 10.0 ** -k3], 1)
+    m = (u * s[:, None, :]) @ v.transpose(0, 2, 1)
+    r = rr.symmetric_orthogonalization(dev(m.reshape(n, 9))).cpu().numpy()
+    assert np.isfinite(r).all() and orth_err(r).max() < 1e-5
+    assert np.abs(np.linalg.det(r.astype(np.float64)) - 1).max() < 1e-5
+    well = k2 < 1.5
+    assert np.quantile(np.abs(r[well] - so.symmetric_orthogonalization_np(m[well].astype(np.float32))), 0.999) < 2e-5
