@@ -158,6 +158,20 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N,
                    void *stream);
 
+/* ---- next row: on-device pair synthesis for Kabsch ------------------------------
+ * so3_rotations_axis_angle_f32: the arithmetic of the reference's sampler, point_cloud/prepare.py:21-49
+ *   (normalize_vector :12-18, quaternion (cos theta, axis sin theta) -> matrix :27-47), given the random
+ *   draws theta (B) and axis (B,3) (the reference draws them with numpy / torch.randn: RNG stays with the caller).
+ * so3_kabsch_synth_f32: K5 with the second cloud synthesised on the fly,
+ *       q_bi = Rgt_b p_bi + sigma * n(seed, b, i)        (pairing rule point_cloud/main.py:173-181, plus noise)
+ *   so only P (12 B per point) is read from HBM instead of P and Q.  n is a stateless counter-based standard
+ *   normal (32-bit mix -> Box-Muller, csrc/so3proj.hip `synth_normal`; restated in oracle/so3_oracle.py).
+ *   sigma = 0 skips the generator.  R, H as in so3_kabsch_f32.
+ */
+int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream);
+int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t seed, float *R, float *H,
+                         int64_t B, int32_t N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

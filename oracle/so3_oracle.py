@@ -149,6 +149,49 @@ def sample_rotations_axis_angle_np(rng, batch):
     return np.stack((row0, row1, row2), 1)                          # :47
 
 
+def rotations_from_draws_np(theta, axis):
+    """The arithmetic of the reference sampler (point_cloud/prepare.py:24-47) for given draws theta (B,), axis (B,3)."""
+    theta = np.asarray(theta, np.float64)
+    axis = np.asarray(axis, np.float64)
+    axis = axis / np.maximum(np.linalg.norm(axis, axis=1, keepdims=True), 1e-8)
+    sin, qw = np.sin(theta), np.cos(theta)
+    qx, qy, qz = axis[:, 0] * sin, axis[:, 1] * sin, axis[:, 2] * sin
+    xx, yy, zz, xy, xz, yz = qx * qx, qy * qy, qz * qz, qx * qy, qx * qz, qy * qz
+    xw, yw, zw = qx * qw, qy * qw, qz * qw
+    return np.stack((np.stack((1 - 2 * yy - 2 * zz, 2 * xy - 2 * zw, 2 * xz + 2 * yw), 1),
+                     np.stack((2 * xy + 2 * zw, 1 - 2 * xx - 2 * zz, 2 * yz - 2 * xw), 1),
+                     np.stack((2 * xz - 2 * yw, 2 * yz + 2 * xw, 1 - 2 * xx - 2 * yy), 1)), 1)
+
+
+def _mix32(x):
+    x = np.asarray(x, np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def synth_normal_np(seed, cloud, point, comp):
+    """The stateless standard normal of so3_kabsch_synth_f32 (csrc/so3proj.hip `synth_normal`), restated."""
+    cloud, point, comp = (np.asarray(v, np.uint64) for v in (cloud, point, comp))
+    k = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & 0xFFFFFFFF) ^ _mix32((point * 3 + comp + 0xc2b2ae35) & 0xFFFFFFFF))
+    k2 = _mix32((k + 0x27d4eb2f) & 0xFFFFFFFF)
+    u1 = ((k >> 8).astype(np.float64) + 1.0) / 16777216.0
+    u2 = (k2 >> 8).astype(np.float64) / 16777216.0
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2 * np.pi * u2)
+
+
+def synth_pairs_np(p, r_gt, sigma, seed):
+    """q_bi = R_gt_b p_bi + sigma n(seed, b, i, c)  (pairing rule point_cloud/main.py:173-181 plus noise)."""
+    p = np.asarray(p, np.float64)
+    b, n, _ = p.shape
+    q = np.einsum("bac,bic->bia", np.asarray(r_gt, np.float64).reshape(b, 3, 3), p)
+    if sigma != 0:
+        cb, pi, cc = np.meshgrid(np.arange(b), np.arange(n), np.arange(3), indexing="ij")
+        q = q + sigma * synth_normal_np(seed, cb, pi, cc)
+    return q
+
+
 def cross_covariance_np(p, q):
     """H_b = sum_i q_i p_i^T = bmm(Q^T, P), float64 (config #3)."""
     p = np.asarray(p, np.float64)

@@ -7,7 +7,9 @@ from .rotation_representation import (  # noqa: F401
     compute_geodesic_distance_from_two_matrices,
     compute_rotation_matrix_from_ortho6d,
     frobenius_head,
+    get_sampled_rotation_matrices_by_axisAngle,
     kabsch_rotation,
+    kabsch_rotation_synthetic,
     loss_frobenius,
     symmetric_orthogonalization,
     transform_output,
@@ -23,5 +25,7 @@ __all__ = [
     "loss_frobenius",
     "frobenius_head",
     "kabsch_rotation",
+    "kabsch_rotation_synthetic",
+    "get_sampled_rotation_matrices_by_axisAngle",
     "transform_output",
 ]

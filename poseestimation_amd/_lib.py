@@ -34,6 +34,8 @@ SYMBOLS = {
     "so3_angle_stats_workspace_bytes": (ctypes.c_size_t, []),
     "so3_angle_stats": (_INT, [_P, _P, _I32, _P, _P, _I64, _P]),
     "so3_kabsch_f32": (_INT, [_P, _P, _P, _P, _I64, _I32, _P]),
+    "so3_rotations_axis_angle_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_kabsch_synth_f32": (_INT, [_P, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _I64, _I32, _P]),
 }
 
 _lock = threading.Lock()

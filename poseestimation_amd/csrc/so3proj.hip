@@ -415,6 +415,107 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
     }
 }
 
+// ---- next row f4: on-device pair synthesis for Kabsch (point_cloud/prepare.py:21-49, point_cloud/main.py:173-181) --
+// (a) the reference's rotation sampler as a kernel: quaternion (cos t, axis sin t) -> matrix, given the random draws;
+// (b) Kabsch with the second cloud synthesised on the fly, q_i = R_gt p_i + sigma n_i, so only P is read from HBM.
+// The noise is a counter-based generator (no state): a 32-bit mix of (seed, cloud, point) -> two uniforms ->
+// Box-Muller; component c of point i uses the pair (i, c) so the oracle can restate it exactly.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float synth_normal(unsigned seed, unsigned cloud, unsigned point, unsigned comp) {
+    const unsigned k = mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu) ^ mix32(point * 3u + comp + 0xc2b2ae35u));
+    const unsigned k2 = mix32(k + 0x27d4eb2fu);
+    const float u1 = (static_cast<float>(k >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = static_cast<float>(k2 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+__global__ __launch_bounds__(kBlock) void k_rotations_axis_angle(const float *__restrict__ theta, const float *__restrict__ axis,
+                                                                 float *__restrict__ R, int64_t B) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (b >= B) return;
+    const float t = theta[b];
+    float ax = axis[3 * b], ay = axis[3 * b + 1], az = axis[3 * b + 2];
+    const float mag = fmaxf(sqrtf(ax * ax + ay * ay + az * az), 1e-8f);        // normalize_vector, prepare.py:12-18
+    ax /= mag; ay /= mag; az /= mag;
+    const float sn = sinf(t), qw = cosf(t);                                        // :24,27
+    const float qx = ax * sn, qy = ay * sn, qz = az * sn;                          // :28-30
+    const float xx = qx * qx, yy = qy * qy, zz = qz * qz, xy = qx * qy, xz = qx * qz, yz = qy * qz;
+    const float xw = qx * qw, yw = qy * qw, zw = qz * qw;
+    float *o = R + 9 * b;
+    o[0] = 1 - 2 * yy - 2 * zz; o[1] = 2 * xy - 2 * zw;     o[2] = 2 * xz + 2 * yw;      // :43
+    o[3] = 2 * xy + 2 * zw;     o[4] = 1 - 2 * xx - 2 * zz; o[5] = 2 * yz - 2 * xw;      // :44
+    o[6] = 2 * xz - 2 * yw;     o[7] = 2 * yz + 2 * xw;     o[8] = 1 - 2 * xx - 2 * yy;  // :45
+}
+
+__global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict__ P, const float *__restrict__ Rgt, float sigma,
+                                                         unsigned seed, float *__restrict__ R, float *__restrict__ H, int64_t B,
+                                                         int32_t N, int clouds_per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
+    const int64_t c0 = wave * clouds_per_wave;
+    if (c0 >= B) return;
+    const int nc = static_cast<int>(min<int64_t>(clouds_per_wave, B - c0));
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = (i & 3) == 0 ? 1.f : 0.f;
+    const unsigned cloud_bytes = static_cast<unsigned>(N) * 12u;
+    for (int j = 0; j < nc; ++j) {
+        const so3::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        float g[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = Rgt[(c0 + j) * 9 + i];                   // wave-uniform: scalar loads
+        float acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+        for (int i0 = 0; i0 < N; i0 += 64 * kKabschUnroll) {
+            u32x3 pp[kKabschUnroll];
+#pragma unroll
+            for (int u = 0; u < kKabschUnroll; ++u)
+                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+#pragma unroll
+            for (int u = 0; u < kKabschUnroll; ++u) {
+                const int pt = i0 + 64 * u + lane;
+                const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
+                float qx = fmaf(g[2], pz, fmaf(g[1], py, g[0] * px));               // q = R_gt p   (main.py:176-181)
+                float qy = fmaf(g[5], pz, fmaf(g[4], py, g[3] * px));
+                float qz = fmaf(g[8], pz, fmaf(g[7], py, g[6] * px));
+                if (sigma != 0.f && pt < N) {                                       // padded lanes must stay exactly zero
+                    const unsigned cl = static_cast<unsigned>(c0 + j), up = static_cast<unsigned>(pt);
+                    qx = fmaf(sigma, synth_normal(seed, cl, up, 0u), qx);
+                    qy = fmaf(sigma, synth_normal(seed, cl, up, 1u), qy);
+                    qz = fmaf(sigma, synth_normal(seed, cl, up, 2u), qz);
+                }
+                acc[0] = fmaf(qx, px, acc[0]); acc[1] = fmaf(qx, py, acc[1]); acc[2] = fmaf(qx, pz, acc[2]);
+                acc[3] = fmaf(qy, px, acc[3]); acc[4] = fmaf(qy, py, acc[4]); acc[5] = fmaf(qy, pz, acc[5]);
+                acc[6] = fmaf(qz, px, acc[6]); acc[7] = fmaf(qz, py, acc[7]); acc[8] = fmaf(qz, pz, acc[8]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float tot = wave_allsum(acc[i]);
+            h[i] = (lane == j) ? tot : h[i];
+        }
+    }
+    const bool active = lane < nc;
+    const auto f = so3::signed_svd<false>(h);
+    float r[9];
+    so3::rotation_from(f, r);
+    if (active) {
+        float *out = R + (c0 + lane) * 9;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) out[i] = r[i];
+        if (H != nullptr) {
+            float *ho = H + (c0 + lane) * 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ho[i] = h[i];
+        }
+    }
+}
+
 // ---- 6D head, one row per thread: remainder (< 64 rows) and unaligned input of the streaming kernels ----------
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict__ X, const float *__restrict__ G,
@@ -887,6 +988,29 @@ int so3_se3_update_bwd_f32(const float *out12, const float *Tinit, const float *
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) hipLaunchKernelGGL((k_se3_rows<true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, out12 + done * 12, Tinit + done * 16, G + done * 16, dout12 + done * 12, 1.f / fx, 1.f / fy, rest);
     return check_launch("so3_se3_update_bwd_f32");
+}
+
+int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_rotations_axis_angle_f32: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(theta != nullptr && axis != nullptr && R != nullptr, "so3_rotations_axis_angle_f32: null pointer");
+    hipLaunchKernelGGL(k_rotations_axis_angle, dim3(grid_for(B)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), theta, axis, R, B);
+    return check_launch("so3_rotations_axis_angle_f32");
+}
+
+int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t seed, float *R, float *H, int64_t B, int32_t N,
+                         void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 300000000, "so3_kabsch_synth_f32: B/N");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R != nullptr && Rgt != nullptr && (N == 0 || P != nullptr), "so3_kabsch_synth_f32: null pointer");
+    int64_t cpw = B / (256 * 16);
+    if (cpw < 1) cpw = 1;
+    if (cpw > 64) cpw = 64;
+    const int64_t waves = (B + cpw - 1) / cpw;
+    const int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    hipLaunchKernelGGL(k_kabsch_synth, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, Rgt, sigma,
+                       seed, R, H, B, N, static_cast<int>(cpw));
+    return check_launch("so3_kabsch_synth_f32");
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {

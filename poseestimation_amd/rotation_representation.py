@@ -300,6 +300,48 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
 
 
 # --------------------------------------------------------------------------------------------
+# next row f4: on-device pair synthesis for Kabsch
+# --------------------------------------------------------------------------------------------
+def get_sampled_rotation_matrices_by_axisAngle(batch: int, device="cuda", generator: torch.Generator = None) -> torch.Tensor:
+    """Random rotations by the reference's recipe (point_cloud/prepare.py:21-49): theta ~ U(-pi, pi), axis =
+    normalised N(0, I), quaternion (cos theta, axis sin theta).  torch draws the random numbers; the quaternion ->
+    matrix arithmetic runs in the HIP library."""
+    dev = torch.device(device)
+    theta = (torch.rand(batch, device=dev, generator=generator) * 2 - 1) * torch.pi
+    axis = torch.randn(batch, 3, device=dev, generator=generator)
+    return rotations_from_axis_angle_draws(theta, axis)
+
+
+def rotations_from_axis_angle_draws(theta: torch.Tensor, axis: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(theta, axis)
+    t = theta.detach().reshape(-1).contiguous().float()
+    a = axis.detach().reshape(-1, 3).contiguous().float()
+    if a.shape[0] != t.shape[0]:
+        raise RuntimeError("rotations_from_axis_angle_draws: theta (B,) and axis (B,3) disagree")
+    r = torch.empty((t.shape[0], 3, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_rotations_axis_angle_f32(_ptr(t), _ptr(a), _ptr(r), t.shape[0], _stream(dev)), "so3_rotations_axis_angle_f32")
+    return r
+
+
+def kabsch_rotation_synthetic(P: torch.Tensor, R_gt: torch.Tensor, sigma: float = 0.0, seed: int = 0, return_h: bool = False):
+    """Kabsch with the second cloud synthesised in the kernel: q = R_gt p + sigma * n(seed, cloud, point).
+    Only P is read from HBM (config #3 with half the traffic)."""
+    dev = _require_device(P, R_gt)
+    if P.dim() != 3 or P.shape[-1] != 3 or R_gt.shape[0] != P.shape[0]:
+        raise RuntimeError("kabsch_rotation_synthetic: expected P (B,N,3) and R_gt (B,3,3)")
+    p = P.detach().contiguous().float()
+    g = R_gt.detach().reshape(-1, 9).contiguous().float()
+    b, n, _ = p.shape
+    r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_kabsch_synth_f32(_ptr(p), _ptr(g), float(sigma), int(seed) & 0xFFFFFFFF, _ptr(r), _ptr(h), b, n, _stream(dev)),
+                   "so3_kabsch_synth_f32")
+    return (r, h) if return_h else r
+
+
+# --------------------------------------------------------------------------------------------
 # next row f1: the SE(3) pose update of the iterative refiner
 # --------------------------------------------------------------------------------------------
 def get_scene_parameters():

@@ -571,3 +571,35 @@ def test_orthogonality_holds_for_ill_conditioned_input(rr):
     assert np.abs(np.linalg.det(r.astype(np.float64)) - 1).max() < 1e-5
     well = k2 < 1.5
     assert np.quantile(np.abs(r[well] - so.symmetric_orthogonalization_np(m[well].astype(np.float32))), 0.999) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# next row f4: on-device pair synthesis for Kabsch (point_cloud/prepare.py:21-49, main.py:173-181)
+# ------------------------------------------------------------------------------------------------
+def test_g9_sampler_kernel_and_synthesised_kabsch(rr, c_oracle):
+    from oracle import so3_oracle as so
+    g = load_golden("g9_sampler.npz")
+    r = rr.rotations_from_axis_angle_draws(dev(g["theta"]), dev(g["axis"])).cpu().numpy()
+    assert np.abs(r - g["r"]).max() < 2e-6                                  # vs the reference sampler's own output
+    rs = rr.get_sampled_rotation_matrices_by_axisAngle(10_000, DEV).cpu().numpy()
+    assert orth_err(rs).max() < 1e-5 and np.abs(np.linalg.det(rs.astype(np.float64)) - 1).max() < 1e-5
+    # synthesised pairs: H and R against the oracle's restatement of the generator, noise-free and noisy
+    rng = np.random.default_rng(4)
+    for b, n, sigma in ((7, 64, 0.0), (5, 1024, 0.0), (33, 200, 0.02), (300, 1024, 0.01)):
+        p = (rng.random((b, n, 3)) - 0.5).astype(np.float32)
+        rg = so.symmetric_orthogonalization_np(rng.standard_normal((b, 9))).astype(np.float32)
+        rk, h = rr.kabsch_rotation_synthetic(dev(p), dev(rg), sigma, 1234, return_h=True)
+        q = so.synth_pairs_np(p, rg, sigma, 1234)
+        h_ref = so.cross_covariance_np(p, q)
+        assert np.abs(h.cpu().numpy() - h_ref).max() < 2e-5 * max(1.0, np.abs(h_ref).max())
+        r_ref = so.symmetric_orthogonalization_np(h_ref)
+        assert np.quantile(np.abs(rk.cpu().numpy() - r_ref), 0.99) < 2e-5
+        if sigma == 0.0:
+            assert np.abs(rk.cpu().numpy() - rg).max() < 5e-6               # noise-free: the generating rotation comes back
+        else:
+            assert so.angle_error_np(rk.cpu().numpy(), rg).max() < 2.0
+    # the fused form equals the two-array Kabsch on the same (materialised) pairs
+    p = torch.rand(2000, 1024, 3, device=DEV) - 0.5
+    rg = rr.get_sampled_rotation_matrices_by_axisAngle(2000, DEV)
+    q = torch.bmm(p, rg.transpose(1, 2))
+    assert (rr.kabsch_rotation_synthetic(p, rg) - rr.kabsch_rotation(p, q)).abs().max().item() < 5e-6

@@ -188,3 +188,16 @@ def test_g8_se3_update_oracle():
     d = so.se3_update_backward_np(g["out"], g["t_init"], g["g"])
     rel = np.abs(d - g["dout"]).max(1) / (1e-3 + np.abs(g["dout"]).max(1))
     assert np.median(rel) < 2e-6 and rel.max() < 1e-4
+
+
+def test_g9_sampler_and_synthesis_oracle():
+    """Next row f4: the sampler's arithmetic against the reference's output for recorded draws; the stateless
+    normal generator has unit variance and the synthesised pairs reproduce the pairing rule."""
+    g = load_golden("g9_sampler.npz")
+    assert np.abs(so.rotations_from_draws_np(g["theta"], g["axis"]) - g["r"]).max() < 2e-6
+    z = so.synth_normal_np(3, *np.meshgrid(np.arange(50), np.arange(400), np.arange(3), indexing="ij"))
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs(np.corrcoef(z[:, :, 0].ravel(), z[:, :, 1].ravel())[0, 1]) < 0.02
+    rng = np.random.default_rng(0)
+    p = rng.random((4, 100, 3)) - 0.5
+    q = so.synth_pairs_np(p, g["r"][:4], 0.0, 1)
+    assert np.abs(q - np.einsum("bac,bic->bia", g["r"][:4].astype(np.float64), p)).max() < 1e-12

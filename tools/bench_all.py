@@ -79,6 +79,9 @@ def main():
     qc = [torch.rand(b, npts, 3, device=dev) - 0.5 for _ in range(2)]
     rk = torch.empty(b, 9, device=dev)
     timeit("K5 so3_kabsch_f32", lambda i: lib.so3_kabsch_f32(p(pc[i % 2]), p(qc[i % 2]), p(rk), None, b, npts, st), b * (2 * npts * 12 + 36), iters=10, warm=2)
+    rg = rr.get_sampled_rotation_matrices_by_axisAngle(b, dev).reshape(b, 9).contiguous()
+    timeit("f4 so3_kabsch_synth_f32 (sigma=0: P only)", lambda i: lib.so3_kabsch_synth_f32(p(pc[i % 2]), p(rg), ctypes.c_float(0.0), 1, p(rk), None, b, npts, st), b * (npts * 12 + 72), iters=10, warm=2)
+    timeit("f4 so3_kabsch_synth_f32 (sigma=0.01, device RNG)", lambda i: lib.so3_kabsch_synth_f32(p(pc[i % 2]), p(rg), ctypes.c_float(0.01), 1, p(rk), None, b, npts, st), b * (npts * 12 + 72), iters=10, warm=2)
     del pc, qc
     torch.cuda.empty_cache()
     print("--- config #4: B = 512, bf16 storage, fused head + loss + backward ---")

@@ -115,13 +115,31 @@ def g8_se3_update():
     save("g8_se3_update.npz", out=out, t_init=t_init, g=g, t_pred=tp.detach(), dout=o.grad, fx=scene()[0], fy=scene()[1])
 
 
+def g9_sampler():
+    """Next row f4: the rotation sampler (point_cloud/prepare.py:21-49) with its random draws recorded.
+    The sampler takes theta from numpy's global RNG and the axis from torch's; both are re-seeded so the draws
+    can be replayed and stored next to the matrices the reference made from them."""
+    b = 500
+    np.random.seed(11)
+    theta = np.random.uniform(-1, 1, b) * np.pi                      # what prepare.py:23 will draw
+    torch.manual_seed(11)
+    axis = torch.randn(b, 3)                                         # what prepare.py:25 will draw
+    np.random.seed(11)
+    torch.manual_seed(11)
+    r = sample_rot(b)
+    save("g9_sampler.npz", theta=theta.astype(np.float32), axis=axis, r=r)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        return g9_sampler()
     if len(sys.argv) > 1 and sys.argv[1] == "g7":        # regenerate one fixture without touching the others
         return g7_ortho6d()
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         return g8_se3_update()
     g7_ortho6d()
     g8_se3_update()
+    g9_sampler()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
