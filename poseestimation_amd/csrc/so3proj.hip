@@ -418,18 +418,29 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
 // ---- next row f4: on-device pair synthesis for Kabsch (point_cloud/prepare.py:21-49, point_cloud/main.py:173-181) --
 // (a) the reference's rotation sampler as a kernel: quaternion (cos t, axis sin t) -> matrix, given the random draws;
 // (b) Kabsch with the second cloud synthesised on the fly, q_i = R_gt p_i + sigma n_i, so only P is read from HBM.
-// The noise is a counter-based generator (no state): a 32-bit mix of (seed, cloud, point) -> two uniforms ->
-// Box-Muller; component c of point i uses the pair (i, c) so the oracle can restate it exactly.
+// The noise is a counter-based generator (no state): a 32-bit mix of (seed, cloud, point, pair) -> two uniforms ->
+// Box-Muller; restated by the test oracle (synth_normal_np).
 __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ float synth_normal(unsigned seed, unsigned cloud, unsigned point, unsigned comp) {
-    const unsigned k = mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu) ^ mix32(point * 3u + comp + 0xc2b2ae35u));
+// Three standard normals per point from two Box-Muller pairs: (n0, n1) = r_a (cos, sin)(2 pi u_a2), n2 = r_b cos(2 pi u_b2),
+// r = sqrt(-2 ln u_1).  Hardware transcendentals: v_log_f32 (log2), v_cos_f32 / v_sin_f32 (argument in turns).
+__device__ __forceinline__ void synth_uniforms(unsigned seed, unsigned cloud, unsigned point, unsigned pair, float &u1, float &u2) {
+    const unsigned k = mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu) ^ mix32(point * 2u + pair + 0xc2b2ae35u));
     const unsigned k2 = mix32(k + 0x27d4eb2fu);
-    const float u1 = (static_cast<float>(k >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-    const float u2 = static_cast<float>(k2 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    u1 = (static_cast<float>(k >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    u2 = static_cast<float>(k2 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+}
+__device__ __forceinline__ void synth_normal3(unsigned seed, unsigned cloud, unsigned point, float &n0, float &n1, float &n2) {
+    float a1, a2, b1, b2;
+    synth_uniforms(seed, cloud, point, 0u, a1, a2);
+    synth_uniforms(seed, cloud, point, 1u, b1, b2);
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a1));     // -2 ln2 log2(u)
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(b1));
+    n0 = ra * __builtin_amdgcn_cosf(a2);
+    n1 = ra * __builtin_amdgcn_sinf(a2);
+    n2 = rb * __builtin_amdgcn_cosf(b2);
 }
 
 __global__ __launch_bounds__(kBlock) void k_rotations_axis_angle(const float *__restrict__ theta, const float *__restrict__ axis,
@@ -485,9 +496,11 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
                 float qz = fmaf(g[8], pz, fmaf(g[7], py, g[6] * px));
                 if (sigma != 0.f && pt < N) {                                       // padded lanes must stay exactly zero
                     const unsigned cl = static_cast<unsigned>(c0 + j), up = static_cast<unsigned>(pt);
-                    qx = fmaf(sigma, synth_normal(seed, cl, up, 0u), qx);
-                    qy = fmaf(sigma, synth_normal(seed, cl, up, 1u), qy);
-                    qz = fmaf(sigma, synth_normal(seed, cl, up, 2u), qz);
+                    float n0, n1, n2;
+                    synth_normal3(seed, cl, up, n0, n1, n2);
+                    qx = fmaf(sigma, n0, qx);
+                    qy = fmaf(sigma, n1, qy);
+                    qz = fmaf(sigma, n2, qz);
                 }
                 acc[0] = fmaf(qx, px, acc[0]); acc[1] = fmaf(qx, py, acc[1]); acc[2] = fmaf(qx, pz, acc[2]);
                 acc[3] = fmaf(qy, px, acc[3]); acc[4] = fmaf(qy, py, acc[4]); acc[5] = fmaf(qy, pz, acc[5]);
