@@ -308,11 +308,16 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
     rotation_rows<T>(f.u1, f.u2, f.v1, f.v2, r);
 }
 
-// sign(det M) evaluated in float64 (products of floats are exact in double) -> flip flag.
+// sign(det M) -> flip flag.  A float32 cofactor expansion decides whenever |det| clears its own rounding bound
+// (8 eps times the sum of the |terms|); only the rare rows inside that band (and rows whose products leave the
+// float32 range) pay for the float64 evaluation, where products of floats are exact.
 __device__ __forceinline__ bool det_negative(const float (&m)[9]) {
+    const float t0 = m[4] * m[8], t1 = m[5] * m[7], t2 = m[3] * m[8], t3 = m[5] * m[6], t4 = m[3] * m[7], t5 = m[4] * m[6];
+    const float det = fmaf(m[0], t0 - t1, fmaf(-m[1], t2 - t3, m[2] * (t4 - t5)));
+    const float mag = fmaf(fabsf(m[0]), fabsf(t0) + fabsf(t1), fmaf(fabsf(m[1]), fabsf(t2) + fabsf(t3), fabsf(m[2]) * (fabsf(t4) + fabsf(t5))));
+    if (__builtin_expect(fabsf(det) > 1e-6f * mag && mag > 1e-30f && mag < 1e30f, 1)) return det < 0.f;
     const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
-    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
-    return det < 0.0;
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g) < 0.0;
 }
 
 // dM = U' Bm V^T for upstream G (row-major), Bm_ij = (A_ij - A_ji)/(s_i + s_j), A = U'^T G V.
