@@ -92,8 +92,6 @@ def main():
     ms = e0.elapsed_time(e1) / 10
     print("K5 65536x1024: %.1f us  %.1f GB/s (%.1f%% of 8 TB/s)" % (ms * 1e3, B * 24612 / ms / 1e6, B * 24612 / ms / 1e6 / 8000 * 100))
 
-if __name__ == "__main__":
-    main()
 
 
 def time_k4():
@@ -121,8 +119,6 @@ def time_k4():
         print("K4 1M %-9s %.2f us/call (incl. memset + count launches)" % (name, e0.elapsed_time(e1) / 20 * 1e3))
 
 
-if __name__ == "__main__":
-    time_k4()
 
 
 def time_config4():
@@ -171,4 +167,6 @@ def time_config4():
 
 
 if __name__ == "__main__":
+    main()
+    time_k4()
     time_config4()

@@ -1,5 +1,8 @@
 """Numerical prototype (numpy, fp32 emulation) of the per-lane 3x3 signed-SVD used by the HIP kernels.
 
+Shipped schedule (csrc/so3_device.h): 3 fixed sweeps, then one more for the rows whose (0,1) residual exceeds
+0.7e-5 (in the kernel: for the whole wave).  This script is the design study behind that choice.
+
 Design study only -- not shipped, not imported by the package.  It answers: how many one-sided
 (Hestenes) Jacobi sweeps does fp32 need so that R = U'V^T matches LAPACK's
 U diag(1,1,det(UV^T)) V^T on Gaussian 3x3 input?
