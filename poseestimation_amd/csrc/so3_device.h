@@ -254,7 +254,7 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     if (__builtin_expect(R::any(degenerate), 0)) {
 #pragma unroll
         for (int i = 0; i < R::kLanes; ++i) {
-            if (!R::lane_of(degenerate, i)) continue;
+            if (R::lane_of(degenerate, i)) {
             const float f0 = R::get(n0, i), f1 = R::get(n1, i), f2 = R::get(n2, i);
             const bool b0 = (f0 >= f1) && (f0 >= f2);
             const bool b1 = (f1 >= f2);
@@ -275,6 +275,7 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
             set_lane3<T>(u2, i, any_perp(su1));
             set_lane3<T>(v2, i, any_perp(sv1));
             if (WANT_S) { R::set(nt1, i, nb); R::set(nr2, i, 0.f); }
+            }
         }
     }
     o.u1 = u1; o.u2 = u2; o.u3 = cross<T>(u1, u2);

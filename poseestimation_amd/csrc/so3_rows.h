@@ -251,8 +251,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
+            for (int k = 0; k < NPL; ++k) {                 // (constant trip count: fully unrolled without a pragma)
                 I0::to_lds(slot[k], in0[k], lane);
                 if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
                 if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, in2[k], lane);

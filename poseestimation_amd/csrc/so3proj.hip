@@ -923,7 +923,7 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
     const int64_t nunits = stream_units(B, {R1, R2, theta});
     if (nunits > 0) {
         so3::OpGeodesic op; op.in0 = R1; op.in1 = R2; op.theta = theta;
-        launch_rows<2, 4, 256>(op, nunits, s);
+        launch_rows<2, 3, 256>(op, nunits, s);
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
