@@ -103,6 +103,14 @@ int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, dou
 int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count,
                     int32_t *range_flag, int radians, int64_t B, void *stream);
 
+/* K1 + K4 fused: theta_b = angle(proj(M_b), Rtrue_b), R not materialised unless requested -- the evaluation step
+ * `angle_error(func[rot_rep](out), R).mean()` of 3D-Pose/main.py:60-62,110-112 and UPNA/main.py:54-57 in one
+ * launch reading 72 B per row.  deg / sum_count / range_flag / radians as in so3_angle_error; R optional
+ * (required only when B is not a multiple of 64 or a pointer is not 16-byte aligned: the tail then runs as
+ * K1 followed by K4 and needs the buffer). */
+int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                int32_t *range_flag, int radians, int64_t B, void *stream);
+
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
  * point_cloud/main.py:43-57). */

@@ -8,6 +8,7 @@ from .rotation_representation import (  # noqa: F401
     compute_rotation_matrix_from_ortho6d,
     frobenius_head,
     get_sampled_rotation_matrices_by_axisAngle,
+    head_angle_error,
     kabsch_rotation,
     kabsch_rotation_synthetic,
     loss_frobenius,
@@ -24,6 +25,7 @@ __all__ = [
     "compute_rotation_matrix_from_ortho6d",
     "loss_frobenius",
     "frobenius_head",
+    "head_angle_error",
     "kabsch_rotation",
     "kabsch_rotation_synthetic",
     "get_sampled_rotation_matrices_by_axisAngle",

@@ -26,6 +26,7 @@ SYMBOLS = {
     "so3_frob_fwd_bwd_bf16": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
     "so3_frob_loss_f32": (_INT, [_P, _P, _P, _P, _I64, _P]),
     "so3_angle_error": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
+    "so3_project_angle_error_f32": (_INT, [_P, _P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_se3_update_f32": (_INT, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),
     "so3_se3_update_bwd_f32": (_INT, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),

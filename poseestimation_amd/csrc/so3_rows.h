@@ -443,6 +443,48 @@ struct OpAngle : OpBase {
     }
 };
 
+// K1 + K4 fused: theta_b = angle(proj(M_b), T_b) without materialising R (72 B read per row, nothing written
+// unless the per-row angles or R are requested).  The evaluation step of the reference,
+// `angle_error(func[rot_rep](out), R).mean()` (3D-Pose/main.py:60-62,110-112), in one launch.
+template <int M_BYTES, bool WANT_R, bool WANT_DEG, bool WANT_SUM>
+struct OpProjectAngle : OpBase {
+    static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_R ? 4 : 0, kOut1 = 0;
+    static constexpr bool kReduce = true;
+    double *deg = nullptr, *sum_count = nullptr;
+    int32_t *range_flag = nullptr;
+    double unit_scale = 1.0;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpProjectAngle> &rows, RowCtx<NPL> &ctx) const {
+        T r[9];
+        const auto f = signed_svd<false, T>(rows.a);
+        rotation_from(f, r);
+        if (WANT_R) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            double tr = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(Tr<T>::get(r[i], k)), static_cast<double>(Tr<T>::get(rows.b[i], k)), tr);
+            const double c_raw = (tr - 1.0) * 0.5;
+            if (ctx.exists[k]) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
+            double c = fmin(fmax(c_raw, -1.0), 1.0);
+            if (c_raw != c_raw) c = c_raw;
+            const double ang = acos(c) * unit_scale;
+            if (WANT_DEG) {
+                const u32x2 bits = __builtin_bit_cast(u32x2, ang);
+                __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc<8>(deg, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane * 8, 0, 0);
+            }
+            if (WANT_SUM && ctx.exists[k]) ctx.acc += ang;
+        }
+    }
+    __device__ __forceinline__ void finish(double total, bool any_flag) const {
+        if (WANT_SUM) atomicAdd(sum_count, total);
+        if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
+    }
+};
+
 // K4': float32 radians, tr(m1 m2^T), hard clamp (rotation_representation.py:209-227).
 struct OpGeodesic : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 0, kOut1 = 0;

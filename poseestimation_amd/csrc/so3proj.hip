@@ -915,6 +915,42 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
     return check_launch("so3_angle_error");
 }
 
+int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                                int radians, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_angle_error_f32: B");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    if (B == 0) return check_launch("so3_project_angle_error_f32");
+    SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_project_angle_error_f32: null pointer");
+    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
+    const int64_t nunits = stream_units(B, {M, Rtrue, R, deg});
+    if (nunits > 0) {
+#define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
+                                 op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; launch_rows<2, 2, 512>(op, nunits, s); } while (0)
+#define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true); else if (deg) SLAUNCH(WR, true, false); else if (sum_count) SLAUNCH(WR, false, true); else SLAUNCH(WR, false, false); } while (0)
+        if (R) PICKR(true); else PICKR(false);
+#undef PICKR
+#undef SLAUNCH
+    }
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        // remainder / unaligned input: the two-kernel spelling through a temporary-free path is not possible without
+        // scratch, so the caller-provided R (or, if absent, the tail of `deg`) would be needed; instead run the tile
+        // kernels on the tail with R required.
+        SO3_CHECK_ARGS(R != nullptr, "so3_project_angle_error_f32: a < 64-row remainder or unaligned input needs the R buffer");
+        const float *Mt = M + done * 9, *Tt = Rtrue + done * 9;
+        float *Rt = R + done * 9;
+        double *dg = advance(deg, done);
+        const dim3 grid(grid_for(rest)), block(kBlock);
+        if (aligned16(Mt) && aligned16(Rt)) hipLaunchKernelGGL((k_project_fwd<false, true, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
+        else hipLaunchKernelGGL((k_project_fwd<false, false, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
+#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_error<false, WD, WS>), grid, block, 0, s, Rt, Tt, dg, sum_count, range_flag, unit, rest)
+        if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
+#undef LAUNCH
+    }
+    return check_launch("so3_project_angle_error_f32");
+}
+
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_geodesic_f32: B");
     if (B == 0) return 0;

@@ -180,6 +180,37 @@ def angle_error_sum_count(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = 
     return sc
 
 
+def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none", check: bool = True, return_rotation: bool = False):
+    """Fused `angle_error(symmetric_orthogonalization(x), R_true)` (3D-Pose/main.py:60-62): one launch that reads
+    x and R_true (72 B per row) and writes only what is asked for.
+
+    reduce="none": (B,) float64 degrees;  reduce="mean": 0-dim float64 mean;  reduce="sum_count": the (sum, count)
+    pair for a multi-GPU all-reduce.  return_rotation=True also returns R.  Not differentiable (evaluation path)."""
+    dev = _require_device(x, R_true)
+    m = _head_input(x.detach())
+    if m.dtype != torch.float32:
+        m = m.float()
+    t = _f32_blocks(R_true.detach())
+    n = m.shape[0]
+    if t.shape[0] != n:
+        raise RuntimeError(f"head_angle_error: {n} predictions vs {t.shape[0]} targets")
+    want_deg = reduce == "none"
+    need_r = return_rotation or (n % 64 != 0)
+    r = torch.empty((n, 3, 3), dtype=torch.float32, device=dev) if need_r else None
+    deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
+    sc = None if want_deg else torch.empty((2,), dtype=torch.float64, device=dev)
+    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_project_angle_error_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
+                   "so3_project_angle_error_f32")
+    if check and int(flag.item()) != 0:
+        raise ValueError(_RANGE_MSG)
+    out = deg if want_deg else (sc if reduce == "sum_count" else sc[0] / sc[1])
+    if reduce not in ("none", "mean", "sum_count"):
+        raise ValueError("reduce must be 'none', 'mean' or 'sum_count'")
+    return (out, r) if return_rotation else out
+
+
 def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
     """Geodesic distance in radians, float32, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,)."""
     dev = _require_device(m1, m2)

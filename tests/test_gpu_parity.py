@@ -603,3 +603,27 @@ def test_g9_sampler_kernel_and_synthesised_kabsch(rr, c_oracle):
     rg = rr.get_sampled_rotation_matrices_by_axisAngle(2000, DEV)
     q = torch.bmm(p, rg.transpose(1, 2))
     assert (rr.kabsch_rotation_synthetic(p, rg) - rr.kabsch_rotation(p, q)).abs().max().item() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# K1 + K4 fused (evaluation step, 3D-Pose/main.py:60-62): no rotation written
+# ------------------------------------------------------------------------------------------------
+def test_fused_head_angle_error_matches_two_kernel_path(rr):
+    g = load_golden("g6_stats_1m.npz")
+    n = int(g["n"])
+    torch.manual_seed(int(g["seed_x"]))
+    x = torch.randn(n, 9).to(DEV)
+    torch.manual_seed(int(g["seed_t"]))
+    t = rr.symmetric_orthogonalization(torch.randn(n, 9).to(DEV))
+    deg = rr.head_angle_error(x, t)                                          # (B,) degrees, R never written
+    two = rr.angle_error(rr.symmetric_orthogonalization(x), t)
+    assert (deg - two).abs().max().item() < 1e-9
+    mean = rr.head_angle_error(x, t, reduce="mean").item()
+    assert abs(mean - float(g["mean_angle_deg"])) < 1e-4                      # the BASELINE parity metric, one launch
+    sc = rr.head_angle_error(x, t, reduce="sum_count")
+    assert sc[1].item() == n and abs(sc[0].item() / n - mean) < 1e-12
+    d2, r = rr.head_angle_error(x[:1000], t[:1000], return_rotation=True)      # ragged size: tail through K1 + K4
+    assert (d2 - two[:1000]).abs().max().item() < 1e-9
+    assert (r - rr.symmetric_orthogonalization(x[:1000])).abs().max().item() == 0
+    with pytest.raises(ValueError, match="angle out of range"):
+        rr.head_angle_error(x[:128], 1.7 * t[:128])

@@ -52,6 +52,7 @@ def main():
     timeit("K3' so3_frob_loss_f32 (loss + dRpred)", lambda i: lib.so3_frob_loss_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), n, st), 108 * n)
     timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
     timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_f32 (fused sum,count)", lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st), 72 * n)
     timeit("K4' so3_geodesic_f32", lambda i: lib.so3_geodesic_f32(p(r[i % NB]), p(rt[i % NB]), p(th), n, st), 76 * n)
     print("--- next rows (f1, f2, f3) at 1M rows ---")
     x6 = [torch.randn(n, 6, device=dev) for _ in range(NB)]
