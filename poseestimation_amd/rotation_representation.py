@@ -242,7 +242,7 @@ class _LossFrobenius(torch.autograd.Function):
             _lib.check(_lib.load().so3_frob_loss_f32(_ptr(p), _ptr(t), _ptr(g), _ptr(loss_sum), b, _stream(dev)), "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
-        return (loss_sum[0] / max(b, 1)).to(torch.float32)
+        return loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
 
     @staticmethod
     @once_differentiable
@@ -281,7 +281,7 @@ class _FrobeniusHead(torch.autograd.Function):
         fn = lib.so3_frob_fwd_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
         with torch.cuda.device(dev):
             _lib.check(fn(_ptr(m), _ptr(t), _ptr(r), _ptr(dm), _ptr(loss_sum), b, _stream(dev)), "so3_frob_fwd_bwd")
-        loss = (loss_sum[0] / max(b, 1)).to(torch.float32)
+        loss = loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
         ctx.dm = dm
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -296,6 +296,8 @@ class _FrobeniusHead(torch.autograd.Function):
         dm = ctx.dm
         if dm is None:
             return None, None, None
+        if dm.dtype == ctx.in_dtype:                      # one in-place scaling launch; the buffer is ours
+            return dm.mul_(grad_loss).view(ctx.in_shape), None, None
         return (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape), None, None
 
 
