@@ -141,6 +141,30 @@ int so3_se3_update_bwd_f32(const float *out12, const float *Tinit, const float *
 int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream);
 int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
 
+/* ---- next row f5: the remaining heads of the reference's dispatch tables -------------
+ * Model.func / Model.dimension (Comparison/models.py:18-19, point_cloud/model_fetch.py:153-154), func
+ * (3D-Pose/main.py:46,101) and transform_output (rotation_representation.py:323-324) map a key to a head; with
+ * these four plus the SVD and 6D heads above every key is served natively ("Direct" is a reshape).
+ *   quat     X B*4  (w,x,y,z) -> n = q / max(|q|, 1e-8) -> R(n)      rotation_representation.py:39-50, 137-171
+ *   euler    X B*3  R from (c1,s1)=e0, (c2,s2)=e2, (c3,s3)=e1         rotation_representation.py:92-113
+ *   ortho5d  X B*5  stereographic un-projection of X[2:5] * (1+sqrt2, 1+sqrt2, sqrt2), then the 6D head
+ *                                                                     rotation_representation.py:69-90, 118-134
+ *   expmap   X B*3  so(3) exponential map, theta = sqrt(max(|v|^2, 1e-4))   rotation_representation.py:245-275,
+ *                   reached as vec_3d_to_SO3 (:309-321, transform_output['3D'])
+ * Forward: R out B*9 float32.  Backward: G in B*9 float32 (dL/dR), dX out shaped like X (what the reference
+ * gets from autograd through the same formulas).  Degenerate input behaves like the reference's float32 graph
+ * (zero 5D tail or zero 6D halves: Inf/NaN), except that an exactly-zero quaternion gives the clamped
+ * gradient G-terms/1e-8 where autograd yields NaN.
+ */
+int so3_quat_fwd_f32(const float *X, float *R, int64_t B, void *stream);
+int so3_quat_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+int so3_euler_fwd_f32(const float *X, float *R, int64_t B, void *stream);
+int so3_euler_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+int so3_ortho5d_fwd_f32(const float *X, float *R, int64_t B, void *stream);
+int so3_ortho5d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+int so3_expmap_fwd_f32(const float *X, float *R, int64_t B, void *stream);
+int so3_expmap_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
+
 /* ---- next row: per-class evaluation statistics on K4's angles ----------------------
  * Replaces the host-side numpy block of 3D-Pose/test_per_class.py:174-216 (np.mean / np.median / np.std / np.max
  * and the accuracy thresholds (x < 30|15|7.5).sum()/len(x)), which the reference feeds one sample at a time.

@@ -25,6 +25,7 @@ Reference lines followed (all under /root/reference):
   6D Gram-Schmidt head (next row f2)   rotation_representation.py:21-36
   per-class statistics (next row f3)   3D-Pose/test_per_class.py:174-175,206-216
   SE(3) pose update (next row f1)      Iterative/utility.py:63-128
+  other heads (next row f5)            rotation_representation.py:39-50,69-171,245-321
 """
 from __future__ import annotations
 
@@ -294,6 +295,85 @@ def ortho6d_backward_np(poses, g):
     gb = np.cross(gw, x)
     ga = (gxt - x * (x * gxt).sum(1, keepdims=True)) / na            # x = a/|a|
     return np.concatenate((ga, gb), 1)
+
+
+# --------------------------------------------------------------------------------------------
+# next row f5: the other heads of the dispatch tables.  Restated op for op with torch (float64 by default) so
+# that the backward is autograd through the same graph the reference differentiates -- no closed forms here.
+# --------------------------------------------------------------------------------------------
+def quat_torch(q):
+    """(B,4) (w,x,y,z) -> (B,3,3); rotation_representation.py:39-50 (normalize_vector) and :137-171."""
+    mag = torch.sqrt(q.pow(2).sum(1))                                            # :46
+    mag = torch.max(mag, torch.tensor([1e-8], dtype=q.dtype))                    # :47
+    n = q / mag.view(-1, 1)                                                      # :48-49
+    w, x, y, z = n[:, 0:1], n[:, 1:2], n[:, 2:3], n[:, 3:4]                      # :148-151
+    xx, yy, zz, xy, xz, yz, xw, yw, zw = x * x, y * y, z * z, x * y, x * z, y * z, x * w, y * w, z * w   # :154-162
+    r0 = torch.cat((1 - 2 * yy - 2 * zz, 2 * xy - 2 * zw, 2 * xz + 2 * yw), 1)    # :164
+    r1 = torch.cat((2 * xy + 2 * zw, 1 - 2 * xx - 2 * zz, 2 * yz - 2 * xw), 1)    # :165
+    r2 = torch.cat((2 * xz - 2 * yw, 2 * yz + 2 * xw, 1 - 2 * xx - 2 * yy), 1)    # :166
+    return torch.stack((r0, r1, r2), 1)                                          # :168
+
+
+def euler_torch(e):
+    """(B,3) -> (B,3,3); rotation_representation.py:92-113 (note: c2,s2 come from e[:,2] and c3,s3 from e[:,1])."""
+    c1, s1 = torch.cos(e[:, 0:1]), torch.sin(e[:, 0:1])                          # :101-102
+    c2, s2 = torch.cos(e[:, 2:3]), torch.sin(e[:, 2:3])                          # :103-104
+    c3, s3 = torch.cos(e[:, 1:2]), torch.sin(e[:, 1:2])                          # :105-106
+    r0 = torch.cat((c2 * c3, -s2, c2 * s3), 1)                                   # :108
+    r1 = torch.cat((c1 * s2 * c3 + s1 * s3, c1 * c2, c1 * s2 * s3 - s1 * c3), 1)  # :109
+    r2 = torch.cat((s1 * s2 * c3 - c1 * s3, s1 * c2, s1 * s2 * s3 + c1 * c3), 1)  # :110
+    return torch.stack((r0, r1, r2), 1)                                          # :112
+
+
+def ortho6d_torch(p):
+    a, b = p[..., 0:3], p[..., 3:6]
+    x = a / torch.norm(a, p=2, dim=-1, keepdim=True)
+    z = torch.cross(x, b, dim=-1)
+    z = z / torch.norm(z, p=2, dim=-1, keepdim=True)
+    y = torch.cross(z, x, dim=-1)
+    return torch.stack((x, y, z), -1)
+
+
+def ortho5d_torch(a):
+    """(B,5) -> (B,3,3); rotation_representation.py:118-134 with stereographic_unproject(axis=0) of :69-90."""
+    scale = torch.tensor([np.sqrt(2) + 1, np.sqrt(2) + 1, np.sqrt(2)], dtype=a.dtype).view(1, 3)   # :126-127
+    v = a[:, 2:5] * scale
+    s2 = v.pow(2).sum(1)                                                         # :81
+    unproj = 2 * v / (s2 + 1).view(-1, 1)                                        # :83
+    u = torch.cat((((s2 - 1) / (s2 + 1)).view(-1, 1), unproj), 1)                # :84-87 with axis = 0
+    norm = torch.sqrt(u[:, 1:].pow(2).sum(1))                                    # :130
+    u = u / norm.view(-1, 1)                                                     # :131
+    return ortho6d_torch(torch.cat((a[:, 0:2], u), 1))                           # :132-133
+
+
+def expmap_torch(v, eps=1e-4):
+    """(B,3) -> (B,3,3); rotation_representation.py:245-275 (so3_exp_map) with hat() of :278-306."""
+    nrms = (v * v).sum(1)                                                        # :258
+    ang = torch.clamp(nrms, eps).sqrt()                                          # :260
+    inv = 1.0 / ang                                                              # :261
+    fac1 = inv * ang.sin()                                                       # :262
+    fac2 = inv * inv * (1.0 - ang.cos())                                         # :263
+    x, y, z = v.unbind(1)
+    zero = torch.zeros_like(x)
+    k = torch.stack((torch.stack((zero, -z, y), 1), torch.stack((z, zero, -x), 1), torch.stack((-y, x, zero), 1)), 1)   # :299-305
+    return fac1[:, None, None] * k + fac2[:, None, None] * torch.bmm(k, k) + torch.eye(3, dtype=v.dtype)[None]   # :267-273
+
+
+_HEADS_TORCH = {"quat": (4, quat_torch), "euler": (3, euler_torch), "ortho5d": (5, ortho5d_torch), "expmap": (3, expmap_torch)}
+
+
+def head_np(name, x):
+    """Head `name` ('quat' | 'euler' | 'ortho5d' | 'expmap') in float64 -> (B,3,3) numpy."""
+    n, fn = _HEADS_TORCH[name]
+    return fn(torch.as_tensor(np.asarray(x, np.float64).reshape(-1, n))).numpy()
+
+
+def head_backward_np(name, x, g):
+    """dL/dx for upstream G = dL/dR: autograd through the float64 restatement above."""
+    n, fn = _HEADS_TORCH[name]
+    xt = torch.as_tensor(np.asarray(x, np.float64).reshape(-1, n)).clone().requires_grad_(True)
+    fn(xt).backward(torch.as_tensor(np.asarray(g, np.float64).reshape(-1, 3, 3)))
+    return xt.grad.numpy()
 
 
 # --------------------------------------------------------------------------------------------

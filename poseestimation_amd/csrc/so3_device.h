@@ -68,6 +68,8 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }                     // full-range libm forms
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
     // exponent that brings x into [0.5, 1), clamped so that 2^e stays finite (denormal input)
     static __device__ __forceinline__ int neg_frexp_exp(float x) { return min(-__builtin_amdgcn_frexp_expf(x), 126); }
     static __device__ __forceinline__ float ldexp(float x, int e) { return ldexpf(x, e); }
@@ -92,6 +94,8 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
     static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; }
     static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+    static __device__ __forceinline__ f32x2 sin(f32x2 x) { return f32x2{sinf(x.x), sinf(x.y)}; }
+    static __device__ __forceinline__ f32x2 cos(f32x2 x) { return f32x2{cosf(x.x), cosf(x.y)}; }
     static __device__ __forceinline__ i32x2 neg_frexp_exp(f32x2 x) {
         return i32x2{min(-__builtin_amdgcn_frexp_expf(x.x), 126), min(-__builtin_amdgcn_frexp_expf(x.y), 126)};
     }

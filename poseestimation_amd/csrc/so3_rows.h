@@ -512,22 +512,44 @@ struct OpGeodesic : OpBase {
 
 // ---- next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36) --------------------------------
 // x = a/|a|,  z = (x x b)/|x x b|,  y = z x x,  R = [x y z] (columns); a, b = the two halves of the 6-vector.
+template <class T> __device__ __forceinline__ void ortho6d_forward(V3<T> a, V3<T> b, T (&r)[9]) {
+    typedef Tr<T> R;
+    const V3<T> x = scale<T>(a, R::rsq(dot(a, a)));
+    const V3<T> w = cross<T>(x, b);
+    const V3<T> z = scale<T>(w, R::rsq(dot(w, w)));
+    const V3<T> y = cross<T>(z, x);
+    r[0] = x.x; r[1] = y.x; r[2] = z.x;
+    r[3] = x.y; r[4] = y.y; r[5] = z.y;
+    r[6] = x.z; r[7] = y.z; r[8] = z.z;
+}
+// G = dL/dR (row-major)  ->  dL/da, dL/db
+template <class T> __device__ __forceinline__ void ortho6d_backward(V3<T> a, V3<T> b, const T (&g)[9], V3<T> &ga, V3<T> &gb) {
+    typedef Tr<T> R;
+    const T ia = R::rsq(dot(a, a));
+    const V3<T> x = scale<T>(a, ia);
+    const V3<T> w = cross<T>(x, b);
+    const T iw = R::rsq(dot(w, w));
+    const V3<T> z = scale<T>(w, iw);
+    const V3<T> gx = mk<T>(g[0], g[3], g[6]), gy = mk<T>(g[1], g[4], g[7]), gz = mk<T>(g[2], g[5], g[8]);   // columns of G
+    // y = z x x :  gz += x x gy ,  gx += gy x z
+    const V3<T> gzt = axpy<T>(R::splat(1.f), cross<T>(x, gy), gz);
+    V3<T> gxt = axpy<T>(R::splat(1.f), cross<T>(gy, z), gx);
+    // z = w/|w| :  gw = (gz - z (z.gz)) / |w|
+    const V3<T> gw = scale<T>(axpy<T>(-dot(z, gzt), z, gzt), iw);
+    // w = x x b :  gx += b x gw ,  gb = gw x x
+    gxt = axpy<T>(R::splat(1.f), cross<T>(b, gw), gxt);
+    gb = cross<T>(gw, x);
+    // x = a/|a| :  ga = (gx - x (x.gx)) / |a|
+    ga = scale<T>(axpy<T>(-dot(x, gxt), x, gxt), ia);
+}
+
 struct OpOrtho6d : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     static constexpr int kIn0N = 6;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpOrtho6d> &rows, RowCtx<NPL> &) const {
-        typedef Tr<T> R;
         const T (&p)[6] = rows.a;
-        T (&r)[9] = rows.o0;
-        const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
-        const V3<T> x = scale<T>(a, R::rsq(dot(a, a)));
-        const V3<T> w = cross<T>(x, b);
-        const V3<T> z = scale<T>(w, R::rsq(dot(w, w)));
-        const V3<T> y = cross<T>(z, x);
-        r[0] = x.x; r[1] = y.x; r[2] = z.x;
-        r[3] = x.y; r[4] = y.y; r[5] = z.y;
-        r[6] = x.z; r[7] = y.z; r[8] = z.z;
+        ortho6d_forward<T>(mk<T>(p[0], p[1], p[2]), mk<T>(p[3], p[4], p[5]), rows.o0);
     }
 };
 
@@ -537,29 +559,177 @@ struct OpOrtho6dBwd : OpBase {
     static constexpr int kIn0N = 6, kOut0N = 6;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpOrtho6dBwd> &rows, RowCtx<NPL> &) const {
-        typedef Tr<T> R;
         const T (&p)[6] = rows.a;
-        const T (&g)[9] = rows.b;
         T (&dp)[6] = rows.o0;
-        const V3<T> a = mk<T>(p[0], p[1], p[2]), b = mk<T>(p[3], p[4], p[5]);
-        const T ia = R::rsq(dot(a, a));
-        const V3<T> x = scale<T>(a, ia);
-        const V3<T> w = cross<T>(x, b);
-        const T iw = R::rsq(dot(w, w));
-        const V3<T> z = scale<T>(w, iw);
-        const V3<T> gx = mk<T>(g[0], g[3], g[6]), gy = mk<T>(g[1], g[4], g[7]), gz = mk<T>(g[2], g[5], g[8]);   // columns of G
-        // y = z x x :  gz += x x gy ,  gx += gy x z
-        const V3<T> gzt = axpy<T>(R::splat(1.f), cross<T>(x, gy), gz);
-        V3<T> gxt = axpy<T>(R::splat(1.f), cross<T>(gy, z), gx);
-        // z = w/|w| :  gw = (gz - z (z.gz)) / |w|
-        const V3<T> gw = scale<T>(axpy<T>(-dot(z, gzt), z, gzt), iw);
-        // w = x x b :  gx += b x gw ,  gb = gw x x
-        gxt = axpy<T>(R::splat(1.f), cross<T>(b, gw), gxt);
-        const V3<T> gb = cross<T>(gw, x);
-        // x = a/|a| :  ga = (gx - x (x.gx)) / |a|
-        const V3<T> ga = scale<T>(axpy<T>(-dot(x, gxt), x, gxt), ia);
+        V3<T> ga, gb;
+        ortho6d_backward<T>(mk<T>(p[0], p[1], p[2]), mk<T>(p[3], p[4], p[5]), rows.b, ga, gb);
         dp[0] = ga.x; dp[1] = ga.y; dp[2] = ga.z;
         dp[3] = gb.x; dp[4] = gb.y; dp[5] = gb.z;
+    }
+};
+
+// ---- next row f5: the other heads of the reference's dispatch tables (Comparison/models.py:18-19,
+// 3D-Pose/main.py:46, rotation_representation.py:323-324), forward and backward ----------------------------------
+// Every *Bwd operation: in0 = the head's input (B,N), in1 = G = dL/dR (B,9), out0 = dL/dinput (B,N).
+
+// 'Quat': q = (w,x,y,z) -> n = q / max(|q|, 1e-8) -> R(n)   (rotation_representation.py:39-50, 137-171)
+constexpr float kQuatMinNorm = 1e-8f;
+template <bool BWD> struct OpQuat : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = BWD ? 4 : 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 4, kOut0N = BWD ? 4 : 9;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpQuat> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&q)[4] = rows.a;
+        const T n2 = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
+        const T mag = R::max(R::sqrt(n2), R::splat(kQuatMinNorm));
+        const T im = R::rcp(mag);
+        const T w = q[0] * im, x = q[1] * im, y = q[2] * im, z = q[3] * im;
+        const T two = R::splat(2.f);
+        if constexpr (!BWD) {
+            T (&r)[9] = rows.o0;
+            const T xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, xw = x * w, yw = y * w, zw = z * w;
+            const T one = R::splat(1.f);
+            r[0] = one - two * (yy + zz); r[1] = two * (xy - zw);       r[2] = two * (xz + yw);
+            r[3] = two * (xy + zw);       r[4] = one - two * (xx + zz); r[5] = two * (yz - xw);
+            r[6] = two * (xz - yw);       r[7] = two * (yz + xw);       r[8] = one - two * (xx + yy);
+        } else {
+            const T (&g)[9] = rows.b;
+            T (&dq)[4] = rows.o0;
+            // dL/dn from the nine polynomial entries
+            const T s12 = g[1] + g[3], s02 = g[2] + g[6], s21 = g[5] + g[7];      // symmetric parts
+            const T a0 = g[7] - g[5], a1 = g[2] - g[6], a2 = g[3] - g[1];          // antisymmetric parts
+            const T gw = two * R::fma(x, a0, R::fma(y, a1, z * a2));
+            const T gx = two * R::fma(w, a0, R::fma(y, s12, R::fma(z, s02, -two * x * (g[4] + g[8]))));
+            const T gy = two * R::fma(w, a1, R::fma(x, s12, R::fma(z, s21, -two * y * (g[0] + g[8]))));
+            const T gz = two * R::fma(w, a2, R::fma(x, s02, R::fma(y, s21, -two * z * (g[0] + g[4]))));
+            // n = q/|q| (or q/1e-8 when clamped: the divisor is then a constant)
+            const typename R::mask clamped = R::le(R::sqrt(n2), R::splat(kQuatMinNorm));
+            const T proj = R::sel(clamped, R::splat(0.f), R::fma(w, gw, R::fma(x, gx, R::fma(y, gy, z * gz))));
+            dq[0] = R::fma(-proj, w, gw) * im;
+            dq[1] = R::fma(-proj, x, gx) * im;
+            dq[2] = R::fma(-proj, y, gy) * im;
+            dq[3] = R::fma(-proj, z, gz) * im;
+        }
+    }
+};
+
+// 'Euler': angles (e0, e1, e2) -> R, with c1,s1 of e0; c2,s2 of e2; c3,s3 of e1   (rotation_representation.py:92-113)
+template <bool BWD> struct OpEuler : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = BWD ? 4 : 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 3, kOut0N = BWD ? 3 : 9;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpEuler> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&e)[3] = rows.a;
+        const T c1 = R::cos(e[0]), s1 = R::sin(e[0]), c2 = R::cos(e[2]), s2 = R::sin(e[2]), c3 = R::cos(e[1]), s3 = R::sin(e[1]);
+        T r[9];
+        r[0] = c2 * c3;                     r[1] = -s2;     r[2] = c2 * s3;
+        r[3] = R::fma(c1 * s2, c3, s1 * s3); r[4] = c1 * c2; r[5] = R::fma(c1 * s2, s3, -(s1 * c3));
+        r[6] = R::fma(s1 * s2, c3, -(c1 * s3)); r[7] = s1 * c2; r[8] = R::fma(s1 * s2, s3, c1 * c3);
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];
+        } else {
+            const T (&g)[9] = rows.b;
+            T (&de)[3] = rows.o0;
+            // d/de0: row2' = -row3, row3' = row2.   d/de1: column0' = -column2, column2' = column0.
+            de[0] = R::fma(g[8], r[5], R::fma(g[7], r[4], g[6] * r[3])) - R::fma(g[5], r[8], R::fma(g[4], r[7], g[3] * r[6]));
+            de[1] = R::fma(g[8], r[6], R::fma(g[5], r[3], g[2] * r[0])) - R::fma(g[6], r[8], R::fma(g[3], r[5], g[0] * r[2]));
+            // d/de2 (c2' = -s2, s2' = c2)
+            const T d0 = -(s2 * c3), d1 = -c2, d2 = -(s2 * s3);
+            const T d3 = c1 * c2 * c3, d4 = -(c1 * s2), d5 = c1 * c2 * s3;
+            const T d6 = s1 * c2 * c3, d7 = -(s1 * s2), d8 = s1 * c2 * s3;
+            de[2] = R::fma(g[0], d0, R::fma(g[1], d1, R::fma(g[2], d2, R::fma(g[3], d3, R::fma(g[4], d4,
+                    R::fma(g[5], d5, R::fma(g[6], d6, R::fma(g[7], d7, g[8] * d8))))))));
+        }
+    }
+};
+
+// '5D': a -> 6D through the stereographic un-projection of a[2:5] * (1+sqrt2, 1+sqrt2, sqrt2), then the 6D head
+// (rotation_representation.py:69-90, 118-134).  With v = a[2:5] * scale, s = |v|^2 the reference's normalised
+// 4-vector u/|u[1:]| is ((s-1)/(2|v|), v/|v|):  x_raw = (a0, a1, (s-1)/(2|v|)),  y_raw = v/|v|.
+template <bool BWD> struct OpOrtho5d : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = BWD ? 4 : 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 5, kOut0N = BWD ? 5 : 9;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpOrtho5d> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&a)[5] = rows.a;
+        const T k0 = R::splat(2.41421356237309505f), k2 = R::splat(1.41421356237309505f);
+        const V3<T> v = mk<T>(a[2] * k0, a[3] * k0, a[4] * k2);
+        const T s = dot(v, v);
+        const T ir = R::rsq(s);
+        const V3<T> vh = scale<T>(v, ir);
+        const V3<T> xr = mk<T>(a[0], a[1], (s - R::splat(1.f)) * R::splat(0.5f) * ir);
+        if constexpr (!BWD) {
+            ortho6d_forward<T>(xr, vh, rows.o0);
+        } else {
+            T (&da)[5] = rows.o0;
+            V3<T> gx, gy;
+            ortho6d_backward<T>(xr, vh, rows.b, gx, gy);
+            // d x_raw.z / dv = v (s+1) / (2 s |v|) ;  y_raw = v/|v|
+            const T kx = gx.z * (s + R::splat(1.f)) * R::splat(0.5f) * ir * ir * ir;
+            const V3<T> gv = axpy<T>(kx, v, scale<T>(axpy<T>(-dot(vh, gy), vh, gy), ir));
+            da[0] = gx.x; da[1] = gx.y;
+            da[2] = gv.x * k0; da[3] = gv.y * k0; da[4] = gv.z * k2;
+        }
+    }
+};
+
+// '3D': the so(3) exponential map with PyTorch3D's clamp, theta = sqrt(max(|v|^2, 1e-4))
+// (rotation_representation.py:245-275, 278-321):  R = I + (sin t / t) K + ((1 - cos t) / t^2) K^2,  K = hat(v),
+// K^2 = v v^T - |v|^2 I  (the un-clamped |v|^2, as the reference's bmm gives).
+constexpr float kExpMapEps = 1e-4f;
+template <bool BWD> struct OpExpMap : OpBase {
+    static constexpr int kIn0 = 4, kIn1 = BWD ? 4 : 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kIn0N = 3, kOut0N = BWD ? 3 : 9;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpExpMap> &rows, RowCtx<NPL> &) const {
+        typedef Tr<T> R;
+        const T (&p)[3] = rows.a;
+        const V3<T> v = mk<T>(p[0], p[1], p[2]);
+        const T nrm = dot(v, v);
+        const T t2 = R::max(nrm, R::splat(kExpMapEps));
+        const T it = R::rsq(t2);
+        const T t = t2 * it;
+        const T st = R::sin(t), sh = R::sin(t * R::splat(0.5f));
+        const T f1 = st * it;
+        const T f2 = R::splat(2.f) * sh * sh * it * it;              // (1 - cos t)/t^2 without the cancellation
+        if constexpr (!BWD) {
+            T (&r)[9] = rows.o0;
+            const T one = R::splat(1.f);
+            const T xy = f2 * v.x * v.y, xz = f2 * v.x * v.z, yz = f2 * v.y * v.z;
+            r[0] = R::fma(f2, R::fma(v.x, v.x, -nrm), one); r[1] = R::fma(-f1, v.z, xy); r[2] = R::fma(f1, v.y, xz);
+            r[3] = R::fma(f1, v.z, xy); r[4] = R::fma(f2, R::fma(v.y, v.y, -nrm), one); r[5] = R::fma(-f1, v.x, yz);
+            r[6] = R::fma(-f1, v.y, xz); r[7] = R::fma(f1, v.x, yz); r[8] = R::fma(f2, R::fma(v.z, v.z, -nrm), one);
+        } else {
+            const T (&g)[9] = rows.b;
+            T (&dv)[3] = rows.o0;
+            const V3<T> a = mk<T>(g[7] - g[5], g[2] - g[6], g[3] - g[1]);                  // <G, dK/dv>
+            const T tr = g[0] + g[4] + g[8];
+            const V3<T> sv = mk<T>(R::fma(g[1] + g[3], v.y, R::fma(g[2] + g[6], v.z, (g[0] + g[0]) * v.x)),
+                                   R::fma(g[1] + g[3], v.x, R::fma(g[5] + g[7], v.z, (g[4] + g[4]) * v.y)),
+                                   R::fma(g[2] + g[6], v.x, R::fma(g[5] + g[7], v.y, (g[8] + g[8]) * v.z)));   // (G + G^T) v
+            const T df1 = dot(v, a);                                                       // dL/dfac1 = <G, K>
+            const T df2 = R::fma(R::splat(0.5f), dot(v, sv), -(nrm * tr));                 // dL/dfac2 = <G, K^2>
+            // (dfac/dtheta)/theta: closed forms cancel badly for small theta -> series below theta = 1
+            const T ct = R::cos(t);
+            const T it3 = it * it * it;
+            const T a1c = R::fma(t, ct, -st) * it3;
+            const T a2c = R::fma(t, st, -(R::splat(4.f) * sh * sh)) * it3 * it;
+            const T a1s = R::fma(t2, R::fma(t2, R::fma(t2, R::fma(t2, R::splat(-1.f / 3991680.f), R::splat(1.f / 45360.f)),
+                                 R::splat(-1.f / 840.f)), R::splat(1.f / 30.f)), R::splat(-1.f / 3.f));
+            const T a2s = R::fma(t2, R::fma(t2, R::fma(t2, R::fma(t2, R::splat(-1.f / 47900160.f), R::splat(1.f / 453600.f)),
+                                 R::splat(-1.f / 6720.f)), R::splat(1.f / 180.f)), R::splat(-1.f / 12.f));
+            const typename R::mask small = R::le(t2, R::splat(1.f));
+            const T a1 = R::sel(small, a1s, a1c), a2 = R::sel(small, a2s, a2c);
+            const T via_theta = R::sel(R::ge(nrm, R::splat(kExpMapEps)), R::fma(df1, a1, df2 * a2), R::splat(0.f));
+            const T m2 = -(tr + tr);
+            dv[0] = R::fma(via_theta, v.x, R::fma(f1, a.x, f2 * R::fma(m2, v.x, sv.x)));
+            dv[1] = R::fma(via_theta, v.y, R::fma(f1, a.y, f2 * R::fma(m2, v.y, sv.y)));
+            dv[2] = R::fma(via_theta, v.z, R::fma(f1, a.z, f2 * R::fma(m2, v.z, sv.z)));
+        }
     }
 };
 

@@ -557,6 +557,27 @@ __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict
     }
 }
 
+// ---- any float32 row operation, one row per thread: remainder (< 64 rows) and unaligned input of the streaming kernels
+template <class Op>
+__global__ __launch_bounds__(kBlock) void k_op_rows(Op op, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= B) return;
+    so3::RowCtx<1> ctx{};
+    so3::Rows<float, Op> rows;
+    const float *a = static_cast<const float *>(op.in0) + row * Op::kIn0N;
+#pragma unroll
+    for (int i = 0; i < Op::kIn0N; ++i) rows.a[i] = a[i];
+    if constexpr (Op::kIn1 != 0) {
+        const float *b = static_cast<const float *>(op.in1) + row * Op::kIn1N;
+#pragma unroll
+        for (int i = 0; i < Op::kIn1N; ++i) rows.b[i] = b[i];
+    }
+    op.template compute<float, 1>(rows, ctx);
+    float *o = static_cast<float *>(op.out0) + row * Op::kOut0N;
+#pragma unroll
+    for (int i = 0; i < Op::kOut0N; ++i) o[i] = rows.o0[i];
+}
+
 // ---- SE(3) update, one row per thread: remainder and unaligned input of the streaming kernels -----------------
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ out12, const float *__restrict__ Tinit,
@@ -730,6 +751,23 @@ inline int64_t stream_units(int64_t B, std::initializer_list<const void *> ptrs)
     for (const void *p : ptrs)
         if (p != nullptr && !aligned16(p)) return 0;
     return B / so3::kUnitRows;
+}
+
+// A float32 row operation with one or two inputs and one output: whole units on the streaming engine, the rest
+// (and everything when a pointer is not 16-byte aligned) one row per thread.
+template <int NPL, int WPS, int BLOCK, class Op>
+int run_row_op(Op op, int64_t B, hipStream_t s, const char *what) {
+    const int64_t nunits = stream_units(B, {op.in0, op.in1, op.out0});
+    if (nunits > 0) launch_rows<NPL, WPS, BLOCK>(op, nunits, s);
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        Op t = op;
+        t.in0 = static_cast<const float *>(op.in0) + done * Op::kIn0N;
+        if (Op::kIn1 != 0) t.in1 = static_cast<const float *>(op.in1) + done * Op::kIn1N;
+        t.out0 = static_cast<float *>(op.out0) + done * Op::kOut0N;
+        hipLaunchKernelGGL((k_op_rows<Op>), dim3(grid_for(rest)), dim3(kBlock), 0, s, t, rest);
+    }
+    return check_launch(what);
 }
 
 template <class T> inline T *advance(T *p, int64_t elems) { return p ? p + elems : nullptr; }
@@ -994,6 +1032,28 @@ int so3_ortho6d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, vo
     if (rest > 0) hipLaunchKernelGGL((k_ortho6d_rows<true>), dim3(grid_for(rest)), dim3(kBlock), 0, s, X + done * 6, G + done * 9, dX + done * 6, rest);
     return check_launch("so3_ortho6d_bwd_f32");
 }
+
+// The other heads of the reference's dispatch tables (include/so3proj.h, "next row f5").
+#define SO3_DEFINE_HEAD(NAME, OP)                                                                                   \
+    int so3_##NAME##_fwd_f32(const float *X, float *R, int64_t B, void *stream) {                                    \
+        SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_" #NAME "_fwd_f32: B");                                        \
+        if (B == 0) return 0;                                                                                        \
+        SO3_CHECK_ARGS(X != nullptr && R != nullptr, "so3_" #NAME "_fwd_f32: null pointer");                         \
+        so3::OP<false> op; op.in0 = X; op.out0 = R;                                                                  \
+        return run_row_op<1, 6, 256>(op, B, static_cast<hipStream_t>(stream), "so3_" #NAME "_fwd_f32");              \
+    }                                                                                                                \
+    int so3_##NAME##_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream) {                   \
+        SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_" #NAME "_bwd_f32: B");                                        \
+        if (B == 0) return 0;                                                                                        \
+        SO3_CHECK_ARGS(X != nullptr && G != nullptr && dX != nullptr, "so3_" #NAME "_bwd_f32: null pointer");        \
+        so3::OP<true> op; op.in0 = X; op.in1 = G; op.out0 = dX;                                                      \
+        return run_row_op<1, 6, 256>(op, B, static_cast<hipStream_t>(stream), "so3_" #NAME "_bwd_f32");              \
+    }
+SO3_DEFINE_HEAD(quat, OpQuat)
+SO3_DEFINE_HEAD(euler, OpEuler)
+SO3_DEFINE_HEAD(ortho5d, OpOrtho5d)
+SO3_DEFINE_HEAD(expmap, OpExpMap)
+#undef SO3_DEFINE_HEAD
 
 size_t so3_angle_stats_workspace_bytes(void) { return sizeof(StatWork); }
 

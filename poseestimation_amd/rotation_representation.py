@@ -491,6 +491,90 @@ def compute_rotation_matrix_from_ortho6d(poses: torch.Tensor) -> torch.Tensor:
     return _Ortho6d.apply(poses)
 
 
-# Head dispatch table, keyed like the reference's (rotation_representation.py:323-324;
-# Comparison/models.py:18-19; 3D-Pose/main.py:46).  The SVD head is the scope of SURVEY.md section 8; '6D' is its next row f2.
-transform_output = {"SVD": (9, symmetric_orthogonalization), "6D": (6, compute_rotation_matrix_from_ortho6d)}
+# --------------------------------------------------------------------------------------------
+# next row f5: the other heads of the reference's dispatch tables
+# --------------------------------------------------------------------------------------------
+def _make_head(symbol: str, width: int):
+    """autograd.Function over so3_<symbol>_fwd_f32 / _bwd_f32 for a (B, width) -> (B, 3, 3) head."""
+
+    class _Head(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x_in):
+            dev = _require_device(x_in)
+            x = x_in.detach().contiguous().float()
+            b = x.shape[0]
+            r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(getattr(_lib.load(), "so3_%s_fwd_f32" % symbol)(_ptr(x), _ptr(r), b, _stream(dev)), "so3_%s_fwd_f32" % symbol)
+            ctx.save_for_backward(x)
+            ctx.in_dtype = x_in.dtype
+            return r
+
+        @staticmethod
+        @once_differentiable
+        def backward(ctx, grad_r):
+            (x,) = ctx.saved_tensors
+            dev = x.device
+            g = grad_r.reshape(-1, 9).contiguous().float()
+            dx = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                _lib.check(getattr(_lib.load(), "so3_%s_bwd_f32" % symbol)(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_%s_bwd_f32" % symbol)
+            return dx.to(ctx.in_dtype)
+
+    _Head.__name__ = "_Head_" + symbol
+    return _Head
+
+
+_Quat, _Euler, _Ortho5d, _ExpMap = (_make_head(sym, n) for sym, n in (("quat", 4), ("euler", 3), ("ortho5d", 5), ("expmap", 3)))
+
+
+def _batch_of(x: torch.Tensor, width: int, name: str) -> None:
+    if x.dim() != 2 or x.shape[1] != width:          # the reference indexes [:, k] and .view(batch, 1): 2-D input only
+        raise RuntimeError("%s expects a (batch, %d) tensor, got %s" % (name, width, tuple(x.shape)))
+
+
+def compute_rotation_matrix_from_quaternion(quaternion: torch.Tensor) -> torch.Tensor:
+    """(B,4) quaternion (w,x,y,z), normalised with max(|q|, 1e-8) -> (B,3,3); rotation_representation.py:137-171."""
+    _batch_of(quaternion, 4, "compute_rotation_matrix_from_quaternion")
+    return _Quat.apply(quaternion)
+
+
+def compute_rotation_matrix_from_euler(euler: torch.Tensor) -> torch.Tensor:
+    """(B,3) Euler angles -> (B,3,3) in the reference's convention (c2,s2 from column 2, c3,s3 from column 1);
+    rotation_representation.py:92-113."""
+    _batch_of(euler, 3, "compute_rotation_matrix_from_euler")
+    return _Euler.apply(euler)
+
+
+def compute_rotation_matrix_from_ortho5d(a: torch.Tensor) -> torch.Tensor:
+    """(B,5) -> (B,3,3): stereographic un-projection of a[:,2:5] to a unit 4-vector, then the 6D head;
+    rotation_representation.py:118-134."""
+    _batch_of(a, 5, "compute_rotation_matrix_from_ortho5d")
+    return _Ortho5d.apply(a)
+
+
+def so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001) -> torch.Tensor:
+    """so(3) exponential map with PyTorch3D's clamp; rotation_representation.py:245-275."""
+    if log_rot.dim() != 2 or log_rot.shape[1] != 3:
+        raise ValueError("Input tensor shape has to be Nx3.")                   # reference: :255-256
+    if eps != 0.0001:
+        raise NotImplementedError("so3_exp_map: the kernel is built for the reference's only eps, 1e-4")
+    return _ExpMap.apply(log_rot)
+
+
+def vec_3d_to_SO3(x: torch.Tensor) -> torch.Tensor:
+    """transform_output['3D']: (B,3) -> (B,3,3) through so3_exp_map; rotation_representation.py:309-321."""
+    assert x.dim() == 2 and x.shape[1] == 3                                      # reference: assert, :316
+    return so3_exp_map(x)
+
+
+# Head dispatch tables, keyed like the reference's.  `transform_output` is rotation_representation.py:323-324;
+# `head_functions` / `head_dimensions` are Model.func / Model.dimension of Comparison/models.py:18-19 and
+# point_cloud/model_fetch.py:153-154 ("Direct" is a reshape there and has no function), with 3D-Pose/main.py:46's
+# lower-case "quat" as an alias.  The SVD head is the scope of SURVEY.md section 8; the rest are its next rows f2, f5.
+transform_output = {"SVD": (9, symmetric_orthogonalization), "6D": (6, compute_rotation_matrix_from_ortho6d),
+                    "3D": (3, vec_3d_to_SO3)}
+head_dimensions = {"SVD": 9, "6D": 6, "5D": 5, "Quat": 4, "Euler": 3, "Direct": 9}
+head_functions = {"SVD": symmetric_orthogonalization, "6D": compute_rotation_matrix_from_ortho6d,
+                  "5D": compute_rotation_matrix_from_ortho5d, "Quat": compute_rotation_matrix_from_quaternion,
+                  "quat": compute_rotation_matrix_from_quaternion, "Euler": compute_rotation_matrix_from_euler}

@@ -414,6 +414,76 @@ def test_g7_ortho6d_head_forward_backward(rr, pa):
 
 
 # ------------------------------------------------------------------------------------------------
+# next row f5: the quaternion / Euler / 5D / exp-map heads (rotation_representation.py:39-171, 245-321)
+# ------------------------------------------------------------------------------------------------
+HEADS = {"quat": (4, "compute_rotation_matrix_from_quaternion"), "euler": (3, "compute_rotation_matrix_from_euler"),
+         "ortho5d": (5, "compute_rotation_matrix_from_ortho5d"), "expmap": (3, "vec_3d_to_SO3")}
+
+
+@pytest.mark.parametrize("name", sorted(HEADS))
+def test_g10_heads_forward_backward(rr, name):
+    from oracle import so3_oracle as so
+    n, fn_name = HEADS[name]
+    fn = getattr(rr, fn_name)
+    g = load_golden("g10_heads.npz")
+    x = dev(g[name + "_x"]).requires_grad_(True)
+    r = fn(x)
+    assert tuple(r.shape) == (192, 3, 3) and r.dtype == torch.float32
+    r64 = so.head_np(name, g[name + "_x"])
+    assert np.abs(r.detach().cpu().numpy() - r64).max() < 2e-6           # vs the float64 restatement
+    assert np.abs(r.detach().cpu().numpy() - g[name + "_r"]).max() < 5e-6  # vs the reference's float32 output
+    r.backward(dev(g[name + "_g"]))
+    ref = so.head_backward_np(name, g[name + "_x"], g[name + "_g"])
+    scale = np.maximum(np.abs(ref).max(axis=1), 1.0)
+    err = np.abs(x.grad.cpu().numpy() - ref).max(axis=1) / scale
+    ref_err = np.abs(g[name + "_dx"] - ref).max(axis=1) / scale          # how far the reference's own float32 autograd is
+    assert np.median(err) < 2e-6 and err.max() < max(2e-5, 2.0 * ref_err.max()), (err.max(), ref_err.max())
+    # ragged sizes: streaming units + the one-row-per-thread remainder; unaligned views
+    for b in (1, 63, 64, 65, 1000, 100_003):
+        xb = torch.randn(b, n, device=DEV, requires_grad=True)
+        out = fn(xb)
+        gb = torch.randn(b, 3, 3, device=DEV)
+        out.backward(gb)
+        e = np.abs(out.detach().cpu().numpy() - so.head_np(name, xb.detach().cpu().numpy())).reshape(b, -1).max(1)
+        # float32 conditioning: rows whose two Gram-Schmidt vectors are nearly parallel (5D) amplify round-off
+        assert np.median(e) < 3e-7 and np.quantile(e, 0.999) < 5e-6 and e.max() < 5e-4, (np.median(e), e.max())
+        refb = so.head_backward_np(name, xb.detach().cpu().numpy(), gb.cpu().numpy())
+        sc = np.maximum(np.abs(refb).max(axis=1), 1.0)
+        assert (np.abs(xb.grad.cpu().numpy() - refb).max(axis=1) / sc).max() < 5e-4
+    base = torch.randn(1001 * n + 1, device=DEV)
+    odd = base[1:].view(1001, n)                                           # 4-byte aligned only
+    assert np.abs(fn(odd).cpu().numpy() - so.head_np(name, odd.cpu().numpy())).max() < 5e-6
+    big = torch.randn(1_000_000, n, device=DEV, requires_grad=True)
+    rb = fn(big)
+    rb.backward(torch.randn(1_000_000, 3, 3, device=DEV))
+    assert torch.isfinite(big.grad).all()
+    tol = 1e-5 if name != "expmap" else 1e-4                               # exp map below the clamp is only nearly orthogonal
+    assert (torch.linalg.det(rb.detach().double()) - 1).abs().max().item() < tol
+
+
+def test_head_tables_and_argument_errors(rr, pa):
+    assert set(pa.transform_output) == {"SVD", "6D", "3D"} and pa.transform_output["3D"] == (3, rr.vec_3d_to_SO3)
+    assert pa.head_dimensions == {"SVD": 9, "6D": 6, "5D": 5, "Quat": 4, "Euler": 3, "Direct": 9}
+    for key, width in pa.head_dimensions.items():
+        if key == "Direct":
+            continue
+        out = pa.head_functions[key](torch.randn(10, width, device=DEV))
+        assert tuple(out.shape) == (10, 3, 3) and orth_err(out.cpu().numpy()).max() < 1e-5
+    assert pa.head_functions["quat"] is pa.head_functions["Quat"]
+    with pytest.raises(ValueError, match="Nx3"):
+        rr.so3_exp_map(torch.zeros(4, 4, device=DEV))
+    with pytest.raises(RuntimeError):
+        rr.compute_rotation_matrix_from_quaternion(torch.zeros(4, 3, device=DEV))
+    with pytest.raises(RuntimeError):
+        rr.compute_rotation_matrix_from_euler(torch.zeros(3, device=DEV))
+    # identity cases
+    eye = np.eye(3)
+    assert np.abs(rr.compute_rotation_matrix_from_quaternion(torch.tensor([[2.0, 0, 0, 0]], device=DEV)).cpu().numpy()[0] - eye).max() == 0
+    assert np.abs(rr.compute_rotation_matrix_from_euler(torch.zeros(1, 3, device=DEV)).cpu().numpy()[0] - eye).max() == 0
+    assert np.abs(rr.vec_3d_to_SO3(torch.zeros(1, 3, device=DEV)).cpu().numpy()[0] - eye).max() == 0
+
+
+# ------------------------------------------------------------------------------------------------
 # next row f3: per-class evaluation statistics (3D-Pose/test_per_class.py:174-216)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,ncls", [(1, 1), (2, 1), (1000, 1), (1001, 3), (250_000, 10), (1_000_000, 10)])

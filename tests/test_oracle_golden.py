@@ -178,6 +178,27 @@ def test_g7_ortho6d_oracle():
     assert orth_err(g["r"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("name", ["quat", "euler", "ortho5d", "expmap"])
+def test_g10_heads_oracle(name):
+    """Next row f5: each remaining head restated (float64) against the reference function's output and autograd."""
+    g = load_golden("g10_heads.npz")
+    x, gr = g[name + "_x"], g[name + "_g"]
+    r = so.head_np(name, x)
+    dx = so.head_backward_np(name, x, gr)
+    tol = 1e-8 if name == "expmap" else 1e-12          # below the clamp (|v|^2 < 1e-4) the map is only nearly orthogonal
+    assert orth_err(r).max() < tol and np.abs(np.linalg.det(r) - 1).max() < tol
+    if name + "_r_f64" in g:
+        assert np.abs(r - g[name + "_r_f64"]).max() < 1e-12
+        ref = g[name + "_dx_f64"]
+        assert np.abs(dx - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    # the reference's own float32 run: forward to float32 round-off; the gradient to a few 1e-4 of its scale
+    # (the exp-map factors (1 - cos t)/t^2 and d/dt cancel in float32 for small t; 1/|q| amplifies for small q)
+    assert np.abs(r - g[name + "_r"]).max() < 5e-6
+    ref32 = g[name + "_dx"].astype(np.float64)
+    scale = np.maximum(np.abs(ref32).max(axis=1, keepdims=True), 1.0)
+    assert (np.abs(dx - ref32) / scale).max() < 2e-3
+
+
 def test_g8_se3_update_oracle():
     """Next row f1: calculate_T_pred restated (float64) against the reference function's float32 output and autograd."""
     g = load_golden("g8_se3_update.npz")

@@ -60,6 +60,13 @@ def main():
     timeit("f2 so3_ortho6d_fwd_f32", lambda i: lib.so3_ortho6d_fwd_f32(p(x6[i % NB]), p(r[i % NB]), n, st), 60 * n)
     timeit("f2 so3_ortho6d_bwd_f32", lambda i: lib.so3_ortho6d_bwd_f32(p(x6[i % NB]), p(g[i % NB]), p(d6), n, st), 84 * n)
     del x6, d6
+    for name, w in (("quat", 4), ("euler", 3), ("ortho5d", 5), ("expmap", 3)):
+        xh = [torch.randn(n, w, device=dev) for _ in range(NB)]
+        dh = torch.empty(n, w, device=dev)
+        fwd, bwd = getattr(lib, "so3_%s_fwd_f32" % name), getattr(lib, "so3_%s_bwd_f32" % name)
+        timeit("f5 so3_%s_fwd_f32" % name, lambda i: fwd(p(xh[i % NB]), p(r[i % NB]), n, st), (4 * w + 36) * n)
+        timeit("f5 so3_%s_bwd_f32" % name, lambda i: bwd(p(xh[i % NB]), p(g[i % NB]), p(dh), n, st), (8 * w + 36) * n)
+        del xh, dh
     o12 = [torch.randn(n, 12, device=dev) for _ in range(3)]
     ti = [torch.eye(4, device=dev).repeat(n, 1, 1).contiguous() + 0.1 * torch.randn(n, 4, 4, device=dev) for _ in range(3)]
     tp = torch.empty(n, 16, device=dev); g16 = torch.randn(n, 16, device=dev); do12 = torch.empty(n, 12, device=dev)

@@ -130,6 +130,35 @@ def g9_sampler():
     save("g9_sampler.npz", theta=theta.astype(np.float32), axis=axis, r=r)
 
 
+def g10_heads():
+    """Next row f5: the quaternion / Euler / 5D / exp-map heads (rotation_representation.py:39-171, 245-321) and
+    their autograd, float32 as the reference runs them; float64 too where the reference's code keeps float64."""
+    heads = {"quat": (4, rr.compute_rotation_matrix_from_quaternion), "euler": (3, rr.compute_rotation_matrix_from_euler),
+             "ortho5d": (5, rr.compute_rotation_matrix_from_ortho5d), "expmap": (3, rr.vec_3d_to_SO3)}
+    out = {}
+    for seed, (name, (n, fn)) in enumerate(sorted(heads.items())):
+        torch.manual_seed(100 + seed)
+        b = 192
+        x = torch.randn(b, n)
+        x[:32] *= 4.0                                       # large angles / magnitudes
+        x[32:64] *= 0.05                                    # small ones
+        if name == "expmap":
+            x[64:80] *= 0.004                               # |v|^2 < 1e-4: the clamped branch
+            x[80:96] = x[80:96] / x[80:96].norm(dim=1, keepdim=True) * torch.linspace(0.9, 1.1, 16).view(-1, 1)   # around theta = 1
+        g = torch.randn(b, 3, 3)
+        xf = x.clone().requires_grad_(True)
+        r = fn(xf)
+        r.backward(g)
+        out.update({name + "_x": x, name + "_r": r.detach(), name + "_g": g, name + "_dx": xf.grad})
+        if name != "ortho5d":                               # its float64 run goes through float32 zeros (:82)
+            xd = x.double().requires_grad_(True)
+            rd = fn(xd)
+            rd.backward(g.double())
+            assert rd.dtype == torch.float64
+            out.update({name + "_r_f64": rd.detach(), name + "_dx_f64": xd.grad})
+    save("g10_heads.npz", **out)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         return g9_sampler()
@@ -137,9 +166,12 @@ def main():
         return g7_ortho6d()
     if len(sys.argv) > 1 and sys.argv[1] == "g8":
         return g8_se3_update()
+    if len(sys.argv) > 1 and sys.argv[1] == "g10":
+        return g10_heads()
     g7_ortho6d()
     g8_se3_update()
     g9_sampler()
+    g10_heads()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
