@@ -165,6 +165,27 @@ int so3_ortho5d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, vo
 int so3_expmap_fwd_f32(const float *X, float *R, int64_t B, void *stream);
 int so3_expmap_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
 
+/* ---- next row f6: the ADD-L1 losses that consume calculate_T_pred's output, with their gradient ----------------
+ * Replaces Iterative/loss.py:10-26 (compute_ADD_L1_loss), :29-48 (compute_disentangled_ADD_L1_loss) and :51-70
+ * (transform_pts), called at Iterative/main.py:94-95,150-151,196-197 right after calculate_T_pred, plus the autograd
+ * of the loss w.r.t. the predicted pose (which so3_se3_update_bwd_f32 then takes to the network output).
+ *   Tgt, Tpred   in  B*16 float32, row-major 4x4 poses
+ *   points       in  B*N*3 float32 model points (the reference's `verts`), N >= 1
+ *   so3_add_l1_f32:  dist_b = mean over points and coordinates of |T_gt p - T_pred p|
+ *     dists      out optional B float32 (use_batch_mean=False);  loss_sum out optional double[1] = sum_b dist_b
+ *   so3_add_l1_disentangled_f32:  the three terms of the disentangled loss per sample -- rotation (R_pred with
+ *     T_gt's translation), translation x,y and depth z (each with T_gt's rotation; these two do not depend on the
+ *     points: the transformed clouds differ by a constant vector)
+ *     loss_sum   out double[3] = sum_b (rot_b, transl_b, depth_b);  the reference's value is their total / B
+ *   dTpred       out optional B*16 float32: grad_scale * d(sum_b loss_b)/dTpred  (grad_scale = 1/B for the batch
+ *                mean; the bottom row is 0; d|x|/dx = sgn(x) with sgn(0) = 0, as autograd)
+ * loss_sum is zeroed by the call.  One pass over the points (12 B per point: HBM-read bound).
+ */
+int so3_add_l1_f32(const float *Tgt, const float *Tpred, const float *points, float *dists, double *loss_sum,
+                   float *dTpred, float grad_scale, int64_t B, int32_t N, void *stream);
+int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const float *points, double *loss_sum,
+                                float *dTpred, float grad_scale, int64_t B, int32_t N, void *stream);
+
 /* ---- next row: per-class evaluation statistics on K4's angles ----------------------
  * Replaces the host-side numpy block of 3D-Pose/test_per_class.py:174-216 (np.mean / np.median / np.std / np.max
  * and the accuracy thresholds (x < 30|15|7.5).sum()/len(x)), which the reference feeds one sample at a time.

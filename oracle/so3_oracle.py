@@ -26,6 +26,7 @@ Reference lines followed (all under /root/reference):
   per-class statistics (next row f3)   3D-Pose/test_per_class.py:174-175,206-216
   SE(3) pose update (next row f1)      Iterative/utility.py:63-128
   other heads (next row f5)            rotation_representation.py:39-50,69-171,245-321
+  ADD-L1 losses (next row f6)          Iterative/loss.py:10-70
 """
 from __future__ import annotations
 
@@ -374,6 +375,58 @@ def head_backward_np(name, x, g):
     xt = torch.as_tensor(np.asarray(x, np.float64).reshape(-1, n)).clone().requires_grad_(True)
     fn(xt).backward(torch.as_tensor(np.asarray(g, np.float64).reshape(-1, 3, 3)))
     return xt.grad.numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# next row f6: the ADD-L1 losses on the output of calculate_T_pred (Iterative/loss.py), op for op in torch
+# --------------------------------------------------------------------------------------------
+def transform_pts_torch(t, pts):
+    """(B,4,4), (B,N,3) -> (B,N,3): R p + t   (Iterative/loss.py:51-70, the 3-D `T` branch)."""
+    return (t.unsqueeze(-3)[..., :3, :3] @ pts.unsqueeze(-1) + t.unsqueeze(-3)[..., :3, [-1]]).squeeze(-1)   # :69-70
+
+
+def add_l1_torch(t_gt, t_pred, points, use_batch_mean=True):
+    """Iterative/loss.py:10-26."""
+    dists = (transform_pts_torch(t_gt, points) - transform_pts_torch(t_pred, points)).abs().mean(dim=(-1, -2))   # :21-22
+    return dists.mean() if use_batch_mean else dists                                                            # :23-26
+
+
+def add_l1_disentangled_torch(t_pred, t_gt, points, terms=False):
+    """Iterative/loss.py:29-48; `terms=True` also returns the (rot, transl, depth) summands."""
+    rot, transl, depth = t_gt.clone(), t_gt.clone(), t_gt.clone()                # :35-37
+    rot[:, :3, :3] = t_pred[:, :3, :3]                                           # :39
+    transl[:, :2, 3] = t_pred[:, :2, 3]                                          # :40
+    depth[:, 2, 3] = t_pred[:, 2, 3]                                             # :41
+    parts = (add_l1_torch(t_gt, rot, points), add_l1_torch(t_gt, transl, points), add_l1_torch(t_gt, depth, points))   # :43-45
+    total = parts[0] + parts[1] + parts[2]                                       # :47
+    return (total, parts) if terms else total
+
+
+def se3_update_torch(model_output, t_init, fx=50 / (36 / 320), fy=50 / (36 / 320)):
+    """calculate_T_pred (Iterative/utility.py:90-128) as a differentiable torch graph (any float dtype)."""
+    o, t = model_output, t_init
+    dr = symmetric_orthogonalization_torch(o[:, :9])                            # :105
+    z_new = o[:, 11] * t[:, 2, 3]                                               # :116
+    x_new = (o[:, 9] / fx + t[:, 0, 3] / t[:, 2, 3]) * z_new                    # :120
+    y_new = (o[:, 10] / fy + t[:, 1, 3] / t[:, 2, 3]) * z_new                   # :121
+    top = torch.cat((torch.matmul(dr, t[:, :3, :3]), torch.stack((x_new, y_new, z_new), 1).unsqueeze(-1)), 2)   # :124, combine :63-71
+    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=o.dtype).expand(o.shape[0], 1, 4)
+    return torch.cat((top, bottom), 1)
+
+
+def add_l1_np(t_gt, t_pred, points, disentangled=False):
+    """float64: (loss, dL/dT_pred, per-sample dists or the three disentangled terms)."""
+    tg = torch.as_tensor(np.asarray(t_gt, np.float64))
+    tp = torch.as_tensor(np.asarray(t_pred, np.float64)).clone().requires_grad_(True)
+    pts = torch.as_tensor(np.asarray(points, np.float64))
+    if disentangled:
+        loss, parts = add_l1_disentangled_torch(tp, tg, pts, terms=True)
+        extra = np.array([p.item() for p in parts])
+    else:
+        loss = add_l1_torch(tg, tp, pts)
+        extra = add_l1_torch(tg, tp.detach(), pts, use_batch_mean=False).numpy()
+    loss.backward()
+    return loss.item(), tp.grad.numpy(), extra
 
 
 # --------------------------------------------------------------------------------------------

@@ -529,6 +529,123 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
     }
 }
 
+// ---- next row f6: the ADD-L1 losses that consume calculate_T_pred's output (Iterative/loss.py:10-48) ------------
+// dist_b = mean_{i,c} |(T_gt p_i - T_pred p_i)_c| = mean |dR p_i + dt|,  dR = R_gt - R_pred, dt = t_gt - t_pred, and
+// its gradient  dL/dR_pred[c][j] = -k sum_i sgn(d_ic) p_ij,  dL/dt_pred[c] = -k sum_i sgn(d_ic),  k = scale / (3 N),
+// in one pass over the points (the K5 skeleton: one wave per sample at a time, 12-byte loads, lane j of the wave
+// keeps the results of its j-th sample).  DISENT = compute_disentangled_ADD_L1_loss: the rotation term is the same
+// sum with dt = 0; the translation and depth terms do not depend on the points at all -- (|dtx| + |dty|)/3 and
+// |dtz|/3 -- because the two transformed clouds differ by a constant vector.
+__device__ __forceinline__ float sgn_of(float d) { return __builtin_amdgcn_fmed3f(d * 0x1p127f, -1.f, 1.f); }   // -1, 0, +1
+
+// kAddUnroll = 12-byte loads in flight per lane: 16 for large clouds (12 KB per wave, what K5 has with two arrays),
+// fewer for small ones, whose zero-filled slots would only cost arithmetic.
+template <bool DISENT, int kAddUnroll>
+__global__ __launch_bounds__(kBlock) void k_add_l1(const float *__restrict__ Tgt, const float *__restrict__ Tpred,
+                                                   const float *__restrict__ pts, float *__restrict__ dists,
+                                                   double *__restrict__ loss_sum, float *__restrict__ dT, float grad_scale,
+                                                   int64_t B, int32_t N, int per_wave) {
+    __shared__ double red[kBlock / 64][3];
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
+    const int64_t c0 = wave * per_wave;
+    const int nc = c0 < B ? static_cast<int>(min<int64_t>(per_wave, B - c0)) : 0;
+    const float inv3n = 1.0f / (3.0f * static_cast<float>(N));
+    const unsigned cloud_bytes = static_cast<unsigned>(N) * 12u;
+    const int slots = ((N + 64 * kAddUnroll - 1) / (64 * kAddUnroll)) * kAddUnroll;      // loads per lane and sample
+    const int valid = N > lane ? (N - lane + 63) / 64 : 0;
+    const float npad = static_cast<float>(slots - valid);     // zero-filled slots of this lane: each adds |dt|, sgn(dt)
+    float keep[13];                                            // lane j: dist, G (9), gt (3) of sample c0 + j
+    float keep_dt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 13; ++i) keep[i] = 0.f;
+    for (int j = 0; j < nc; ++j) {
+        const float *tg = Tgt + (c0 + j) * 16, *tp = Tpred + (c0 + j) * 16;      // wave-uniform: scalar loads
+        float dr[9], dt[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dr[3 * c + k] = tg[4 * c + k] - tp[4 * c + k];
+            dt[c] = tg[4 * c + 3] - tp[4 * c + 3];
+        }
+        const float ax = DISENT ? 0.f : dt[0], ay = DISENT ? 0.f : dt[1], az = DISENT ? 0.f : dt[2];
+        const so3::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pts) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        float acc[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) acc[i] = 0.f;
+        for (int i0 = 0; i0 < N; i0 += 64 * kAddUnroll) {
+            u32x3 pp[kAddUnroll];
+#pragma unroll
+            for (int u = 0; u < kAddUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+#pragma unroll
+            for (int u = 0; u < kAddUnroll; ++u) {
+                const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
+                const float dx = fmaf(dr[0], px, fmaf(dr[1], py, fmaf(dr[2], pz, ax)));
+                const float dy = fmaf(dr[3], px, fmaf(dr[4], py, fmaf(dr[5], pz, ay)));
+                const float dz = fmaf(dr[6], px, fmaf(dr[7], py, fmaf(dr[8], pz, az)));
+                acc[0] += fabsf(dx) + fabsf(dy) + fabsf(dz);
+                const float sx = sgn_of(dx), sy = sgn_of(dy), sz = sgn_of(dz);
+                acc[1] = fmaf(sx, px, acc[1]); acc[2] = fmaf(sx, py, acc[2]); acc[3] = fmaf(sx, pz, acc[3]);
+                acc[4] = fmaf(sy, px, acc[4]); acc[5] = fmaf(sy, py, acc[5]); acc[6] = fmaf(sy, pz, acc[6]);
+                acc[7] = fmaf(sz, px, acc[7]); acc[8] = fmaf(sz, py, acc[8]); acc[9] = fmaf(sz, pz, acc[9]);
+                acc[10] += sx; acc[11] += sy; acc[12] += sz;
+            }
+        }
+        if (!DISENT) {      // take the zero-filled slots back out (they saw d = dt exactly)
+            acc[0] = fmaf(-npad, fabsf(ax) + fabsf(ay) + fabsf(az), acc[0]);
+            acc[10] = fmaf(-npad, sgn_of(ax), acc[10]);
+            acc[11] = fmaf(-npad, sgn_of(ay), acc[11]);
+            acc[12] = fmaf(-npad, sgn_of(az), acc[12]);
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+            const float tot = wave_allsum(acc[i]);
+            keep[i] = (lane == j) ? tot : keep[i];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) keep_dt[c] = (lane == j) ? dt[c] : keep_dt[c];
+    }
+    // lane j < nc finishes sample c0 + j
+    const bool active = lane < nc;
+    const float dist = keep[0] * inv3n;
+    double part[3] = {0.0, 0.0, 0.0};
+    if (active) {
+        const int64_t b = c0 + lane;
+        part[0] = dist;
+        if (DISENT) {
+            part[1] = (fabsf(keep_dt[0]) + fabsf(keep_dt[1])) * (1.0f / 3.0f);
+            part[2] = fabsf(keep_dt[2]) * (1.0f / 3.0f);
+        }
+        if (dists != nullptr) dists[b] = dist;
+        if (dT != nullptr) {
+            const float k = -grad_scale * inv3n, kt = -grad_scale * (1.0f / 3.0f);
+            float *o = dT + b * 16;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[4 * c + 0] = k * keep[1 + 3 * c]; o[4 * c + 1] = k * keep[2 + 3 * c]; o[4 * c + 2] = k * keep[3 + 3 * c];
+                o[4 * c + 3] = DISENT ? kt * sgn_of(keep_dt[c]) : k * keep[10 + c];
+            }
+            o[12] = 0.f; o[13] = 0.f; o[14] = 0.f; o[15] = 0.f;
+        }
+    }
+    if (loss_sum != nullptr) {
+        constexpr int kTerms = DISENT ? 3 : 1;
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t) {
+            const double v = wave_sum(part[t]);
+            if (lane == 0) red[wave_in_block][t] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < kTerms) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) tot += red[w][threadIdx.x];
+            atomicAdd(loss_sum + threadIdx.x, tot);
+        }
+    }
+}
+
 // ---- 6D head, one row per thread: remainder (< 64 rows) and unaligned input of the streaming kernels ----------
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict__ X, const float *__restrict__ G,
@@ -870,6 +987,29 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
+namespace {
+template <bool DISENT>
+int launch_add_l1(const float *Tgt, const float *Tpred, const float *points, float *dists, double *loss_sum, float *dTpred,
+                  float grad_scale, int64_t B, int32_t N, hipStream_t s, const char *what) {
+    if (loss_sum != nullptr) {
+        const hipError_t e = hipMemsetAsync(loss_sum, 0, (DISENT ? 3 : 1) * sizeof(double), s);
+        if (e != hipSuccess) return fail(static_cast<int>(e), what);
+    }
+    if (B == 0) return 0;
+    int64_t per_wave = B / (256 * 16);              // enough waves for 256 CUs x 16, at most 64 samples per wave
+    if (per_wave < 1) per_wave = 1;
+    if (per_wave > 64) per_wave = 64;
+    const int64_t waves = (B + per_wave - 1) / per_wave;
+    const int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    const dim3 grid(static_cast<unsigned>(blocks)), block(kBlock);
+    const int pw = static_cast<int>(per_wave);
+    if (N > 512) hipLaunchKernelGGL((k_add_l1<DISENT, 16>), grid, block, 0, s, Tgt, Tpred, points, dists, loss_sum, dTpred, grad_scale, B, N, pw);
+    else if (N > 128) hipLaunchKernelGGL((k_add_l1<DISENT, 8>), grid, block, 0, s, Tgt, Tpred, points, dists, loss_sum, dTpred, grad_scale, B, N, pw);
+    else hipLaunchKernelGGL((k_add_l1<DISENT, 2>), grid, block, 0, s, Tgt, Tpred, points, dists, loss_sum, dTpred, grad_scale, B, N, pw);
+    return check_launch(what);
+}
+}  // namespace
+
 extern "C" {
 
 int so3_version(void) { return SO3PROJ_VERSION; }
@@ -1054,6 +1194,21 @@ SO3_DEFINE_HEAD(euler, OpEuler)
 SO3_DEFINE_HEAD(ortho5d, OpOrtho5d)
 SO3_DEFINE_HEAD(expmap, OpExpMap)
 #undef SO3_DEFINE_HEAD
+
+int so3_add_l1_f32(const float *Tgt, const float *Tpred, const float *points, float *dists, double *loss_sum, float *dTpred,
+                   float grad_scale, int64_t B, int32_t N, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_add_l1_f32: B/N");
+    SO3_CHECK_ARGS(B == 0 || (Tgt != nullptr && Tpred != nullptr && points != nullptr), "so3_add_l1_f32: null pointer");
+    return launch_add_l1<false>(Tgt, Tpred, points, dists, loss_sum, dTpred, grad_scale, B, N, static_cast<hipStream_t>(stream), "so3_add_l1_f32");
+}
+
+int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const float *points, double *loss_sum, float *dTpred,
+                                float grad_scale, int64_t B, int32_t N, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_add_l1_disentangled_f32: B/N");
+    SO3_CHECK_ARGS(B == 0 || (Tgt != nullptr && Tpred != nullptr && points != nullptr), "so3_add_l1_disentangled_f32: null pointer");
+    return launch_add_l1<true>(Tgt, Tpred, points, nullptr, loss_sum, dTpred, grad_scale, B, N, static_cast<hipStream_t>(stream),
+                               "so3_add_l1_disentangled_f32");
+}
 
 size_t so3_angle_stats_workspace_bytes(void) { return sizeof(StatWork); }
 

@@ -428,6 +428,85 @@ def calculate_T_pred(model_output: torch.Tensor, T_init: torch.Tensor, device=No
 
 
 # --------------------------------------------------------------------------------------------
+# next row f6: the ADD-L1 losses on calculate_T_pred's output (Iterative/loss.py)
+# --------------------------------------------------------------------------------------------
+def _add_l1_args(t_gt, t_pred, points):
+    bsz = len(t_gt)
+    assert t_pred.shape == (bsz, 4, 4) and t_gt.shape == (bsz, 4, 4)            # reference: Iterative/loss.py:18
+    assert points.dim() == 3 and points.shape[-1] == 3                          # :19
+    assert points.shape[0] == bsz                                               # transform_pts, :58
+    dev = _require_device(t_pred)
+    _require_device(t_gt)
+    _require_device(points)
+    if points.shape[1] < 1:
+        raise RuntimeError("ADD-L1: at least one model point per sample is needed")
+    prep = lambda t: t.detach().contiguous().float()
+    return dev, bsz, int(points.shape[1]), prep(t_gt), prep(t_pred), prep(points)
+
+
+class _AddL1(torch.autograd.Function):
+    """compute_ADD_L1_loss and its gradient w.r.t. the predicted pose, one launch (so3_add_l1_f32)."""
+
+    @staticmethod
+    def forward(ctx, t_gt, t_pred, points, use_batch_mean):
+        dev, b, n, tg, tp, pts = _add_l1_args(t_gt, t_pred, points)
+        want_grad = t_pred.requires_grad
+        dt = torch.empty((b, 4, 4), dtype=torch.float32, device=dev) if want_grad else None
+        dists = None if use_batch_mean else torch.empty((b,), dtype=torch.float32, device=dev)
+        loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if use_batch_mean else None
+        scale = 1.0 / max(b, 1) if use_batch_mean else 1.0
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_add_l1_f32(_ptr(tg), _ptr(tp), _ptr(pts), _ptr(dists), _ptr(loss_sum), _ptr(dt), scale, b, n,
+                                                  _stream(dev)), "so3_add_l1_f32")
+        ctx.dt, ctx.per_sample, ctx.in_dtype = dt, not use_batch_mean, t_pred.dtype
+        if use_batch_mean:
+            return loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
+        return dists
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        if ctx.dt is None:
+            return None, None, None, None
+        g = grad_out.reshape(-1, 1, 1) if ctx.per_sample else grad_out
+        return None, (ctx.dt * g).to(ctx.in_dtype), None, None
+
+
+class _AddL1Disentangled(torch.autograd.Function):
+    """compute_disentangled_ADD_L1_loss and its gradient, one launch (so3_add_l1_disentangled_f32)."""
+
+    @staticmethod
+    def forward(ctx, t_pred, t_gt, points):
+        dev, b, n, tg, tp, pts = _add_l1_args(t_gt, t_pred, points)
+        dt = torch.empty((b, 4, 4), dtype=torch.float32, device=dev) if t_pred.requires_grad else None
+        loss_sum = torch.empty((3,), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().so3_add_l1_disentangled_f32(_ptr(tp), _ptr(tg), _ptr(pts), _ptr(loss_sum), _ptr(dt), 1.0 / max(b, 1),
+                                                               b, n, _stream(dev)), "so3_add_l1_disentangled_f32")
+        ctx.dt, ctx.in_dtype = dt, t_pred.dtype
+        return loss_sum.sum().to(torch.float32).mul_(1.0 / max(b, 1))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        if ctx.dt is None:
+            return None, None, None
+        return (ctx.dt * grad_out).to(ctx.in_dtype), None, None
+
+
+def compute_ADD_L1_loss(TCO_gt: torch.Tensor, TCO_pred: torch.Tensor, points: torch.Tensor, use_batch_mean: bool = True) -> torch.Tensor:
+    """mean |T_gt p - T_pred p| over points and coordinates (and the batch); Iterative/loss.py:10-26.
+    Differentiable w.r.t. TCO_pred (the ground-truth pose and the model points are constants in the reference's loops)."""
+    return _AddL1.apply(TCO_gt, TCO_pred, points, bool(use_batch_mean))
+
+
+def compute_disentangled_ADD_L1_loss(T_CO_pred: torch.Tensor, T_CO_gt: torch.Tensor, points: torch.Tensor) -> torch.Tensor:
+    """rotation + xy-translation + depth ADD-L1 terms; Iterative/loss.py:29-48, called right after calculate_T_pred
+    (Iterative/main.py:94-95).  Differentiable w.r.t. T_CO_pred."""
+    return _AddL1Disentangled.apply(T_CO_pred, T_CO_gt, points)
+
+
+# --------------------------------------------------------------------------------------------
 # next row f3: per-class evaluation statistics
 # --------------------------------------------------------------------------------------------
 STAT_FIELDS = ("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")

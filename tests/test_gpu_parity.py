@@ -484,6 +484,87 @@ def test_head_tables_and_argument_errors(rr, pa):
 
 
 # ------------------------------------------------------------------------------------------------
+# next row f6: the ADD-L1 losses after calculate_T_pred (Iterative/loss.py:10-70)
+# ------------------------------------------------------------------------------------------------
+def test_g11_add_l1_losses_and_gradients(rr):
+    from oracle import so3_oracle as so
+    g = load_golden("g11_add_l1.npz")
+    tg, pts = dev(g["t_gt"]), dev(g["points"])
+    tp = dev(g["t_pred"]).requires_grad_(True)
+    loss = rr.compute_ADD_L1_loss(tg, tp, pts)
+    loss.backward()
+    assert loss.dtype == torch.float32 and loss.dim() == 0
+    assert abs(loss.item() - float(g["add_f64"])) < 2e-7 and abs(loss.item() - float(g["add"])) < 1e-6
+    assert np.abs(tp.grad.cpu().numpy() - g["add_grad_f64"]).max() < 2e-7
+    d = rr.compute_ADD_L1_loss(tg, tp.detach(), pts, use_batch_mean=False)
+    assert tuple(d.shape) == (24,) and np.abs(d.cpu().numpy() - g["add_dists_f64"]).max() < 2e-7
+    # per-sample mode is differentiable too: weights w_b -> sum_b w_b dist_b
+    tp2 = dev(g["t_pred"]).requires_grad_(True)
+    w = torch.linspace(0.5, 2.0, 24, device=DEV)
+    (rr.compute_ADD_L1_loss(tg, tp2, pts, use_batch_mean=False) * w).sum().backward()
+    assert np.abs(tp2.grad.cpu().numpy() - 24 * g["add_grad_f64"] * w.cpu().numpy()[:, None, None]).max() < 5e-6
+    tp3 = dev(g["t_pred"]).requires_grad_(True)
+    ldis = rr.compute_disentangled_ADD_L1_loss(tp3, tg, pts)
+    ldis.backward()
+    assert abs(ldis.item() - float(g["dis_f64"])) < 2e-7 and abs(ldis.item() - float(g["dis"])) < 1e-6
+    assert np.abs(tp3.grad.cpu().numpy() - g["dis_grad_f64"]).max() < 2e-7
+    assert np.all(tp3.grad[0].cpu().numpy() == 0)                               # exact hit: sgn(0) = 0, as autograd
+    with pytest.raises(AssertionError):
+        rr.compute_ADD_L1_loss(tg, tp.detach()[:, :3], pts)
+    with pytest.raises(AssertionError):
+        rr.compute_disentangled_ADD_L1_loss(tp.detach(), tg, pts[..., :2])
+
+
+@pytest.mark.parametrize("b,n", [(1, 1), (3, 63), (5, 64), (7, 513), (300, 1024), (4097, 100)])
+def test_add_l1_ragged_sizes_against_oracle(rr, b, n):
+    from oracle import so3_oracle as so
+    gen = torch.Generator().manual_seed(b * 1000 + n)
+    def poses():
+        t = torch.eye(4).repeat(b, 1, 1)
+        t[:, :3, :3] = so.symmetric_orthogonalization_torch(torch.randn(b, 9, generator=gen))
+        t[:, :3, 3] = torch.randn(b, 3, generator=gen)
+        return t
+    t_gt, t_pred, pts = poses(), poses(), torch.randn(b, n, 3, generator=gen)
+    for dis in (False, True):
+        ref_loss, ref_grad, _ = so.add_l1_np(t_gt.numpy(), t_pred.numpy(), pts.numpy(), disentangled=dis)
+        tp = t_pred.to(DEV).requires_grad_(True)
+        loss = rr.compute_disentangled_ADD_L1_loss(tp, t_gt.to(DEV), pts.to(DEV)) if dis else rr.compute_ADD_L1_loss(t_gt.to(DEV), tp, pts.to(DEV))
+        loss.backward()
+        assert abs(loss.item() - ref_loss) < 3e-6 * max(1.0, abs(ref_loss))
+        # a coordinate difference within float32 round-off of its kink may take the other sign: allow a handful of points
+        err = np.abs(tp.grad.cpu().numpy() - ref_grad)
+        assert err.max() < 3e-6 + 8.0 * 3.0 / (3 * n * b), err.max()
+
+
+def test_iterative_step_head_update_loss_backward(rr):
+    """The refiner's training step end to end (Iterative/main.py:88-99): network output -> calculate_T_pred ->
+    disentangled ADD-L1 -> backward to the network output, all through the library; against float64 autograd."""
+    from oracle import so3_oracle as so
+    gen = torch.Generator().manual_seed(5)
+    b, n = 48, 300
+    out = torch.randn(b, 12, generator=gen)
+    out[:, 11] = 1.0 + 0.05 * torch.randn(b, generator=gen)
+    t_init = torch.eye(4).repeat(b, 1, 1)
+    t_init[:, :3, :3] = so.symmetric_orthogonalization_torch(torch.randn(b, 9, generator=gen))
+    t_init[:, :3, 3] = torch.tensor([0.0, 0.0, 2.0]) + 0.2 * torch.randn(b, 3, generator=gen)
+    t_gt = t_init.clone()
+    t_gt[:, :3, 3] += 0.05 * torch.randn(b, 3, generator=gen)
+    pts = 0.2 * torch.randn(b, n, 3, generator=gen)
+    o = out.to(DEV).requires_grad_(True)
+    t_pred = rr.calculate_T_pred(o, t_init.to(DEV), DEV)
+    loss = rr.compute_disentangled_ADD_L1_loss(t_pred, t_gt.to(DEV), pts.to(DEV))
+    loss.backward()
+    fx, fy = rr.get_scene_parameters()
+    od = out.double().requires_grad_(True)
+    tp64 = so.se3_update_torch(od, t_init.double(), fx, fy)
+    l64 = so.add_l1_disentangled_torch(tp64, t_gt.double(), pts.double())
+    l64.backward()
+    assert abs(loss.item() - l64.item()) < 2e-6
+    ref = od.grad.numpy()
+    assert np.abs(o.grad.cpu().numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------------
 # next row f3: per-class evaluation statistics (3D-Pose/test_per_class.py:174-216)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,ncls", [(1, 1), (2, 1), (1000, 1), (1001, 3), (250_000, 10), (1_000_000, 10)])

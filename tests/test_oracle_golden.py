@@ -199,6 +199,24 @@ def test_g10_heads_oracle(name):
     assert (np.abs(dx - ref32) / scale).max() < 2e-3
 
 
+def test_g11_add_l1_oracle():
+    """Next row f6: the ADD-L1 losses restated (float64) against the reference functions and their autograd."""
+    g = load_golden("g11_add_l1.npz")
+    loss, grad, dists = so.add_l1_np(g["t_gt"], g["t_pred"], g["points"])
+    assert abs(loss - g["add_f64"]) < 1e-14 and np.abs(grad - g["add_grad_f64"]).max() < 1e-15
+    assert np.abs(dists - g["add_dists_f64"]).max() < 1e-14
+    assert abs(loss - g["add"]) < 1e-6 and np.abs(grad - g["add_grad"]).max() < 1e-6        # the float32 run
+    loss, grad, parts = so.add_l1_np(g["t_gt"], g["t_pred"], g["points"], disentangled=True)
+    assert abs(loss - g["dis_f64"]) < 1e-14 and np.abs(grad - g["dis_grad_f64"]).max() < 1e-15
+    assert abs(loss - g["dis"]) < 1e-6 and np.abs(grad - g["dis_grad"]).max() < 1e-6
+    assert abs(parts.sum() - loss) < 1e-14
+    # the translation / depth terms do not depend on the points: (|dtx| + |dty|)/3 and |dtz|/3 per sample
+    dt = g["t_gt"][:, :3, 3].astype(np.float64) - g["t_pred"][:, :3, 3].astype(np.float64)
+    assert abs(parts[1] - ((np.abs(dt[:, 0]) + np.abs(dt[:, 1])) / 3).mean()) < 1e-12
+    assert abs(parts[2] - (np.abs(dt[:, 2]) / 3).mean()) < 1e-12
+    assert np.all(g["dis_grad_f64"][0] == 0)                                                 # exact hit: sgn(0) = 0
+
+
 def test_g8_se3_update_oracle():
     """Next row f1: calculate_T_pred restated (float64) against the reference function's float32 output and autograd."""
     g = load_golden("g8_se3_update.npz")

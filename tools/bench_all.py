@@ -90,7 +90,14 @@ def main():
     rg = rr.get_sampled_rotation_matrices_by_axisAngle(b, dev).reshape(b, 9).contiguous()
     timeit("f4 so3_kabsch_synth_f32 (sigma=0: P only)", lambda i: lib.so3_kabsch_synth_f32(p(pc[i % 2]), p(rg), ctypes.c_float(0.0), 1, p(rk), None, b, npts, st), b * (npts * 12 + 72), iters=10, warm=2)
     timeit("f4 so3_kabsch_synth_f32 (sigma=0.01, device RNG)", lambda i: lib.so3_kabsch_synth_f32(p(pc[i % 2]), p(rg), ctypes.c_float(0.01), 1, p(rk), None, b, npts, st), b * (npts * 12 + 72), iters=10, warm=2)
-    del pc, qc
+    del qc
+    tg = torch.eye(4, device=dev).repeat(b, 1, 1).contiguous(); tg[:, :3, :3] = rg.view(b, 3, 3); tg[:, :3, 3] = torch.randn(b, 3, device=dev)
+    tq = tg.clone(); tq[:, :3, :3] = rr.get_sampled_rotation_matrices_by_axisAngle(b, dev); tq[:, :3, 3] += 0.1 * torch.randn(b, 3, device=dev)
+    dtq = torch.empty(b, 16, device=dev); l3 = torch.empty(3, dtype=torch.float64, device=dev)
+    sc = ctypes.c_float(1.0 / b)
+    timeit("f6 so3_add_l1_f32 (loss + dTpred)", lambda i: lib.so3_add_l1_f32(p(tg), p(tq), p(pc[i % 2]), None, p(l3), p(dtq), sc, b, npts, st), b * (npts * 12 + 192), iters=10, warm=2)
+    timeit("f6 so3_add_l1_disentangled_f32 (loss + dTpred)", lambda i: lib.so3_add_l1_disentangled_f32(p(tq), p(tg), p(pc[i % 2]), p(l3), p(dtq), sc, b, npts, st), b * (npts * 12 + 192), iters=10, warm=2)
+    del pc, tg, tq, dtq
     torch.cuda.empty_cache()
     print("--- config #4: B = 512, bf16 storage, fused head + loss + backward ---")
     b = 512

@@ -130,6 +130,41 @@ def g9_sampler():
     save("g9_sampler.npz", theta=theta.astype(np.float32), axis=axis, r=r)
 
 
+def g11_add_l1():
+    """Next row f6: compute_ADD_L1_loss / compute_disentangled_ADD_L1_loss (Iterative/loss.py:10-70) and their
+    autograd w.r.t. the predicted pose, float32 as the training loop runs them and float64."""
+    add_l1, add_l1_dis, _ = functions_from(os.path.join(REF, "Iterative", "loss.py"),
+                                           ["compute_ADD_L1_loss", "compute_disentangled_ADD_L1_loss", "transform_pts"])
+    add_l1.__globals__["transform_pts"] = _
+    torch.manual_seed(21)
+    b, n = 24, 200                                                        # N not a multiple of 64: ragged tail
+    def poses(noise):
+        t = torch.eye(4).repeat(b, 1, 1)
+        t[:, :3, :3] = rr.symmetric_orthogonalization(torch.randn(b, 9))
+        t[:, :3, 3] = torch.randn(b, 3) * 0.3 + torch.tensor([0.0, 0.0, 2.0])
+        return t
+    t_gt = poses(0)
+    t_pred = t_gt.clone()
+    t_pred[:, :3, :3] = torch.matmul(rr.symmetric_orthogonalization(torch.eye(3).reshape(1, 9) + 0.2 * torch.randn(b, 9)), t_gt[:, :3, :3])
+    t_pred[:, :3, 3] += 0.1 * torch.randn(b, 3)
+    t_pred[0] = t_gt[0]                                                   # an exact hit: every |.| sits at its kink
+    t_pred[1, :3, 3] = t_gt[1, :3, 3]                                     # rotation error only
+    t_pred[2, :3, :3] = t_gt[2, :3, :3]                                   # translation error only
+    pts = torch.randn(b, n, 3) * 0.2
+    out = {"t_gt": t_gt, "t_pred": t_pred, "points": pts}
+    for tag, dt in (("", torch.float32), ("_f64", torch.float64)):
+        tg, p = t_gt.to(dt), pts.to(dt)
+        tp = t_pred.to(dt).clone().requires_grad_(True)
+        loss = add_l1(tg, tp, p)
+        loss.backward()
+        out.update({"add" + tag: loss.detach(), "add_grad" + tag: tp.grad, "add_dists" + tag: add_l1(tg, tp.detach(), p, use_batch_mean=False)})
+        tp = t_pred.to(dt).clone().requires_grad_(True)
+        loss = add_l1_dis(tp, tg, p)
+        loss.backward()
+        out.update({"dis" + tag: loss.detach(), "dis_grad" + tag: tp.grad})
+    save("g11_add_l1.npz", **out)
+
+
 def g10_heads():
     """Next row f5: the quaternion / Euler / 5D / exp-map heads (rotation_representation.py:39-171, 245-321) and
     their autograd, float32 as the reference runs them; float64 too where the reference's code keeps float64."""
@@ -168,10 +203,13 @@ def main():
         return g8_se3_update()
     if len(sys.argv) > 1 and sys.argv[1] == "g10":
         return g10_heads()
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        return g11_add_l1()
     g7_ortho6d()
     g8_se3_update()
     g9_sampler()
     g10_heads()
+    g11_add_l1()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
