@@ -165,6 +165,17 @@ int so3_ortho5d_bwd_f32(const float *X, const float *G, float *dX, int64_t B, vo
 int so3_expmap_fwd_f32(const float *X, float *R, int64_t B, void *stream);
 int so3_expmap_bwd_f32(const float *X, const float *G, float *dX, int64_t B, void *stream);
 
+/* ---- row a7: the cloud side of the point-cloud path -------------------------------------
+ * so3_rotate_clouds_f32 replaces the pairing rule of the training loop, point_cloud/main.py:173-181
+ *   (expand gt_rmat to every point, bmm, view) and, with transposed != 0, the `.transpose(1, 2)` at :183 as well:
+ *     P B*N*3, R B*9  ->  out[b][i][:] = R_b p_i   (transposed: out[b][:][i], the (B,3,N) layout the network reads).
+ * so3_pc_normalize_f32 replaces pc_normalize, point_cloud/prepare.py:51-56, for a batch of clouds:
+ *     centre = (max + min)/2 per axis, scale = |max - min| of the centred cloud, out = (P - centre)/scale;
+ *     centroid (B*3) and scale (B) are optional outputs.  float32 (the reference runs it in numpy float64).
+ */
+int so3_rotate_clouds_f32(const float *P, const float *R, float *out, int transposed, int64_t B, int32_t N, void *stream);
+int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *scale, int64_t B, int32_t N, void *stream);
+
 /* ---- next row f6: the ADD-L1 losses that consume calculate_T_pred's output, with their gradient ----------------
  * Replaces Iterative/loss.py:10-26 (compute_ADD_L1_loss), :29-48 (compute_disentangled_ADD_L1_loss) and :51-70
  * (transform_pts), called at Iterative/main.py:94-95,150-151,196-197 right after calculate_T_pred, plus the autograd

@@ -27,6 +27,7 @@ Reference lines followed (all under /root/reference):
   SE(3) pose update (next row f1)      Iterative/utility.py:63-128
   other heads (next row f5)            rotation_representation.py:39-50,69-171,245-321
   ADD-L1 losses (next row f6)          Iterative/loss.py:10-70
+  cloud pairing / pc_normalize (a7)    point_cloud/main.py:173-183, point_cloud/prepare.py:51-56
 """
 from __future__ import annotations
 
@@ -206,6 +207,22 @@ def cross_covariance_np(p, q):
     p = np.asarray(p, np.float64)
     q = np.asarray(q, np.float64)
     return np.einsum("bia,bic->bac", q, p)
+
+
+def rotate_clouds_np(p, r, transposed=False):
+    """q_i = R_b p_i for every point (point_cloud/main.py:173-181); transposed -> (B,3,N) as main.py:183 feeds the net."""
+    q = np.einsum("bac,bic->bia", np.asarray(r, np.float64).reshape(-1, 3, 3), np.asarray(p, np.float64))
+    return q.transpose(0, 2, 1) if transposed else q
+
+
+def pc_normalize_np(pc):
+    """point_cloud/prepare.py:51-56 for one (N,3) cloud or a (B,N,3) batch, float64: (pc, centroid, scale)."""
+    pc = np.asarray(pc, np.float64)
+    centroid = (np.max(pc, axis=-2, keepdims=True) + np.min(pc, axis=-2, keepdims=True)) / 2          # :52
+    pc = pc - centroid                                                                                # :53
+    scale = np.linalg.norm(np.max(pc, axis=-2) - np.min(pc, axis=-2), axis=-1)                        # :54
+    pc = pc / scale[..., None, None]                                                                  # :55
+    return pc, centroid.squeeze(-2), scale
 
 
 def kabsch_np(p, q):

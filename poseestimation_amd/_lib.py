@@ -34,6 +34,8 @@ SYMBOLS = {
     "so3_ortho6d_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
     **{"so3_%s_fwd_f32" % h: (_INT, [_P, _P, _I64, _P]) for h in ("quat", "euler", "ortho5d", "expmap")},
     **{"so3_%s_bwd_f32" % h: (_INT, [_P, _P, _P, _I64, _P]) for h in ("quat", "euler", "ortho5d", "expmap")},
+    "so3_rotate_clouds_f32": (_INT, [_P, _P, _P, _INT, _I64, _I32, _P]),
+    "so3_pc_normalize_f32": (_INT, [_P, _P, _P, _P, _I64, _I32, _P]),
     "so3_add_l1_f32": (_INT, [_P, _P, _P, _P, _P, _P, ctypes.c_float, _I64, _I32, _P]),
     "so3_add_l1_disentangled_f32": (_INT, [_P, _P, _P, _P, _P, ctypes.c_float, _I64, _I32, _P]),
     "so3_angle_stats_workspace_bytes": (ctypes.c_size_t, []),

@@ -529,6 +529,123 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
     }
 }
 
+// ---- row a7 (cloud side of the Kabsch / PointNet path) ----------------------------------------------------------
+// (a) the training loop's pairing rule, point_cloud/main.py:173-181: q_i = R_b p_i for every point of cloud b, written
+//     either as (B,N,3) or already transposed to the (B,3,N) layout the network consumes (`gg = pc_out.transpose(1,2)`);
+// (b) pc_normalize, point_cloud/prepare.py:51-56: subtract the bounding-box centre, divide by the box diagonal.
+// One wave per cloud at a time, 12-byte nt loads with a per-cloud descriptor (lanes past the end read zeros and their
+// stores are dropped by the range check).
+constexpr int kCloudUnroll = 8;
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(kBlock) void k_rotate_clouds(const float *__restrict__ P, const float *__restrict__ R,
+                                                          float *__restrict__ out, int64_t B, int32_t N, int per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
+    const int64_t c0 = wave * per_wave;
+    const int nc = c0 < B ? static_cast<int>(min<int64_t>(per_wave, B - c0)) : 0;
+    const unsigned cloud_bytes = static_cast<unsigned>(N) * 12u;
+    for (int j = 0; j < nc; ++j) {
+        const float *r = R + (c0 + j) * 9;                       // wave-uniform: scalar loads
+        const float r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7], r8 = r[8];
+        const so3::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        float *ob = out + (c0 + j) * N * 3;
+        const so3::rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, cloud_bytes, so3::kRsrcFlags);
+        const so3::rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(ob, 0, static_cast<unsigned>(N) * 4u, so3::kRsrcFlags);
+        const so3::rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(ob + N, 0, static_cast<unsigned>(N) * 4u, so3::kRsrcFlags);
+        const so3::rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(ob + 2 * static_cast<int64_t>(N), 0, static_cast<unsigned>(N) * 4u, so3::kRsrcFlags);
+        for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
+            u32x3 pp[kCloudUnroll];
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) {
+                const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
+                const float qx = fmaf(r0, px, fmaf(r1, py, r2 * pz));
+                const float qy = fmaf(r3, px, fmaf(r4, py, r5 * pz));
+                const float qz = fmaf(r6, px, fmaf(r7, py, r8 * pz));
+                const int i = i0 + 64 * u + lane;
+                if (TRANSPOSED) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qx), rx, i * 4, 0, so3::kStreamCpol);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qy), ry, i * 4, 0, so3::kStreamCpol);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qz), rz, i * 4, 0, so3::kStreamCpol);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro, i * 12, 0, so3::kStreamCpol);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = fmaxf(v, dpp_xor1(v));
+    v = fmaxf(v, dpp_xor2(v));
+    v = fmaxf(v, dpp_half_mirror(v));
+    v = fmaxf(v, dpp_mirror(v));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict__ P, float *__restrict__ out,
+                                                         float *__restrict__ centroid, float *__restrict__ scale_out,
+                                                         int64_t B, int32_t N, int per_wave) {
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
+    const int64_t c0 = wave * per_wave;
+    const int nc = c0 < B ? static_cast<int>(min<int64_t>(per_wave, B - c0)) : 0;
+    const unsigned cloud_bytes = static_cast<unsigned>(N) * 12u;
+    const float inf = __builtin_huge_valf();
+    for (int j = 0; j < nc; ++j) {
+        const so3::rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P) + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        const so3::rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
+        // pass 1: bounding box.  Out-of-range lanes read zeros, which must not enter the box: they are masked by index.
+        float hi[3] = {-inf, -inf, -inf}, lo[3] = {inf, inf, inf};
+        for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
+            u32x3 pp[kCloudUnroll];
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) {
+                const bool in = i0 + 64 * u + lane < N;
+                const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
+                hi[0] = fmaxf(hi[0], in ? px : -inf); hi[1] = fmaxf(hi[1], in ? py : -inf); hi[2] = fmaxf(hi[2], in ? pz : -inf);
+                lo[0] = fminf(lo[0], in ? px : inf);  lo[1] = fminf(lo[1], in ? py : inf);  lo[2] = fminf(lo[2], in ? pz : inf);
+            }
+        }
+        float c[3], ext2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float mx = wave_allmax(hi[k]), mn = -wave_allmax(-lo[k]);
+            c[k] = (mx + mn) * 0.5f;                                   // prepare.py:52
+            const float e = (mx - c[k]) - (mn - c[k]);                 // :54 on the centred cloud
+            ext2 = fmaf(e, e, ext2);
+        }
+        const float sc = __builtin_amdgcn_sqrtf(ext2);
+        const float inv = 1.0f / sc;
+        if (lane == 0) {
+            if (centroid != nullptr) { centroid[(c0 + j) * 3 + 0] = c[0]; centroid[(c0 + j) * 3 + 1] = c[1]; centroid[(c0 + j) * 3 + 2] = c[2]; }
+            if (scale_out != nullptr) scale_out[c0 + j] = sc;
+        }
+        // pass 2: the cloud was just read (12 KB at N = 1024): it comes back from L2
+        for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
+            u32x3 pp[kCloudUnroll];
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kCloudUnroll; ++u) {
+                const float qx = (__uint_as_float(pp[u].x) - c[0]) * inv, qy = (__uint_as_float(pp[u].y) - c[1]) * inv,
+                            qz = (__uint_as_float(pp[u].z) - c[2]) * inv;
+                __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro,
+                                                      (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+            }
+        }
+    }
+}
+
 // ---- next row f6: the ADD-L1 losses that consume calculate_T_pred's output (Iterative/loss.py:10-48) ------------
 // dist_b = mean_{i,c} |(T_gt p_i - T_pred p_i)_c| = mean |dR p_i + dt|,  dR = R_gt - R_pred, dt = t_gt - t_pred, and
 // its gradient  dL/dR_pred[c][j] = -k sum_i sgn(d_ic) p_ij,  dL/dt_pred[c] = -k sum_i sgn(d_ic),  k = scale / (3 N),
@@ -1208,6 +1325,34 @@ int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const floa
     SO3_CHECK_ARGS(B == 0 || (Tgt != nullptr && Tpred != nullptr && points != nullptr), "so3_add_l1_disentangled_f32: null pointer");
     return launch_add_l1<true>(Tgt, Tpred, points, nullptr, loss_sum, dTpred, grad_scale, B, N, static_cast<hipStream_t>(stream),
                                "so3_add_l1_disentangled_f32");
+}
+
+int so3_rotate_clouds_f32(const float *P, const float *R, float *out, int transposed, int64_t B, int32_t N, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 300000000, "so3_rotate_clouds_f32: B/N");
+    if (B == 0 || N == 0) return 0;
+    SO3_CHECK_ARGS(P != nullptr && R != nullptr && out != nullptr, "so3_rotate_clouds_f32: null pointer");
+    int64_t per_wave = B / (256 * 16);
+    if (per_wave < 1) per_wave = 1;
+    if (per_wave > 64) per_wave = 64;
+    const int64_t waves = (B + per_wave - 1) / per_wave;
+    const dim3 grid(static_cast<unsigned>((waves + (kBlock / 64) - 1) / (kBlock / 64))), block(kBlock);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (transposed) hipLaunchKernelGGL((k_rotate_clouds<true>), grid, block, 0, s, P, R, out, B, N, static_cast<int>(per_wave));
+    else hipLaunchKernelGGL((k_rotate_clouds<false>), grid, block, 0, s, P, R, out, B, N, static_cast<int>(per_wave));
+    return check_launch("so3_rotate_clouds_f32");
+}
+
+int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *scale, int64_t B, int32_t N, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_pc_normalize_f32: B/N");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(P != nullptr && out != nullptr, "so3_pc_normalize_f32: null pointer");
+    int64_t per_wave = B / (256 * 16);
+    if (per_wave < 1) per_wave = 1;
+    if (per_wave > 64) per_wave = 64;
+    const int64_t waves = (B + per_wave - 1) / per_wave;
+    const dim3 grid(static_cast<unsigned>((waves + (kBlock / 64) - 1) / (kBlock / 64))), block(kBlock);
+    hipLaunchKernelGGL(k_pc_normalize, grid, block, 0, static_cast<hipStream_t>(stream), P, out, centroid, scale, B, N, static_cast<int>(per_wave));
+    return check_launch("so3_pc_normalize_f32");
 }
 
 size_t so3_angle_stats_workspace_bytes(void) { return sizeof(StatWork); }

@@ -333,6 +333,41 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
 
 
 # --------------------------------------------------------------------------------------------
+# row a7: the cloud side of the point-cloud path
+# --------------------------------------------------------------------------------------------
+def rotate_point_clouds(pc: torch.Tensor, R: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """q_bi = R_b p_bi for every point of every cloud: the pairing rule of point_cloud/main.py:173-181 (expand the
+    rotation to all points, bmm, view) in one launch.  pc: (B,N,3), R: (B,3,3).  Returns (B,N,3), or with
+    `transposed` the contiguous (B,3,N) tensor the reference obtains from `.transpose(1, 2)` at :183."""
+    dev = _require_device(pc, R)
+    if pc.dim() != 3 or pc.shape[-1] != 3 or R.numel() != pc.shape[0] * 9:
+        raise RuntimeError(f"rotate_point_clouds: expected (B, N, 3) and (B, 3, 3), got {tuple(pc.shape)} and {tuple(R.shape)}")
+    p = pc.detach().contiguous().float()
+    r = R.detach().reshape(-1, 9).contiguous().float()
+    b, n, _ = p.shape
+    out = torch.empty((b, 3, n) if transposed else (b, n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_rotate_clouds_f32(_ptr(p), _ptr(r), _ptr(out), 1 if transposed else 0, b, n, _stream(dev)), "so3_rotate_clouds_f32")
+    return out
+
+
+def pc_normalize(pc: torch.Tensor):
+    """Centre a cloud on its bounding box and scale by the box diagonal; point_cloud/prepare.py:51-56.
+    pc: (N,3) as the reference takes it, or a (B,N,3) batch.  Returns (pc, centroid, scale) like the reference
+    (centroid (3,) / (B,3); scale 0-dim / (B,)), float32 on the device."""
+    dev = _require_device(pc)
+    single = pc.dim() == 2
+    p = (pc.unsqueeze(0) if single else pc).detach().contiguous().float()
+    if p.dim() != 3 or p.shape[-1] != 3 or p.shape[1] < 1:
+        raise RuntimeError(f"pc_normalize: expected (N, 3) or (B, N, 3) with N >= 1, got {tuple(pc.shape)}")
+    b, n, _ = p.shape
+    out, cen, sc = torch.empty_like(p), torch.empty((b, 3), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().so3_pc_normalize_f32(_ptr(p), _ptr(out), _ptr(cen), _ptr(sc), b, n, _stream(dev)), "so3_pc_normalize_f32")
+    return (out[0], cen[0], sc[0]) if single else (out, cen, sc)
+
+
+# --------------------------------------------------------------------------------------------
 # next row f4: on-device pair synthesis for Kabsch
 # --------------------------------------------------------------------------------------------
 def get_sampled_rotation_matrices_by_axisAngle(batch: int, device="cuda", generator: torch.Generator = None) -> torch.Tensor:

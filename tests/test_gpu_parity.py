@@ -484,6 +484,39 @@ def test_head_tables_and_argument_errors(rr, pa):
 
 
 # ------------------------------------------------------------------------------------------------
+# row a7: cloud pairing (point_cloud/main.py:173-183) and pc_normalize (point_cloud/prepare.py:51-56)
+# ------------------------------------------------------------------------------------------------
+def test_g12_cloud_pairing_and_normalisation(rr):
+    from oracle import so3_oracle as so
+    g = load_golden("g12_clouds.npz")
+    out = rr.rotate_point_clouds(dev(g["pc1"]), dev(g["gt_rmat"]))
+    assert tuple(out.shape) == (6, 200, 3) and np.abs(out.cpu().numpy() - g["pc_out"]).max() < 3e-7
+    outt = rr.rotate_point_clouds(dev(g["pc1"]), dev(g["gt_rmat"]), transposed=True)
+    assert tuple(outt.shape) == (6, 3, 200) and outt.is_contiguous() and np.abs(outt.cpu().numpy() - g["gg"]).max() < 3e-7
+    n, c, s = rr.pc_normalize(dev(g["clouds"]))
+    assert np.abs(n.cpu().numpy() - g["norm"]).max() < 3e-7 and np.abs(c.cpu().numpy() - g["centroid"]).max() < 3e-7
+    assert np.abs(s.cpu().numpy() - g["scale"]).max() < 5e-7
+    n1, c1, s1 = rr.pc_normalize(dev(g["clouds"][2]))                       # the reference's single-cloud call
+    assert tuple(n1.shape) == (200, 3) and tuple(c1.shape) == (3,) and s1.dim() == 0
+    assert np.abs(n1.cpu().numpy() - g["norm"][2]).max() < 3e-7
+    for b, npts in ((1, 1), (3, 63), (2, 64), (5, 1000), (4099, 70), (256, 1024)):
+        p = torch.randn(b, npts, 3, device=DEV)
+        r = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
+        ref = so.rotate_clouds_np(p.cpu().numpy(), r.cpu().numpy())
+        assert np.abs(rr.rotate_point_clouds(p, r).cpu().numpy() - ref).max() < 2e-6
+        assert np.abs(rr.rotate_point_clouds(p, r, transposed=True).cpu().numpy() - ref.transpose(0, 2, 1)).max() < 2e-6
+        nn, cc, ss = rr.pc_normalize(p)
+        rn, rc, rs = so.pc_normalize_np(p.cpu().numpy())
+        if npts > 1:                                                         # a single point has a zero box: 0/0 as in numpy
+            assert np.abs(nn.cpu().numpy() - rn).max() < 2e-6 and np.abs(ss.cpu().numpy() - rs).max() < 2e-6 * max(1.0, rs.max())
+        assert np.abs(cc.cpu().numpy() - rc).max() < 1e-6
+    # the loop's pairing feeds Kabsch: rotate, then recover the rotation
+    p = torch.rand(512, 1024, 3, device=DEV) - 0.5
+    r = rr.get_sampled_rotation_matrices_by_axisAngle(512, DEV)
+    assert (rr.kabsch_rotation(p, rr.rotate_point_clouds(p, r)) - r).abs().max().item() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------
 # next row f6: the ADD-L1 losses after calculate_T_pred (Iterative/loss.py:10-70)
 # ------------------------------------------------------------------------------------------------
 def test_g11_add_l1_losses_and_gradients(rr):

@@ -217,6 +217,17 @@ def test_g11_add_l1_oracle():
     assert np.all(g["dis_grad_f64"][0] == 0)                                                 # exact hit: sgn(0) = 0
 
 
+def test_g12_cloud_prep_oracle():
+    """Row a7: pc_normalize against the reference function; the pairing rule against the loop's own statements."""
+    g = load_golden("g12_clouds.npz")
+    n, c, sc = so.pc_normalize_np(g["clouds"])
+    assert np.abs(n - g["norm"]).max() < 1e-15 and np.abs(c - g["centroid"]).max() < 1e-15 and np.abs(sc - g["scale"]).max() < 1e-15
+    one = so.pc_normalize_np(g["clouds"][3])
+    assert one[0].shape == (200, 3) and np.abs(one[0] - g["norm"][3]).max() < 1e-15
+    assert np.abs(so.rotate_clouds_np(g["pc1"], g["gt_rmat"]) - g["pc_out"]).max() < 2e-7
+    assert np.abs(so.rotate_clouds_np(g["pc1"], g["gt_rmat"], transposed=True) - g["gg"]).max() < 2e-7
+
+
 def test_g8_se3_update_oracle():
     """Next row f1: calculate_T_pred restated (float64) against the reference function's float32 output and autograd."""
     g = load_golden("g8_se3_update.npz")

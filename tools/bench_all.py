@@ -97,7 +97,11 @@ def main():
     sc = ctypes.c_float(1.0 / b)
     timeit("f6 so3_add_l1_f32 (loss + dTpred)", lambda i: lib.so3_add_l1_f32(p(tg), p(tq), p(pc[i % 2]), None, p(l3), p(dtq), sc, b, npts, st), b * (npts * 12 + 192), iters=10, warm=2)
     timeit("f6 so3_add_l1_disentangled_f32 (loss + dTpred)", lambda i: lib.so3_add_l1_disentangled_f32(p(tq), p(tg), p(pc[i % 2]), p(l3), p(dtq), sc, b, npts, st), b * (npts * 12 + 192), iters=10, warm=2)
-    del pc, tg, tq, dtq
+    qo = torch.empty(b, npts, 3, device=dev)
+    timeit("a7 so3_rotate_clouds_f32", lambda i: lib.so3_rotate_clouds_f32(p(pc[i % 2]), p(rg), p(qo), 0, b, npts, st), b * (npts * 24 + 36), iters=10, warm=2)
+    timeit("a7 so3_rotate_clouds_f32 (transposed out)", lambda i: lib.so3_rotate_clouds_f32(p(pc[i % 2]), p(rg), p(qo), 1, b, npts, st), b * (npts * 24 + 36), iters=10, warm=2)
+    timeit("a7 so3_pc_normalize_f32", lambda i: lib.so3_pc_normalize_f32(p(pc[i % 2]), p(qo), None, None, b, npts, st), b * (npts * 24), iters=10, warm=2)
+    del pc, tg, tq, dtq, qo
     torch.cuda.empty_cache()
     print("--- config #4: B = 512, bf16 storage, fused head + loss + backward ---")
     b = 512

@@ -165,6 +165,26 @@ def g11_add_l1():
     save("g11_add_l1.npz", **out)
 
 
+def g12_clouds():
+    """Row a7: pc_normalize (point_cloud/prepare.py:51-56, the reference function, numpy float64) and the training
+    loop's pairing rule (point_cloud/main.py:173-183), whose four statements are replayed here verbatim on CPU."""
+    (pc_normalize,) = functions_from(os.path.join(REF, "point_cloud", "prepare.py"), ["pc_normalize"])
+    rng = np.random.RandomState(12)
+    clouds = (rng.rand(6, 200, 3) - 0.5) * np.array([1.0, 2.0, 0.5]) + np.array([0.3, -1.0, 2.0])
+    norm, cent, scale = zip(*(pc_normalize(c) for c in clouds))
+    torch.manual_seed(12)
+    np.random.seed(12)
+    batch, point_num = 6, 200
+    pc1 = torch.tensor(np.stack(norm)).float()
+    gt_rmat = sample_rot(batch)
+    gt_rmats = gt_rmat.contiguous().view(batch, 1, 3, 3).expand(batch, point_num, 3, 3).contiguous().view(-1, 3, 3)   # :176-177
+    pc2 = torch.bmm(gt_rmats, pc1.view(-1, 3, 1))                                                                      # :180
+    pc_out = pc2.view(batch, point_num, 3)                                                                             # :181
+    gg = pc_out.transpose(1, 2)                                                                                        # :183
+    save("g12_clouds.npz", clouds=clouds, norm=np.stack(norm), centroid=np.stack(cent), scale=np.array(scale),
+         pc1=pc1, gt_rmat=gt_rmat, pc_out=pc_out, gg=gg.contiguous())
+
+
 def g10_heads():
     """Next row f5: the quaternion / Euler / 5D / exp-map heads (rotation_representation.py:39-171, 245-321) and
     their autograd, float32 as the reference runs them; float64 too where the reference's code keeps float64."""
@@ -205,11 +225,14 @@ def main():
         return g10_heads()
     if len(sys.argv) > 1 and sys.argv[1] == "g11":
         return g11_add_l1()
+    if len(sys.argv) > 1 and sys.argv[1] == "g12":
+        return g12_clouds()
     g7_ortho6d()
     g8_se3_update()
     g9_sampler()
     g10_heads()
     g11_add_l1()
+    g12_clouds()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
