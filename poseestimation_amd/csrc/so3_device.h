@@ -70,6 +70,7 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }                     // full-range libm forms
     static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+    static __device__ __forceinline__ void sincos(float x, float &s, float &c) { sincosf(x, &s, &c); }   // one range reduction
     // exponent that brings x into [0.5, 1), clamped so that 2^e stays finite (denormal input)
     static __device__ __forceinline__ int neg_frexp_exp(float x) { return min(-__builtin_amdgcn_frexp_expf(x), 126); }
     static __device__ __forceinline__ float ldexp(float x, int e) { return ldexpf(x, e); }
@@ -96,6 +97,13 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
     static __device__ __forceinline__ f32x2 sin(f32x2 x) { return f32x2{sinf(x.x), sinf(x.y)}; }
     static __device__ __forceinline__ f32x2 cos(f32x2 x) { return f32x2{cosf(x.x), cosf(x.y)}; }
+    static __device__ __forceinline__ void sincos(f32x2 x, f32x2 &s, f32x2 &c) {
+        float s0, c0, s1, c1;
+        sincosf(x.x, &s0, &c0);
+        sincosf(x.y, &s1, &c1);
+        s = f32x2{s0, s1};
+        c = f32x2{c0, c1};
+    }
     static __device__ __forceinline__ i32x2 neg_frexp_exp(f32x2 x) {
         return i32x2{min(-__builtin_amdgcn_frexp_expf(x.x), 126), min(-__builtin_amdgcn_frexp_expf(x.y), 126)};
     }

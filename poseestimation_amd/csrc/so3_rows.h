@@ -622,7 +622,10 @@ template <bool BWD> struct OpEuler : OpBase {
     __device__ __forceinline__ void compute(Rows<T, OpEuler> &rows, RowCtx<NPL> &) const {
         typedef Tr<T> R;
         const T (&e)[3] = rows.a;
-        const T c1 = R::cos(e[0]), s1 = R::sin(e[0]), c2 = R::cos(e[2]), s2 = R::sin(e[2]), c3 = R::cos(e[1]), s3 = R::sin(e[1]);
+        T c1, s1, c2, s2, c3, s3;
+        R::sincos(e[0], s1, c1);
+        R::sincos(e[2], s2, c2);
+        R::sincos(e[1], s3, c3);
         T r[9];
         r[0] = c2 * c3;                     r[1] = -s2;     r[2] = c2 * s3;
         r[3] = R::fma(c1 * s2, c3, s1 * s3); r[4] = c1 * c2; r[5] = R::fma(c1 * s2, s3, -(s1 * c3));
@@ -693,7 +696,9 @@ template <bool BWD> struct OpExpMap : OpBase {
         const T t2 = R::max(nrm, R::splat(kExpMapEps));
         const T it = R::rsq(t2);
         const T t = t2 * it;
-        const T st = R::sin(t), sh = R::sin(t * R::splat(0.5f));
+        T st, ct;
+        R::sincos(t, st, ct);
+        const T sh = R::sin(t * R::splat(0.5f));
         const T f1 = st * it;
         const T f2 = R::splat(2.f) * sh * sh * it * it;              // (1 - cos t)/t^2 without the cancellation
         if constexpr (!BWD) {
@@ -714,7 +719,6 @@ template <bool BWD> struct OpExpMap : OpBase {
             const T df1 = dot(v, a);                                                       // dL/dfac1 = <G, K>
             const T df2 = R::fma(R::splat(0.5f), dot(v, sv), -(nrm * tr));                 // dL/dfac2 = <G, K^2>
             // (dfac/dtheta)/theta: closed forms cancel badly for small theta -> series below theta = 1
-            const T ct = R::cos(t);
             const T it3 = it * it * it;
             const T a1c = R::fma(t, ct, -st) * it3;
             const T a2c = R::fma(t, st, -(R::splat(4.f) * sh * sh)) * it3 * it;
