@@ -811,3 +811,47 @@ def test_fused_head_angle_error_matches_two_kernel_path(rr):
     assert (r - rr.symmetric_orthogonalization(x[:1000])).abs().max().item() == 0
     with pytest.raises(ValueError, match="angle out of range"):
         rr.head_angle_error(x[:128], 1.7 * t[:128])
+
+
+# ------------------------------------------------------------------------------------------------
+# drop-in check: the reference's comparison experiment (Comparison/models.py:14-43, Comparison/main.py:43-66)
+# trained with the library's heads and with the oracle's ATen restatements, same weights, same data
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key", ["SVD", "6D", "5D", "Quat", "Euler"])
+def test_comparison_experiment_trains_identically(rr, pa, key):
+    from oracle import so3_oracle as so
+    ref_heads = {"SVD": so.symmetric_orthogonalization_torch, "6D": so.ortho6d_torch, "5D": so.ortho5d_torch,
+                 "Quat": so.quat_torch, "Euler": so.euler_torch}
+
+    def make_model():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Linear(9, 128), torch.nn.ReLU(), torch.nn.Linear(128, 64), torch.nn.ReLU(),
+                                   torch.nn.Linear(64, pa.head_dimensions[key])).double()
+
+    gen = torch.Generator().manual_seed(17)
+    target = so.symmetric_orthogonalization_torch(torch.randn(20, 128, 9, generator=gen).double()).reshape(20, 128, 3, 3)   # (steps, batch, 3, 3)
+    inputs = target.reshape(20, 128, 9) + 0.05 * torch.randn(20, 128, 9, generator=gen).double()
+
+    # Step by step: the float64 reference model (CPU, the reference's ops) leads; at every step the library model
+    # (float32, device) starts from the same weights, and its loss and parameter gradients must agree.  (Free-running
+    # float32 and float64 trajectories drift apart after ~10 steps through the head's ill-conditioned rows.)
+    m_ref = make_model()
+    m = make_model().float().to(DEV)
+    opt = torch.optim.SGD(m_ref.parameters(), lr=0.01)
+    first, last = None, None
+    for x, r in zip(inputs, target):
+        m.load_state_dict({k: v.float() for k, v in m_ref.state_dict().items()})
+        opt.zero_grad()
+        loss_ref = so.loss_frobenius_torch(ref_heads[key](m_ref(x)), r)
+        loss_ref.backward()
+        m.zero_grad()
+        loss = rr.loss_frobenius(pa.head_functions[key](m(x.float().to(DEV))), r.float().to(DEV))
+        loss.backward()
+        assert abs(loss.item() - loss_ref.item()) < 2e-6 * max(1.0, loss_ref.item())
+        for a, b in zip(m.parameters(), m_ref.parameters()):
+            ga, gb = a.grad.detach().cpu().double(), b.grad.detach()
+            assert (ga - gb).norm().item() < 1e-3 * gb.norm().item() + 1e-9, (key, (ga - gb).norm().item(), gb.norm().item())
+        opt.step()
+        first = loss_ref.item() if first is None else first
+        last = loss_ref.item()
+    assert last < first                                       # and it does train
