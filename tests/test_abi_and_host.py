@@ -32,6 +32,35 @@ def test_binding_table_matches_header(built_library):
     assert lib.so3_last_error() == b""
 
 
+def build_c_demo(built_library, out_dir):
+    """examples/c_abi_demo.c compiled as C11 against include/so3proj.h and the shared library (plain gcc, no hipcc)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"):
+        pytest.skip("gcc or the ROCm headers are not available")
+    exe = os.path.join(str(out_dir), "c_abi_demo")
+    libdir = os.path.dirname(built_library)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"),
+                           "-L" + libdir, "-lso3proj", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_links(built_library, tmp_path):
+    """The boundary is usable without C++, Python or torch: the demo compiles as C11 and links against the .so."""
+    assert os.path.exists(build_c_demo(built_library, tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_demo_runs_on_the_gpu(built_library, tmp_path):
+    import subprocess
+    exe = build_c_demo(built_library, tmp_path)
+    for rows in ("100003", "64", "1"):
+        res = subprocess.run([exe, rows], capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
 def test_argument_validation_without_gpu(built_library):
     """Bad arguments are rejected on the host before any launch (no GPU needed)."""
     from poseestimation_amd import _lib
