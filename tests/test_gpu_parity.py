@@ -675,6 +675,44 @@ def test_config5_shard_size_sixteen_million_rows(rr):
     assert sc[1].item() == n and sc[0].item() / n < 0.05                        # ~0 degrees up to acos noise
 
 
+def test_offsets_past_four_gigabytes(rr, c_oracle):
+    """120M rows: each array is 4.32 GB, so unit byte offsets cross 2^32.  Checked in windows (start, around the
+    2^32-byte boundary, end) against the C oracle, and by the device-side properties on every row."""
+    n = 120_000_001                                         # odd: the last unit is a 1-row remainder for the tile kernel
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.empty(n, 9, device=DEV)
+    for lo in range(0, n, 20_000_000):                      # fill in slabs: randn of 1e9 elements at once needs no extra 4 GB
+        hi = min(n, lo + 20_000_000)
+        x[lo:hi] = torch.randn(hi - lo, 9, device=DEV, generator=gen)
+    r, flip = rr.symmetric_orthogonalization_with_flip(x)
+    boundary = (1 << 32) // 36
+    for lo in (0, boundary - 500, n - 1000):
+        xs = x[lo:lo + 1000].cpu().numpy()
+        ref = c_oracle.project(xs)
+        err = np.abs(r[lo:lo + 1000].cpu().numpy() - ref).reshape(1000, -1).max(1)
+        assert np.median(err) < 5e-7 and err.max() < 1e-3, (lo, err.max())
+        assert np.array_equal(flip[lo:lo + 1000].cpu().numpy(), np.linalg.det(xs.reshape(-1, 3, 3).astype(np.float64)) < 0)
+    worst, mismatches = 0.0, 0
+    for lo in range(0, n, 20_000_000):                      # element-wise (a 20M-batch bmm aborts inside rocBLAS)
+        blk = r[lo:lo + 20_000_000]
+        e = torch.zeros(blk.shape[0], device=DEV)
+        for i in range(3):
+            for j in range(i, 3):
+                d = (blk[:, :, i] * blk[:, :, j]).sum(1) - (1.0 if i == j else 0.0)
+                e += (1.0 if i == j else 2.0) * d * d
+        worst = max(worst, e.sqrt().max().item())
+        m = x[lo:lo + 20_000_000].view(-1, 3, 3).double()
+        det = (m[:, 0, 0] * (m[:, 1, 1] * m[:, 2, 2] - m[:, 1, 2] * m[:, 2, 1]) - m[:, 0, 1] * (m[:, 1, 0] * m[:, 2, 2] - m[:, 1, 2] * m[:, 2, 0])
+               + m[:, 0, 2] * (m[:, 1, 0] * m[:, 2, 1] - m[:, 1, 1] * m[:, 2, 0]))
+        mismatches += int(((det < 0) != flip[lo:lo + 20_000_000]).sum())
+        del blk, e, m, det
+    assert worst < 1e-5 and mismatches == 0
+    sc = rr.angle_error_sum_count(r, r)
+    assert sc[1].item() == n and sc[0].item() / n < 0.05
+    del x, r, flip
+    torch.cuda.empty_cache()
+
+
 def test_engine_dtype_paths_at_size(rr, c_oracle):
     """bf16 in / bf16 gradients and the flip variant through the streaming engine (not the remainder kernels)."""
     n = 100_000 + 37                                                           # 1562 units + a 69-row remainder
