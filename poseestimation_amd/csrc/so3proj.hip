@@ -1316,21 +1316,21 @@ SO3_DEFINE_HEAD(expmap, OpExpMap)
 
 int so3_add_l1_f32(const float *Tgt, const float *Tpred, const float *points, float *dists, double *loss_sum, float *dTpred,
                    float grad_scale, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_add_l1_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 150000000, "so3_add_l1_f32: B/N");
     SO3_CHECK_ARGS(B == 0 || (Tgt != nullptr && Tpred != nullptr && points != nullptr), "so3_add_l1_f32: null pointer");
     return launch_add_l1<false>(Tgt, Tpred, points, dists, loss_sum, dTpred, grad_scale, B, N, static_cast<hipStream_t>(stream), "so3_add_l1_f32");
 }
 
 int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const float *points, double *loss_sum, float *dTpred,
                                 float grad_scale, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_add_l1_disentangled_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 150000000, "so3_add_l1_disentangled_f32: B/N");
     SO3_CHECK_ARGS(B == 0 || (Tgt != nullptr && Tpred != nullptr && points != nullptr), "so3_add_l1_disentangled_f32: null pointer");
     return launch_add_l1<true>(Tgt, Tpred, points, nullptr, loss_sum, dTpred, grad_scale, B, N, static_cast<hipStream_t>(stream),
                                "so3_add_l1_disentangled_f32");
 }
 
 int so3_rotate_clouds_f32(const float *P, const float *R, float *out, int transposed, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 300000000, "so3_rotate_clouds_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 150000000, "so3_rotate_clouds_f32: B/N");
     if (B == 0 || N == 0) return 0;
     SO3_CHECK_ARGS(P != nullptr && R != nullptr && out != nullptr, "so3_rotate_clouds_f32: null pointer");
     int64_t per_wave = B / (256 * 16);
@@ -1345,7 +1345,7 @@ int so3_rotate_clouds_f32(const float *P, const float *R, float *out, int transp
 }
 
 int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *scale, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 300000000, "so3_pc_normalize_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 150000000, "so3_pc_normalize_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(P != nullptr && out != nullptr, "so3_pc_normalize_f32: null pointer");
     int64_t per_wave = B / (256 * 16);
@@ -1411,7 +1411,7 @@ int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R
 
 int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t seed, float *R, float *H, int64_t B, int32_t N,
                          void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 300000000, "so3_kabsch_synth_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 150000000, "so3_kabsch_synth_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R != nullptr && Rgt != nullptr && (N == 0 || P != nullptr), "so3_kabsch_synth_f32: null pointer");
     int64_t cpw = B / (256 * 16);
@@ -1425,7 +1425,7 @@ int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t
 }
 
 int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B, int32_t N, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 40) && N >= 0 && N <= 300000000, "so3_kabsch_f32: B/N");
+    SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 40) && N >= 0 && N <= 150000000, "so3_kabsch_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R != nullptr && (N == 0 || (P != nullptr && Q != nullptr)), "so3_kabsch_f32: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
