@@ -14,7 +14,12 @@ st = P(torch.cuda.current_stream().cuda_stream)
 NB = 6
 
 
+QUICK = os.environ.get("SO3_BENCH_QUICK") == "1"      # 2 calls per entry: for rocprofv3 --pmc passes (kernels are serialised)
+
+
 def timeit(name, fn, bytes_per_call, iters=60, warm=5):
+    if QUICK:
+        iters, warm = 2, 1
     for i in range(warm): fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
