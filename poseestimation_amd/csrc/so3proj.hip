@@ -589,9 +589,12 @@ __device__ __forceinline__ float wave_allmax(float v) {
     return v;
 }
 
+// HOLD > 0: the whole cloud (N <= 64 * HOLD points) stays in registers between the two passes: one HBM read.
+template <int HOLD>
 __global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict__ P, float *__restrict__ out,
                                                          float *__restrict__ centroid, float *__restrict__ scale_out,
                                                          int64_t B, int32_t N, int per_wave) {
+    constexpr int kU = HOLD > 0 ? HOLD : kCloudUnroll;
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t wave = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave_in_block;
@@ -604,12 +607,12 @@ __global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict
         const so3::rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (c0 + j) * N * 3, 0, cloud_bytes, so3::kRsrcFlags);
         // pass 1: bounding box.  Out-of-range lanes read zeros, which must not enter the box: they are masked by index.
         float hi[3] = {-inf, -inf, -inf}, lo[3] = {inf, inf, inf};
-        for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
-            u32x3 pp[kCloudUnroll];
+        u32x3 pp[kU];
+        for (int i0 = 0; i0 < N; i0 += 64 * kU) {
 #pragma unroll
-            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, 0);
+            for (int u = 0; u < kU; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, HOLD > 0 ? so3::kStreamCpol : 0);
 #pragma unroll
-            for (int u = 0; u < kCloudUnroll; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 const bool in = i0 + 64 * u + lane < N;
                 const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
                 hi[0] = fmaxf(hi[0], in ? px : -inf); hi[1] = fmaxf(hi[1], in ? py : -inf); hi[2] = fmaxf(hi[2], in ? pz : -inf);
@@ -630,13 +633,14 @@ __global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict
             if (centroid != nullptr) { centroid[(c0 + j) * 3 + 0] = c[0]; centroid[(c0 + j) * 3 + 1] = c[1]; centroid[(c0 + j) * 3 + 2] = c[2]; }
             if (scale_out != nullptr) scale_out[c0 + j] = sc;
         }
-        // pass 2: the cloud was just read (12 KB at N = 1024): it comes back from L2
-        for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
-            u32x3 pp[kCloudUnroll];
+        // pass 2: from the registers when the cloud fits, otherwise a second read (mostly served by L2 / Infinity Cache)
+        for (int i0 = 0; i0 < N; i0 += 64 * kU) {
+            if (HOLD == 0) {
 #pragma unroll
-            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, 0);
+                for (int u = 0; u < kU; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, 0);
+            }
 #pragma unroll
-            for (int u = 0; u < kCloudUnroll; ++u) {
+            for (int u = 0; u < kU; ++u) {
                 const float qx = (__uint_as_float(pp[u].x) - c[0]) * inv, qy = (__uint_as_float(pp[u].y) - c[1]) * inv,
                             qz = (__uint_as_float(pp[u].z) - c[2]) * inv;
                 __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro,
@@ -1353,7 +1357,11 @@ int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *sca
     if (per_wave > 64) per_wave = 64;
     const int64_t waves = (B + per_wave - 1) / per_wave;
     const dim3 grid(static_cast<unsigned>((waves + (kBlock / 64) - 1) / (kBlock / 64))), block(kBlock);
-    hipLaunchKernelGGL(k_pc_normalize, grid, block, 0, static_cast<hipStream_t>(stream), P, out, centroid, scale, B, N, static_cast<int>(per_wave));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int pw = static_cast<int>(per_wave);
+    if (N <= 256) hipLaunchKernelGGL((k_pc_normalize<4>), grid, block, 0, s, P, out, centroid, scale, B, N, pw);
+    else if (N <= 1024) hipLaunchKernelGGL((k_pc_normalize<16>), grid, block, 0, s, P, out, centroid, scale, B, N, pw);
+    else hipLaunchKernelGGL((k_pc_normalize<0>), grid, block, 0, s, P, out, centroid, scale, B, N, pw);
     return check_launch("so3_pc_normalize_f32");
 }
 

@@ -499,7 +499,7 @@ def test_g12_cloud_pairing_and_normalisation(rr):
     n1, c1, s1 = rr.pc_normalize(dev(g["clouds"][2]))                       # the reference's single-cloud call
     assert tuple(n1.shape) == (200, 3) and tuple(c1.shape) == (3,) and s1.dim() == 0
     assert np.abs(n1.cpu().numpy() - g["norm"][2]).max() < 3e-7
-    for b, npts in ((1, 1), (3, 63), (2, 64), (5, 1000), (4099, 70), (256, 1024)):
+    for b, npts in ((1, 1), (3, 63), (2, 64), (5, 1000), (4099, 70), (256, 1024), (3, 3001)):   # 3001 > 1024: the two-pass variant
         p = torch.randn(b, npts, 3, device=DEV)
         r = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
         ref = so.rotate_clouds_np(p.cpu().numpy(), r.cpu().numpy())
