@@ -65,6 +65,12 @@ int so3_project_fwd_bf16(const void *M, float *R, uint8_t *flip, int64_t B, void
 int so3_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B, void *stream);
 int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, void *stream);
 
+/* float64 variants (the reference's functions accept double tensors; callers on the hot path never pass them):
+ * M, R, G, dM are B*9 float64.  Same algorithm in float64 arithmetic, sweeps repeated until the residual is below
+ * 1e-14; one row per thread, not tuned.  flip (nullable) as above. */
+int so3_project_fwd_f64(const double *M, double *R, uint8_t *flip, int64_t B, void *stream);
+int so3_project_bwd_f64(const double *M, const double *G, double *dM, int64_t B, void *stream);
+
 /* ---- K3: fused head forward + Frobenius loss + backward (config #4) ------------------------------
  * loss = mean_b ||Rtrue_b - R_b||_F  (3D-Pose/loss.py:7-11; NOT squared),  dM = dloss/dM.
  * Replaces the chain 3D-Pose/main.py:60 (head), :85 (loss), :90 (backward) in one launch.

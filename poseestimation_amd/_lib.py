@@ -22,6 +22,8 @@ SYMBOLS = {
     "so3_project_fwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_project_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_project_bwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_project_fwd_f64": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_project_bwd_f64": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_frob_fwd_bwd_f32": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
     "so3_frob_fwd_bwd_bf16": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
     "so3_frob_loss_f32": (_INT, [_P, _P, _P, _P, _I64, _P]),

@@ -48,6 +48,13 @@ constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
 constexpr float kTinyNorm2 = 1e-30f;
 constexpr float kTieBreak = 1.0f - 4e-6f;
+// The same four for float64 arithmetic (so3_project_*_f64): tolerance (1e-14)^2, and sweeps run until it is met.
+template <class S> struct Consts {          // S = float
+    static constexpr float tol2 = kResidualTol2, delta = kDelta, tiny = kTinyNorm2, tie = kTieBreak, bwd_rel = 1e-12f, bwd_abs = 1e-30f;
+};
+template <> struct Consts<double> {
+    static constexpr double tol2 = 1e-28, delta = 1e-150, tiny = 1e-280, tie = 1.0 - 1e-13, bwd_rel = 1e-24, bwd_abs = 1e-290;
+};
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -57,6 +64,7 @@ template <class T> struct Tr;
 template <> struct Tr<float> {
     typedef bool mask;
     typedef int ivec;
+    typedef float scalar;
     static constexpr int kLanes = 1;
     static __device__ __forceinline__ float splat(float v) { return v; }
     static __device__ __forceinline__ float get(float v, int) { return v; }
@@ -84,6 +92,7 @@ template <> struct Tr<float> {
 template <> struct Tr<f32x2> {
     typedef i32x2 mask;     // all-ones / zero per component
     typedef i32x2 ivec;
+    typedef float scalar;
     static constexpr int kLanes = 2;
     static __device__ __forceinline__ f32x2 splat(float v) { return f32x2{v, v}; }
     static __device__ __forceinline__ float get(f32x2 v, int i) { return i ? v.y : v.x; }
@@ -116,6 +125,31 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ bool lane_of(i32x2 m, int i) { return (i ? m.y : m.x) != 0; }
 };
 
+template <> struct Tr<double> {           // one matrix per lane in float64 (so3_project_*_f64; not a benchmark path)
+    typedef bool mask;
+    typedef int ivec;
+    typedef double scalar;
+    static constexpr int kLanes = 1;
+    static __device__ __forceinline__ double splat(double v) { return v; }
+    static __device__ __forceinline__ double get(double v, int) { return v; }
+    static __device__ __forceinline__ void set(double &v, int, double x) { v = x; }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double abs(double a) { return __builtin_fabs(a); }
+    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double copysign(double a, double b) { return __builtin_copysign(a, b); }
+    static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }          // correctly rounded
+    static __device__ __forceinline__ double rsq(double x) { return 1.0 / __builtin_sqrt(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ int neg_frexp_exp(double x) { return min(-__builtin_amdgcn_frexp_exp(x), 1022); }
+    static __device__ __forceinline__ double ldexp(double x, int e) { return ::ldexp(x, e); }
+    static __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+    static __device__ __forceinline__ bool le(double a, double b) { return a <= b; }
+    static __device__ __forceinline__ bool ge(double a, double b) { return a >= b; }
+    static __device__ __forceinline__ bool gt(double a, double b) { return a > b; }
+    static __device__ __forceinline__ bool any(bool m) { return m; }
+    static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
+};
+
 // ---- 3-vectors over T -----------------------------------------------------------------------------
 template <class T> struct V3 {
     T x, y, z;
@@ -145,7 +179,7 @@ template <class T> __device__ __forceinline__ void rotate(V3<T> &p, V3<T> &q) {
     const T d = al - be;
     const T g = ga + ga;
     const T gg = g * g;
-    const T h = R::sqrt(R::fma(d, d, gg)) + R::splat(kDelta);
+    const T h = R::sqrt(R::fma(d, d, gg)) + R::splat(Consts<typename R::scalar>::delta);
     const T ae = d + R::copysign(h, d);
     const T rw = R::rsq(R::fma(ae, ae, gg));
     const T c = ae * rw, s = g * rw;
@@ -159,13 +193,13 @@ template <class T> __device__ __forceinline__ void rotate(V3<T> &p, V3<T> &q) {
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
 // A unit vector orthogonal to the unit vector u: e_k x u, k = index of the smallest |u_k| (z first).
-__device__ __forceinline__ V3<float> any_perp(V3<float> u) {
-    const float ax = fabsf(u.x), ay = fabsf(u.y), az = fabsf(u.z);
-    V3<float> w;
-    if (az <= ax && az <= ay) w = mk<float>(-u.y, u.x, 0.f);
-    else if (ay <= ax) w = mk<float>(u.z, 0.f, -u.x);
-    else w = mk<float>(0.f, -u.z, u.y);
-    return scale<float>(w, __builtin_amdgcn_rsqf(dot(w, w)));
+template <class S> __device__ __forceinline__ V3<S> any_perp(V3<S> u) {
+    const S ax = Tr<S>::abs(u.x), ay = Tr<S>::abs(u.y), az = Tr<S>::abs(u.z);
+    V3<S> w;
+    if (az <= ax && az <= ay) w = mk<S>(-u.y, u.x, S(0));
+    else if (ay <= ax) w = mk<S>(u.z, S(0), -u.x);
+    else w = mk<S>(S(0), -u.z, u.y);
+    return scale<S>(w, Tr<S>::rsq(dot(w, w)));
 }
 
 template <class T> struct SignedSvd {
@@ -175,25 +209,28 @@ template <class T> struct SignedSvd {
     T inv_scale;        // M_prescaled = M * 2^k ;  inv_scale = 2^k  (multiply gradients by it)
 };
 
-template <class T> __device__ __forceinline__ V3<float> lane3(V3<T> v, int i) {
-    return mk<float>(Tr<T>::get(v.x, i), Tr<T>::get(v.y, i), Tr<T>::get(v.z, i));
+template <class T> __device__ __forceinline__ V3<typename Tr<T>::scalar> lane3(V3<T> v, int i) {
+    return mk<typename Tr<T>::scalar>(Tr<T>::get(v.x, i), Tr<T>::get(v.y, i), Tr<T>::get(v.z, i));
 }
-template <class T> __device__ __forceinline__ void set_lane3(V3<T> &v, int i, V3<float> s) {
+template <class T> __device__ __forceinline__ void set_lane3(V3<T> &v, int i, V3<typename Tr<T>::scalar> s) {
     Tr<T>::set(v.x, i, s.x); Tr<T>::set(v.y, i, s.y); Tr<T>::set(v.z, i, s.z);
 }
 
 // m: row-major 3x3 (m[3*i+j]).  WANT_S: also fill s1,s2,s3 (backward needs them).
 // SWEEPS fixed sweeps; ADAPT: plus one more when the wave-wide residual test fails.
-template <bool WANT_S, class T, int SWEEPS = kSweeps, bool ADAPT = true>
+// MAX_EXTRA: how many adaptive sweeps may follow (1 for float32: a fourth sweep reaches round-off).
+template <bool WANT_S, class T, int SWEEPS = kSweeps, bool ADAPT = true, int MAX_EXTRA = 1>
 __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     typedef Tr<T> R;
+    typedef typename R::scalar S;
+    typedef Consts<S> K;
     SignedSvd<T> o;
     // 1. exact power-of-two prescale: largest |entry| lands in [0.5, 1)
     T mx = R::max(R::max(R::abs(m_in[0]), R::abs(m_in[1])), R::abs(m_in[2]));
     mx = R::max(mx, R::max(R::max(R::abs(m_in[3]), R::abs(m_in[4])), R::abs(m_in[5])));
     mx = R::max(mx, R::max(R::max(R::abs(m_in[6]), R::abs(m_in[7])), R::abs(m_in[8])));
     const typename R::ivec ex = R::neg_frexp_exp(mx);    // 0 for mx == 0; finite for inf/NaN too
-    const T sc = R::ldexp(R::splat(1.0f), ex);
+    const T sc = R::ldexp(R::splat(S(1)), ex);
     T m[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] = m_in[i] * sc;     // exact: sc is a power of two
@@ -213,19 +250,22 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     //     gamma_01^2  <=  tol^2 |a_0|^2 |a_1|^2 .
     T n0 = dot(a0, a0), n1 = dot(a1, a1), n2 = dot(a2, a2);
     if (ADAPT) {
-        const T g01 = dot(a0, a1);
-        if (wave_any(R::any(R::gt(g01 * g01, n0 * n1 * R::splat(kResidualTol2))))) {   // NaN / zero rows compare false
+        int extra = 0;
+        while (true) {
+            const T g01 = dot(a0, a1);
+            if (!wave_any(R::any(R::gt(g01 * g01, n0 * n1 * R::splat(K::tol2))))) break;   // NaN / zero rows compare false
             rotate(a0, a1);
             rotate(a0, a2);
             rotate(a1, a2);
             n0 = dot(a0, a0); n1 = dot(a1, a1); n2 = dot(a2, a2);
+            if (MAX_EXTRA == 1 || ++extra >= MAX_EXTRA) break;      // (compile-time exit for the float32 kernels)
         }
     }
 
     // 3. smallest column last, cyclic order kept (so det of the implied V stays +1).
     // Ties (equal singular values to within a few ulp, e.g. diag(1,1,-1)) go to the LAST column, as
     // LAPACK's ordering does: the reference then maps a pure reflection to the identity.
-    const T n2t = n2 * R::splat(kTieBreak);
+    const T n2t = n2 * R::splat(K::tie);
     const typename R::mask z2 = R::le(n2t, n0) & R::le(n2t, n1);
     const typename R::mask z0 = R::le(n0, n1);
     const V3<T> x = sel<T>(z2, a0, sel<T>(z0, a1, a2));
@@ -261,32 +301,32 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
 
     // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.
     // (`<=` comparisons are false for NaN, so NaN input flows through the fast path to NaN output.)
-    const T tiny = R::splat(kTinyNorm2);
+    const T tiny = R::splat(K::tiny);
     const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, tiny) | R::le(nt1, tiny) | R::le(nr2, tiny);
     if (__builtin_expect(R::any(degenerate), 0)) {
 #pragma unroll
         for (int i = 0; i < R::kLanes; ++i) {
             if (R::lane_of(degenerate, i)) {
-            const float f0 = R::get(n0, i), f1 = R::get(n1, i), f2 = R::get(n2, i);
+            const S f0 = R::get(n0, i), f1 = R::get(n1, i), f2 = R::get(n2, i);
             const bool b0 = (f0 >= f1) && (f0 >= f2);
             const bool b1 = (f1 >= f2);
-            const V3<float> big = b0 ? lane3<T>(a0, i) : (b1 ? lane3<T>(a1, i) : lane3<T>(a2, i));
-            const float nb = b0 ? f0 : (b1 ? f1 : f2);
-            const V3<float> q0 = lane3<T>(mr0, i), q1 = lane3<T>(mr1, i), q2 = lane3<T>(mr2, i);
-            V3<float> su1, sv1;
-            if (nb <= kTinyNorm2) {                  // M == 0  ->  identity (matches the reference)
-                su1 = mk<float>(1.f, 0.f, 0.f);
+            const V3<S> big = b0 ? lane3<T>(a0, i) : (b1 ? lane3<T>(a1, i) : lane3<T>(a2, i));
+            const S nb = b0 ? f0 : (b1 ? f1 : f2);
+            const V3<S> q0 = lane3<T>(mr0, i), q1 = lane3<T>(mr1, i), q2 = lane3<T>(mr2, i);
+            V3<S> su1, sv1;
+            if (nb <= K::tiny) {                     // M == 0  ->  identity (matches the reference)
+                su1 = mk<S>(S(1), S(0), S(0));
                 sv1 = su1;
             } else {
-                su1 = scale<float>(big, __builtin_amdgcn_rsqf(nb));
-                const V3<float> st1 = axpy<float>(su1.z, q2, axpy<float>(su1.y, q1, scale<float>(q0, su1.x)));
-                sv1 = scale<float>(st1, __builtin_amdgcn_rsqf(dot(st1, st1)));
+                su1 = scale<S>(big, Tr<S>::rsq(nb));
+                const V3<S> st1 = axpy<S>(su1.z, q2, axpy<S>(su1.y, q1, scale<S>(q0, su1.x)));
+                sv1 = scale<S>(st1, Tr<S>::rsq(dot(st1, st1)));
             }
             set_lane3<T>(u1, i, su1);
             set_lane3<T>(v1, i, sv1);
-            set_lane3<T>(u2, i, any_perp(su1));
-            set_lane3<T>(v2, i, any_perp(sv1));
-            if (WANT_S) { R::set(nt1, i, nb); R::set(nr2, i, 0.f); }
+            set_lane3<T>(u2, i, any_perp<S>(su1));
+            set_lane3<T>(v2, i, any_perp<S>(sv1));
+            if (WANT_S) { R::set(nt1, i, nb); R::set(nr2, i, S(0)); }
             }
         }
     }
@@ -298,7 +338,7 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         o.s2 = nr2 * R::rsq(R::max(nr2, tiny));
         o.s3 = dot(o.u3, z);
     } else {
-        o.s1 = o.s2 = o.s3 = R::splat(0.f);
+        o.s1 = o.s2 = o.s3 = R::splat(S(0));
     }
     return o;
 }
@@ -345,7 +385,7 @@ __device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T 
     const T a12 = dot(f.u1, gv2), a21 = dot(f.u2, gv1);
     const T a13 = dot(f.u1, gv3), a31 = dot(f.u3, gv1);
     const T a23 = dot(f.u2, gv3), a32 = dot(f.u3, gv2);
-    const T floor_ = R::fma(R::splat(1e-12f), f.s1, R::splat(1e-30f));
+    const T floor_ = R::fma(R::splat(Consts<typename R::scalar>::bwd_rel), f.s1, R::splat(Consts<typename R::scalar>::bwd_abs));
     const T k = f.inv_scale;                         // singular values are in prescaled units
     const T b12 = (a12 - a21) * k * R::rcp(R::max(f.s1 + f.s2, floor_));
     const T b13 = (a13 - a31) * k * R::rcp(R::max(f.s1 + f.s3, floor_));

@@ -767,6 +767,43 @@ __global__ __launch_bounds__(kBlock) void k_add_l1(const float *__restrict__ Tgt
     }
 }
 
+// ---- float64 head and backward (the reference's functions accept double tensors): the same templates over
+// T = double, one row per thread with plain loads -- a convenience path, not a benchmark configuration.
+// Four fixed sweeps, then sweeps until the wave-wide residual is below 1e-14 (at most six more).
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void k_project_f64(const double *__restrict__ M, const double *__restrict__ G,
+                                                        double *__restrict__ out, uint8_t *__restrict__ flip, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const bool live = row < B;
+    const int64_t rr_ = live ? row : 0;                         // idle lanes recompute row 0: keeps the sweep loop wave-uniform
+    double m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = M[rr_ * 9 + i];
+    if (!BWD) {
+        const auto f = so3::signed_svd<false, double, 4, true, 6>(m);
+        double r[9];
+        so3::rotation_from(f, r);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) out[row * 9 + i] = r[i];
+            if (flip != nullptr) {
+                const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+                flip[row] = det < 0.0 ? 1 : 0;
+            }
+        }
+    } else {
+        double g[9], dm[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = G[rr_ * 9 + i];
+        const auto f = so3::signed_svd<true, double, 4, true, 6>(m);
+        so3::project_backward(f, g, dm);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) out[row * 9 + i] = dm[i];
+        }
+    }
+}
+
 // ---- 6D head, one row per thread: remainder (< 64 rows) and unaligned input of the streaming kernels ----------
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_ortho6d_rows(const float *__restrict__ X, const float *__restrict__ G,
@@ -1363,6 +1400,22 @@ int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *sca
     else if (N <= 1024) hipLaunchKernelGGL((k_pc_normalize<16>), grid, block, 0, s, P, out, centroid, scale, B, N, pw);
     else hipLaunchKernelGGL((k_pc_normalize<0>), grid, block, 0, s, P, out, centroid, scale, B, N, pw);
     return check_launch("so3_pc_normalize_f32");
+}
+
+int so3_project_fwd_f64(const double *M, double *R, uint8_t *flip, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd_f64: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && R != nullptr, "so3_project_fwd_f64: null pointer");
+    hipLaunchKernelGGL((k_project_f64<false>), dim3(grid_for(B)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), M, nullptr, R, flip, B);
+    return check_launch("so3_project_fwd_f64");
+}
+
+int so3_project_bwd_f64(const double *M, const double *G, double *dM, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_bwd_f64: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && G != nullptr && dM != nullptr, "so3_project_bwd_f64: null pointer");
+    hipLaunchKernelGGL((k_project_f64<true>), dim3(grid_for(B)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), M, G, dM, nullptr, B);
+    return check_launch("so3_project_bwd_f64");
 }
 
 size_t so3_angle_stats_workspace_bytes(void) { return sizeof(StatWork); }

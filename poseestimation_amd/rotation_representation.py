@@ -65,19 +65,29 @@ def _as_blocks(x: torch.Tensor) -> torch.Tensor:
 
 
 def _head_input(x: torch.Tensor) -> torch.Tensor:
-    """Kernel-ready (B,9) tensor: float32, or bfloat16 kept as stored (math is fp32 in registers)."""
+    """Kernel-ready (B,9) tensor: float32, bfloat16 kept as stored (math is fp32 in registers), or float64
+    (its own float64 kernels, as the reference's function accepts double tensors)."""
     m = _as_blocks(x)
-    if m.dtype in (torch.float32, torch.bfloat16):
+    if m.dtype in (torch.float32, torch.bfloat16, torch.float64):
         return m
     if m.dtype == torch.float16:
         return m.float()
     raise TypeError(
-        f"symmetric_orthogonalization: unsupported dtype {m.dtype}; the gfx950 kernel computes in "
-        "float32 (inputs: float32, bfloat16, float16)")
+        f"symmetric_orthogonalization: unsupported dtype {m.dtype} (inputs: float32, bfloat16, float16, float64)")
 
 
 def _f32_blocks(t: torch.Tensor) -> torch.Tensor:
     return _as_blocks(t).float()
+
+
+def _head_fns(dtype):
+    """(forward, backward) entry points and the dtype the rotation / upstream gradient travel in."""
+    lib = _lib.load()
+    if dtype == torch.bfloat16:
+        return lib.so3_project_fwd_bf16, lib.so3_project_bwd_bf16, torch.float32
+    if dtype == torch.float64:
+        return lib.so3_project_fwd_f64, lib.so3_project_bwd_f64, torch.float64
+    return lib.so3_project_fwd_f32, lib.so3_project_bwd_f32, torch.float32
 
 
 # --------------------------------------------------------------------------------------------
@@ -89,9 +99,8 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
         dev = _require_device(x)
         m = _head_input(x.detach())
         b = m.shape[0]
-        r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        fn = lib.so3_project_fwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_fwd_f32
+        fn, _, out_dtype = _head_fns(m.dtype)
+        r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
         with torch.cuda.device(dev):
             _lib.check(fn(_ptr(m), _ptr(r), None, b, _stream(dev)), "so3_project_fwd")
         ctx.save_for_backward(m)
@@ -104,11 +113,10 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
     def backward(ctx, grad_r):
         (m,) = ctx.saved_tensors
         dev = m.device
-        g = grad_r.reshape(-1, 9).contiguous().float()
+        _, fn, g_dtype = _head_fns(m.dtype)
+        g = grad_r.reshape(-1, 9).contiguous().to(g_dtype)
         b = m.shape[0]
         dm = torch.empty_like(m)
-        lib = _lib.load()
-        fn = lib.so3_project_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_bwd_f32
         with torch.cuda.device(dev):
             _lib.check(fn(_ptr(m), _ptr(g), _ptr(dm), b, _stream(dev)), "so3_project_bwd")
         return dm.to(ctx.in_dtype).view(ctx.in_shape)
@@ -118,7 +126,8 @@ def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
     """Maps 9D input vectors onto SO(3) via symmetric orthogonalization (SVD).
 
     x: [batch_size, 9] (any shape whose numel is a multiple of 9, as `x.view(-1, 3, 3)` accepts).
-    Returns [batch_size, 3, 3] float32 rotations R = U diag(1,1,det(UV^T)) V^T, differentiable.
+    Returns [batch_size, 3, 3] rotations R = U diag(1,1,det(UV^T)) V^T, differentiable: float32 for float32,
+    bfloat16 and float16 input, float64 for float64 input.
     """
     return _SymmetricOrthogonalization.apply(x)
 
@@ -129,10 +138,9 @@ def symmetric_orthogonalization_with_flip(x: torch.Tensor):
     dev = _require_device(x)
     m = _head_input(x.detach())
     b = m.shape[0]
-    r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
+    fn, _, out_dtype = _head_fns(m.dtype)
+    r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
     flip = torch.empty((b,), dtype=torch.uint8, device=dev)
-    lib = _lib.load()
-    fn = lib.so3_project_fwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_project_fwd_f32
     with torch.cuda.device(dev):
         _lib.check(fn(_ptr(m), _ptr(r), _ptr(flip), b, _stream(dev)), "so3_project_fwd")
     return r, flip.bool()
@@ -269,6 +277,8 @@ class _FrobeniusHead(torch.autograd.Function):
     def forward(ctx, x, r_true, want_r):
         dev = _require_device(x, r_true)
         m = _head_input(x.detach())
+        if m.dtype == torch.float64:
+            m = m.float()                      # the fused training-step kernel is float32 / bfloat16 only
         t = _f32_blocks(r_true.detach())
         b = m.shape[0]
         if t.shape[0] != b:

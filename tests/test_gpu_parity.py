@@ -113,6 +113,41 @@ def test_ragged_batches_and_unaligned_pointers(rr, c_oracle, b):
     assert np.quantile(np.abs(r - c_oracle.project(x[::2])), 0.9) < 1e-6
 
 
+def test_float64_head_and_backward(rr):
+    """Double tensors go through the float64 kernels (the reference's function accepts them) and come back double."""
+    from oracle import so3_oracle as so
+    g1 = load_golden("g1_gaussian256.npz")
+    x = dev(g1["x"], torch.float64)
+    r = rr.symmetric_orthogonalization(x)
+    assert r.dtype == torch.float64 and tuple(r.shape) == (256, 3, 3)
+    assert np.abs(r.cpu().numpy() - g1["r_f64"]).max() < 1e-11                 # vs the reference run in float64
+    gen = np.random.default_rng(64)
+    xs = gen.standard_normal((100_003, 9))
+    xs[:1000] *= np.array([1, 1, 1, 1e-3, 1e-3, 1e-3, 1e-6, 1e-6, 1e-6])       # graded rows
+    xs[1000] = 0.0                                                              # zero -> identity
+    xs[1001] = np.diag([1.0, 1.0, -1.0]).ravel()                                # reflection -> identity
+    xs[1002] = np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0]).ravel()              # rank one: any rotation, but a rotation
+    xt = torch.as_tensor(xs).to(DEV).requires_grad_(True)
+    rt, flip = rr.symmetric_orthogonalization_with_flip(xt.detach())
+    ref, s, d = so.symmetric_orthogonalization_np(xs, return_parts=True)
+    out = rt.cpu().numpy()
+    assert orth_err(out).max() < 1e-13 and np.abs(np.linalg.det(out) - 1).max() < 1e-13
+    assert np.array_equal(out[1000], np.eye(3)) and np.abs(out[1001] - np.eye(3)).max() < 1e-15
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / np.maximum(s[:, 0], 1e-300)
+    ok = gap > 1e-6
+    ok[1000:1003] = False
+    assert (np.abs(out - ref).reshape(len(xs), -1).max(1) * gap)[ok].max() < 1e-13
+    assert np.array_equal(flip.cpu().numpy()[ok], d[ok] < 0)
+    g = gen.standard_normal((len(xs), 3, 3))
+    rr.symmetric_orthogonalization(xt).backward(torch.as_tensor(g).to(DEV))
+    assert xt.grad.dtype == torch.float64
+    wc = gap > 1e-3
+    wc[1000:1003] = False
+    refg = so.projection_backward_np(xs[wc], g[wc])
+    err = np.abs(xt.grad.cpu().numpy()[wc].reshape(-1, 9) - refg.reshape(-1, 9)).max(1)
+    assert (err * gap[wc] * s[wc, 0]).max() < 1e-11
+
+
 def test_nan_rows_stay_local(rr):
     x = torch.randn(300, 9, device=DEV)
     x[7, 4] = float("nan")
