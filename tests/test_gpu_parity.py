@@ -94,7 +94,9 @@ def test_view_semantics_and_bad_shapes(rr):
     with pytest.raises(RuntimeError, match=r"shape '\[-1, 3, 3\]' is invalid for input of size 10"):
         rr.symmetric_orthogonalization(torch.zeros(10, device=DEV))
     with pytest.raises(TypeError):
-        rr.symmetric_orthogonalization(torch.zeros(2, 9, device=DEV, dtype=torch.float64))
+        rr.symmetric_orthogonalization(torch.zeros(2, 9, device=DEV, dtype=torch.int32))
+    z64 = rr.symmetric_orthogonalization(torch.zeros(2, 9, device=DEV, dtype=torch.float64))       # zero -> identity, in double
+    assert z64.dtype == torch.float64 and torch.equal(z64, torch.eye(3, device=DEV, dtype=torch.float64).expand(2, 3, 3))
     assert tuple(rr.symmetric_orthogonalization(torch.zeros(0, 9, device=DEV)).shape) == (0, 3, 3)
 
 
