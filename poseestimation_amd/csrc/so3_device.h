@@ -58,6 +58,13 @@ template <> struct Consts<double> {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+// Per-half predicate of a packed pair.  Two bools (not an integer vector): the compiler then keeps the predicates as
+// lane masks in SGPRs and does the and / or / not on the scalar unit instead of materialising 0 / -1 in VGPRs.
+struct bool2 {
+    bool x, y;
+};
+__device__ __forceinline__ bool2 operator&(bool2 a, bool2 b) { return bool2{a.x && b.x, a.y && b.y}; }
+__device__ __forceinline__ bool2 operator|(bool2 a, bool2 b) { return bool2{a.x || b.x, a.y || b.y}; }
 
 // ---- scalar-type traits ------------------------------------------------------------------------------
 template <class T> struct Tr;
@@ -88,9 +95,10 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ bool gt(float a, float b) { return a > b; }
     static __device__ __forceinline__ bool any(bool m) { return m; }
     static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
+    static __device__ __forceinline__ bool mnot(bool m) { return !m; }
 };
 template <> struct Tr<f32x2> {
-    typedef i32x2 mask;     // all-ones / zero per component
+    typedef bool2 mask;
     typedef i32x2 ivec;
     typedef float scalar;
     static constexpr int kLanes = 2;
@@ -117,12 +125,13 @@ template <> struct Tr<f32x2> {
         return i32x2{min(-__builtin_amdgcn_frexp_expf(x.x), 126), min(-__builtin_amdgcn_frexp_expf(x.y), 126)};
     }
     static __device__ __forceinline__ f32x2 ldexp(f32x2 x, i32x2 e) { return f32x2{ldexpf(x.x, e.x), ldexpf(x.y, e.y)}; }
-    static __device__ __forceinline__ f32x2 sel(i32x2 c, f32x2 a, f32x2 b) { return f32x2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
-    static __device__ __forceinline__ i32x2 le(f32x2 a, f32x2 b) { return i32x2{a.x <= b.x ? -1 : 0, a.y <= b.y ? -1 : 0}; }
-    static __device__ __forceinline__ i32x2 ge(f32x2 a, f32x2 b) { return i32x2{a.x >= b.x ? -1 : 0, a.y >= b.y ? -1 : 0}; }
-    static __device__ __forceinline__ i32x2 gt(f32x2 a, f32x2 b) { return i32x2{a.x > b.x ? -1 : 0, a.y > b.y ? -1 : 0}; }
-    static __device__ __forceinline__ bool any(i32x2 m) { return (m.x | m.y) != 0; }
-    static __device__ __forceinline__ bool lane_of(i32x2 m, int i) { return (i ? m.y : m.x) != 0; }
+    static __device__ __forceinline__ f32x2 sel(bool2 c, f32x2 a, f32x2 b) { return f32x2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
+    static __device__ __forceinline__ bool2 le(f32x2 a, f32x2 b) { return bool2{a.x <= b.x, a.y <= b.y}; }
+    static __device__ __forceinline__ bool2 ge(f32x2 a, f32x2 b) { return bool2{a.x >= b.x, a.y >= b.y}; }
+    static __device__ __forceinline__ bool2 gt(f32x2 a, f32x2 b) { return bool2{a.x > b.x, a.y > b.y}; }
+    static __device__ __forceinline__ bool any(bool2 m) { return m.x || m.y; }
+    static __device__ __forceinline__ bool lane_of(bool2 m, int i) { return i ? m.y : m.x; }
+    static __device__ __forceinline__ bool2 mnot(bool2 m) { return bool2{!m.x, !m.y}; }
 };
 
 template <> struct Tr<double> {           // one matrix per lane in float64 (so3_project_*_f64; not a benchmark path)
@@ -148,6 +157,7 @@ template <> struct Tr<double> {           // one matrix per lane in float64 (so3
     static __device__ __forceinline__ bool gt(double a, double b) { return a > b; }
     static __device__ __forceinline__ bool any(bool m) { return m; }
     static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
+    static __device__ __forceinline__ bool mnot(bool m) { return !m; }
 };
 
 // ---- 3-vectors over T -----------------------------------------------------------------------------
@@ -262,20 +272,29 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         }
     }
 
-    // 3. smallest column last, cyclic order kept (so det of the implied V stays +1).
-    // Ties (equal singular values to within a few ulp, e.g. diag(1,1,-1)) go to the LAST column, as
-    // LAPACK's ordering does: the reference then maps a pure reflection to the identity.
+    // 3. z = the smallest column (ties, i.e. singular values equal to within a few ulp as in diag(1,1,-1), go to the
+    // LAST column as LAPACK's ordering does: the reference then maps a pure reflection to the identity); of the other
+    // two the LARGER one is x.  The order matters on the V side: v1 = M^T u1 / s_x is exact to eps s1 / s_x, and v2 is
+    // orthogonalised against it -- with a numerically zero x first (rank-one input) v1 would be noise and would drag
+    // the one meaningful direction with it.  R does not depend on the order of the pair (u3 and v3 flip together);
+    // s3' = u3 . z does, through the handedness of (x, y, z): `swapped` undoes it.
     const T n2t = n2 * R::splat(K::tie);
-    const typename R::mask z2 = R::le(n2t, n0) & R::le(n2t, n1);
-    const typename R::mask z0 = R::le(n0, n1);
-    const V3<T> x = sel<T>(z2, a0, sel<T>(z0, a1, a2));
-    const V3<T> y = sel<T>(z2, a1, sel<T>(z0, a2, a0));
+    const typename R::mask z2 = R::le(n2t, n0) & R::le(n2t, n1);         // min is column 2
+    const typename R::mask z0 = R::le(n0, n1);                           // (else) min is column 0, otherwise column 1
+    const typename R::mask g12 = R::ge(n1, n2), g20 = R::ge(n2, n0);
+    const typename R::mask nz2 = R::mnot(z2), nz0 = R::mnot(z0);
+    const typename R::mask x0 = nz0 & (z2 | R::mnot(g20)), x1 = z0 & (z2 | g12);
+    const typename R::mask y0 = (z2 & z0) | (nz2 & nz0 & g20), y1 = (z2 & nz0) | (nz2 & z0 & R::mnot(g12));
+    const typename R::mask swapped = (z2 & z0) | (nz2 & z0 & R::mnot(g12)) | (nz2 & nz0 & R::mnot(g20));
+    const V3<T> x = sel<T>(x0, a0, sel<T>(x1, a1, a2));
+    const V3<T> y = sel<T>(y0, a0, sel<T>(y1, a1, a2));
     const V3<T> z = sel<T>(z2, a2, sel<T>(z0, a0, a1));
-    const T nx = R::sel(z2, n0, R::sel(z0, n1, n2));
+    const T nx = R::sel(x0, n0, R::sel(x1, n1, n2));
 
     const T inx = R::rsq(nx);
     V3<T> u1 = scale<T>(x, inx);
-    V3<T> w = axpy<T>(-dot(u1, y), u1, y);
+    const T qy = dot(u1, y);
+    V3<T> w = axpy<T>(-qy, u1, y);
     T nw = dot(w, w);
     const T inw = R::rsq(nw);
     V3<T> u2 = scale<T>(w, inw);
@@ -294,15 +313,26 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
 #else
     T nt1 = dot(t1, t1);
     V3<T> v1 = scale<T>(t1, R::rsq(nt1));
-    V3<T> r2 = axpy<T>(-dot(v1, t2), v1, t2);
+    const T pt = dot(v1, t2);
+    V3<T> r2 = axpy<T>(-pt, v1, t2);
     T nr2 = dot(r2, r2);
     V3<T> v2 = scale<T>(r2, R::rsq(nr2));
 #endif
 
-    // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.
+    // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.  Numerically rank one
+    // counts too: when the second singular value sits at round-off (s2 <~ eps s1; an outer product, a matrix of small
+    // integers, nine equal network outputs), y or M^T u2 is noise that may lie ALONG the first vector, and one
+    // Gram-Schmidt step then leaves a "unit vector" that is not orthogonal to it.  Such a step is recognised by what
+    // it removed: |w|^2 <= 1e-2 (u1.y)^2, i.e. more than 90 % of the vector was parallel (what is left after a milder
+    // step is orthogonal to ~10 eps).
     // (`<=` comparisons are false for NaN, so NaN input flows through the fast path to NaN output.)
     const T tiny = R::splat(K::tiny);
-    const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, tiny) | R::le(nt1, tiny) | R::le(nr2, tiny);
+    const T lost = R::splat(S(1e-2));
+#if SO3_REUSE_NORMS
+    const T pt = R::splat(S(0));
+#endif
+    const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, R::max(tiny, lost * qy * qy)) | R::le(nt1, tiny)
+                                        | R::le(nr2, R::max(tiny, lost * pt * pt));
     if (__builtin_expect(R::any(degenerate), 0)) {
 #pragma unroll
         for (int i = 0; i < R::kLanes; ++i) {
@@ -336,7 +366,8 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         // s_k = u_k^T M v_k; cheaper: |M^T u_k| for k = 1,2 and u3 . z for the signed one.
         o.s1 = nt1 * R::rsq(R::max(nt1, tiny));
         o.s2 = nr2 * R::rsq(R::max(nr2, tiny));
-        o.s3 = dot(o.u3, z);
+        const T s3u = dot(o.u3, z);
+        o.s3 = R::sel(swapped, -s3u, s3u);
     } else {
         o.s1 = o.s2 = o.s3 = R::splat(S(0));
     }

@@ -150,6 +150,39 @@ def test_float64_head_and_backward(rr):
     assert (err * gap[wc] * s[wc, 0]).max() < 1e-11
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_numerically_rank_deficient_input_still_gives_rotations(rr, dtype):
+    """Exactly or numerically rank-one / rank-two input (small integers, outer products, nine equal network outputs):
+    the SVD is not unique there and the answer is implementation-defined, but it must be a rotation, as LAPACK's is."""
+    gen = torch.Generator(device=DEV).manual_seed(123)
+    n = 500_000
+    a = torch.randn(n, 3, 3, device=DEV, generator=gen)
+    families = {
+        "small integers": torch.randint(-3, 4, (n, 3, 3), device=DEV, generator=gen).float(),
+        "outer products": torch.randn(n, 3, 1, device=DEV, generator=gen) @ torch.randn(n, 1, 3, device=DEV, generator=gen),
+        "integer outer products": torch.randint(-3, 4, (n, 3, 1), device=DEV, generator=gen).float() @ torch.randint(-3, 4, (n, 1, 3), device=DEV, generator=gen).float(),
+        "nine equal entries": torch.randn(n, 1, 1, device=DEV, generator=gen).expand(n, 3, 3).contiguous(),
+        "rank two": torch.cat((a[:, :2], a[:, :1] + a[:, 1:2]), 1),
+        "rank two + 1e-7": torch.cat((a[:, :2], a[:, :1] + a[:, 1:2]), 1) + 1e-7 * torch.randn(n, 3, 3, device=DEV, generator=gen),
+        "outer + 1e-7": torch.randn(n, 3, 1, device=DEV, generator=gen) @ torch.randn(n, 1, 3, device=DEV, generator=gen) + 1e-7 * a,
+    }
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    for name, m in families.items():
+        x = m.to(dtype).requires_grad_(True)
+        r = rr.symmetric_orthogonalization(x)
+        cols = [(r[:, :, i] * r[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
+        orth = torch.stack(cols, 1).norm(dim=1)
+        det = torch.linalg.det(r.detach().double())
+        assert orth.max().item() < tol and (det - 1).abs().max().item() < 10 * tol, (name, orth.max().item())
+        # R maximises tr(R^T M) over SO(3): compare the objective with float64 LAPACK's (unique even where R is not)
+        s = torch.linalg.svdvals(m.double())
+        best = s[:, 0] + s[:, 1] + torch.where(torch.linalg.det(m.double()) < 0, -s[:, 2], s[:, 2])
+        got = (r.detach().double() * m.double()).sum((1, 2))
+        assert ((best - got) / s[:, 0].clamp_min(1e-30)).max().item() < (2e-6 if dtype == torch.float32 else 1e-12), name
+        r.backward(torch.randn(n, 3, 3, device=DEV, generator=gen).to(dtype))
+        assert torch.isfinite(x.grad).all(), name               # floored denominators: large but finite
+
+
 def test_nan_rows_stay_local(rr):
     x = torch.randn(300, 9, device=DEV)
     x[7, 4] = float("nan")

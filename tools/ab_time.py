@@ -29,9 +29,13 @@ def timeit(fn, iters=100, warm=10):
     return a.elapsed_time(b) * 1e3 / iters
 
 
-for rep in range(2):
+for rep in range(3):
     for path in sys.argv[1:]:
         lib = ctypes.CDLL(path)
+        lib.so3_project_fwd_f32.restype = ctypes.c_int
+        lib.so3_project_fwd_f32.argtypes = [P, P, P, ctypes.c_int64, P]
+        lib.so3_project_bwd_f32.restype = ctypes.c_int
+        lib.so3_project_bwd_f32.argtypes = [P, P, P, ctypes.c_int64, P]
         for f in ("so3_angle_error", "so3_project_angle_error_f32", "so3_frob_loss_f32", "so3_frob_fwd_bwd_f32"):
             getattr(lib, f).restype = ctypes.c_int
         lib.so3_angle_error.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int64, P]
@@ -39,6 +43,8 @@ for rep in range(2):
         lib.so3_frob_loss_f32.argtypes = [P, P, P, P, ctypes.c_int64, P]
         lib.so3_frob_fwd_bwd_f32.argtypes = [P, P, P, P, P, ctypes.c_int64, P]
         res = {
+            "K1": timeit(lambda i: lib.so3_project_fwd_f32(p(x[i % NB]), p(r[i % NB]), None, n, st), iters=400, warm=100),
+            "K2": timeit(lambda i: lib.so3_project_bwd_f32(p(x[i % NB]), p(rt[i % NB]), p(dm[i % NB]), n, st)),
             "K4 deg": timeit(lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st)),
             "K4 sum": timeit(lambda i: lib.so3_angle_error(p(rt[(i + 1) % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st)),
             "K1+K4 sum": timeit(lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st)),

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Float32 head (3 sweeps + one adaptive) against the float64 head on adversarial families, on the GPU.
+Reports, per family, the worst orthogonality error and the worst conditioned difference  |R32 - R64| * gap / s1
+(gap = s2 + s3 without flip, s2 - s3 with flip): float32 round-off is ~1e-7 in that measure."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from poseestimation_amd import rotation_representation as rr
+
+dev = "cuda:0"
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+g = torch.Generator(device=dev).manual_seed(77)
+
+
+def rot(k):
+    return rr.symmetric_orthogonalization(torch.randn(k, 9, device=dev, generator=g, dtype=torch.float64))
+
+
+def families():
+    yield "gaussian", torch.randn(n, 3, 3, device=dev, generator=g, dtype=torch.float64)
+    for e in (1e-1, 1e-3, 1e-5, 1e-7):
+        d = torch.ones(n, 3, device=dev, dtype=torch.float64)
+        d[:, 1] = 1 - e * torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+        d[:, 2] = 1 - 2 * e * torch.rand(n, device=dev, generator=g, dtype=torch.float64)
+        yield "clustered singular values, spread %.0e" % e, rot(n) @ torch.diag_embed(d) @ rot(n)
+    for e in (1e-2, 1e-4, 1e-6):
+        d = torch.ones(n, 3, device=dev, dtype=torch.float64)
+        d[:, 1] = e
+        d[:, 2] = e * e
+        yield "graded 1, %.0e, %.0e" % (e, e * e), rot(n) @ torch.diag_embed(d) @ rot(n)
+    for e in (1e-1, 1e-3, 1e-5):
+        yield "rotation + %.0e noise" % e, rot(n) + e * torch.randn(n, 3, 3, device=dev, generator=g, dtype=torch.float64)
+    a = torch.randn(n, 3, 3, device=dev, generator=g, dtype=torch.float64)
+    yield "symmetric", a + a.transpose(1, 2)
+    yield "antisymmetric + 1e-3 I", a - a.transpose(1, 2) + 1e-3 * torch.eye(3, device=dev, dtype=torch.float64)
+    yield "small integers", torch.randint(-3, 4, (n, 3, 3), device=dev, generator=g).double()
+    u, v = torch.randn(n, 3, 1, device=dev, generator=g), torch.randn(n, 1, 3, device=dev, generator=g)
+    yield "outer products (rank one up to rounding)", (u @ v).double()
+    yield "outer products of small integers", (torch.randint(-3, 4, (n, 3, 1), device=dev, generator=g).float()
+                                                @ torch.randint(-3, 4, (n, 1, 3), device=dev, generator=g).float()).double()
+    yield "nine equal entries", torch.randn(n, 1, 1, device=dev, generator=g, dtype=torch.float64).expand(n, 3, 3).contiguous()
+    yield "rank two (third row = sum of the others)", torch.cat((a[:, :2], a[:, :1] + a[:, 1:2]), 1)
+    yield "scaled 1e+18", 1e18 * torch.randn(n, 3, 3, device=dev, generator=g, dtype=torch.float64)
+    yield "scaled 1e-18", 1e-18 * torch.randn(n, 3, 3, device=dev, generator=g, dtype=torch.float64)
+
+
+eye = torch.eye(3, device=dev)
+for name, m64 in families():
+    m32 = m64.float()
+    r32 = rr.symmetric_orthogonalization(m32)
+    r64, flip = rr.symmetric_orthogonalization_with_flip(m32.double())      # the float32-rounded input, exactly
+    cols64 = [(r64[:, :, i] * r64[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
+    orth64 = torch.stack(cols64, 1).norm(dim=1).max().item()
+    s = torch.linalg.svdvals(m32.double())
+    gap = torch.where(flip, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0].clamp_min(1e-300)
+    err = (r32.double() - r64).abs().flatten(1).amax(1)
+    cols = [(r32[:, :, i] * r32[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
+    orth = torch.stack(cols, 1).norm(dim=1)
+    ok = gap > 1e-9
+    print("%-44s orth %.2e (f64 %.1e)   max err*gap %.2e   median err %.2e   (rows with gap > 1e-9: %d)" %
+          (name, orth.max().item(), orth64, (err * gap)[ok].max().item() if ok.any() else float("nan"), err.median().item(), int(ok.sum())), flush=True)
