@@ -368,6 +368,29 @@ def test_kabsch_ragged(rr, c_oracle, b, n):
         assert np.quantile(np.abs(r.cpu().numpy() - ro), 0.9) < 5e-5
 
 
+def test_kabsch_degenerate_clouds(rr):
+    """Coplanar clouds (rank-two H: R still unique thanks to det = +1) and collinear clouds (rank-one H: R is only
+    determined on the line) -- the answer must be a rotation that reproduces the second cloud."""
+    gen = torch.Generator(device=DEV).manual_seed(31)
+    b, n = 4096, 257
+    r_gt = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
+    basis = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
+    coef = torch.randn(b, n, 3, device=DEV, generator=gen)
+    for rank in (2, 1):
+        c = coef.clone()
+        c[:, :, rank:] = 0.0
+        p = torch.bmm(c, basis.transpose(1, 2))                       # points in a plane / on a line through the origin
+        q = torch.bmm(p, r_gt.transpose(1, 2))
+        r = rr.kabsch_rotation(p, q)
+        cols = [(r[:, :, i] * r[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
+        assert torch.stack(cols, 1).norm(dim=1).max().item() < 1e-5
+        assert (torch.linalg.det(r.double()) - 1).abs().max().item() < 1e-5
+        resid = (torch.bmm(p, r.transpose(1, 2)) - q).norm(dim=2).max().item()
+        assert resid < 2e-5 * p.norm(dim=2).max().item(), (rank, resid)
+        if rank == 2:
+            assert (r - r_gt).abs().max().item() < 2e-5
+
+
 def test_config3_kabsch_recovers_rotations(rr):
     """Round trip at a large size: Q = R_gt P (no noise) -> Kabsch returns R_gt."""
     b, n = 8192, 1024
