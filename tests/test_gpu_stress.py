@@ -1,0 +1,116 @@
+"""GPU edge-case sweeps of the secondary entry points against the float64 oracle: extreme magnitudes, the branch points of
+each formula (clamps, series switch-overs, kinks of |x|), long accumulations."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import orth_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def rr():
+    assert torch.cuda.is_available()
+    from poseestimation_amd import _lib, rotation_representation
+    _lib.load()
+    return rotation_representation
+
+
+def _head_case(rr, name, fn_name, x, tol_r, tol_g):
+    from oracle import so3_oracle as so
+    fn = getattr(rr, fn_name)
+    xt = torch.as_tensor(x, dtype=torch.float32).to(DEV).requires_grad_(True)
+    r = fn(xt)
+    x32 = xt.detach().cpu().numpy().astype(np.float64)                 # the oracle sees exactly the float32 input
+    ref = so.head_np(name, x32)
+    finite = np.isfinite(ref).all(axis=(1, 2))
+    assert np.array_equal(torch.isfinite(r).all(dim=(1, 2)).cpu().numpy(), finite) or name == "ortho5d"
+    err = np.abs(r.detach().cpu().numpy()[finite] - ref[finite]).reshape(finite.sum(), -1).max(1)
+    assert err.max() < tol_r, (name, err.max(), x32[finite][err.argmax()])
+    g = np.random.default_rng(0).standard_normal((len(x32), 3, 3))
+    r.backward(torch.as_tensor(g, dtype=torch.float32).to(DEV))
+    refg = so.head_backward_np(name, x32[finite], g[finite].astype(np.float32).astype(np.float64))
+    got = xt.grad.cpu().numpy()[finite]
+    scale = np.maximum(np.abs(refg).max(axis=1), 1.0)
+    gerr = np.abs(got - refg).max(axis=1) / scale
+    assert gerr.max() < tol_g, (name, gerr.max(), x32[finite][gerr.argmax()])
+
+
+def test_quaternion_head_extremes(rr):
+    rng = np.random.default_rng(1)
+    q = rng.standard_normal((4096, 4))
+    scales = np.concatenate([np.full(512, s) for s in (1e-30, 1e-12, 1e-7, 1e-3, 1.0, 1e3, 1e12, 1e18)])
+    _head_case(rr, "quat", "compute_rotation_matrix_from_quaternion", q * scales[:, None], 3e-6, 2e-5)
+    # below the clamp (|q| < 1e-8) the reference divides by 1e-8: R is not a rotation there, and neither is ours
+    z = rr.compute_rotation_matrix_from_quaternion(torch.zeros(3, 4, device=DEV))
+    assert torch.equal(z, torch.eye(3, device=DEV).expand(3, 3, 3))
+
+
+def test_euler_head_large_angles(rr):
+    rng = np.random.default_rng(2)
+    e = rng.uniform(-1, 1, (4096, 3)) * np.concatenate([np.full(1024, s) for s in (1e-4, 3.2, 100.0, 1e4)])[:, None]
+    _head_case(rr, "euler", "compute_rotation_matrix_from_euler", e, 3e-6, 1e-5)
+
+
+def test_expmap_head_around_its_branch_points(rr):
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((4800, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    radii = np.concatenate([np.full(400, s) for s in (0.0, 1e-20, 1e-6, 0.00999, 0.01, 0.010001, 0.3, 0.9999, 1.0, 1.0001, np.pi, 100.0)])
+    _head_case(rr, "expmap", "vec_3d_to_SO3", d * radii[:, None], 1e-5, 3e-5)       # at theta = 100 one float32 ulp of the angle is 8e-6 rad
+    near_pi = d[:512] * (np.pi - 1e-4)
+    r = rr.vec_3d_to_SO3(torch.as_tensor(near_pi, dtype=torch.float32).to(DEV)).cpu().numpy()
+    assert orth_err(r).max() < 1e-5
+
+
+def test_ortho5d_and_6d_heads_extremes(rr):
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((4096, 5)) * np.concatenate([np.full(1024, s) for s in (1e-3, 1.0, 1e3, 1e6)])[:, None]
+    _head_case(rr, "ortho5d", "compute_rotation_matrix_from_ortho5d", a, 2e-5, 2e-3)      # parallel pairs amplify round-off
+    from oracle import so3_oracle as so
+    p = rng.standard_normal((4096, 6)) * np.concatenate([np.full(1024, s) for s in (1e-15, 1e-3, 1e3, 1e15)])[:, None]
+    pt = torch.as_tensor(p, dtype=torch.float32).to(DEV)
+    r = rr.compute_rotation_matrix_from_ortho6d(pt).cpu().numpy()
+    e = np.abs(r - so.ortho6d_np(pt.cpu().numpy().astype(np.float64))).reshape(4096, -1).max(1)
+    assert np.quantile(e, 0.99) < 5e-6 and orth_err(r).max() < 1e-5
+
+
+def test_add_l1_long_clouds_accumulate_accurately(rr):
+    from oracle import so3_oracle as so
+    gen = torch.Generator().manual_seed(8)
+    b, n = 6, 200_003                                            # ~3100 points per lane in float32 accumulators
+    t_gt = torch.eye(4).repeat(b, 1, 1)
+    t_gt[:, :3, :3] = so.symmetric_orthogonalization_torch(torch.randn(b, 9, generator=gen))
+    t_gt[:, :3, 3] = torch.randn(b, 3, generator=gen)
+    t_pred = t_gt.clone()
+    t_pred[:, :3, :3] = so.symmetric_orthogonalization_torch(torch.randn(b, 9, generator=gen))
+    t_pred[:, :3, 3] += 0.3 * torch.randn(b, 3, generator=gen)
+    pts = torch.randn(b, n, 3, generator=gen)
+    ref_loss, ref_grad, ref_d = so.add_l1_np(t_gt.numpy(), t_pred.numpy(), pts.numpy())
+    tp = t_pred.to(DEV).requires_grad_(True)
+    loss = rr.compute_ADD_L1_loss(t_gt.to(DEV), tp, pts.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - ref_loss) < 2e-5 * ref_loss
+    assert np.abs(tp.grad.cpu().numpy() - ref_grad).max() < 2e-5 * np.abs(ref_grad).max()
+    d = rr.compute_ADD_L1_loss(t_gt.to(DEV), t_pred.to(DEV), pts.to(DEV), use_batch_mean=False).cpu().numpy()
+    assert np.abs(d - ref_d).max() < 2e-5 * ref_d.max()
+
+
+def test_angle_error_near_zero_and_pi(rr):
+    from oracle import so3_oracle as so
+    rng = np.random.default_rng(6)
+    axis = rng.standard_normal((3000, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    ang = np.concatenate([np.full(500, a) for a in (0.0, 1e-7, 1e-3, 1.0, np.pi - 1e-3, np.pi)])
+    rel = so.head_np("expmap", axis * np.maximum(ang, 1e-2)[:, None])       # exact rotations by >= 0.01 rad ...
+    k = np.zeros((3000, 3, 3)); k[:, 0, 1], k[:, 0, 2], k[:, 1, 0], k[:, 1, 2], k[:, 2, 0], k[:, 2, 1] = -axis[:, 2], axis[:, 1], axis[:, 2], -axis[:, 0], -axis[:, 1], axis[:, 0]
+    rel = np.eye(3) + np.sin(ang)[:, None, None] * k + (1 - np.cos(ang))[:, None, None] * (k @ k)      # ... and by `ang` exactly (Rodrigues)
+    base = so.symmetric_orthogonalization_np(rng.standard_normal((3000, 9)))
+    r1 = torch.as_tensor(base, dtype=torch.float32).to(DEV)
+    r2 = torch.as_tensor(base @ rel, dtype=torch.float32).to(DEV)
+    got = rr.angle_error(r1, r2).cpu().numpy()
+    ref = so.angle_error_np(r1.cpu().numpy(), r2.cpu().numpy())                 # float64 on the same float32 matrices
+    assert np.abs(got - ref).max() < 1e-9
+    assert np.abs(got[1000:1500] - np.degrees(1e-3)).max() < 0.02 and np.abs(got[-500:] - 180).max() < 0.05
