@@ -59,7 +59,9 @@ def test_expmap_head_around_its_branch_points(rr):
     d = rng.standard_normal((4800, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     radii = np.concatenate([np.full(400, s) for s in (0.0, 1e-20, 1e-6, 0.00999, 0.01, 0.010001, 0.3, 0.9999, 1.0, 1.0001, np.pi, 100.0)])
-    _head_case(rr, "expmap", "vec_3d_to_SO3", d * radii[:, None], 1e-5, 3e-5)       # at theta = 100 one float32 ulp of the angle is 8e-6 rad
+    # forward: at theta = 100 one float32 ulp of the angle is 8e-6 rad.  backward: rows with |v|^2 within round-off of the
+    # clamp 1e-4 fall on either side of it in float32 and float64; the gradient term that switches there is ~|v|^2/3
+    _head_case(rr, "expmap", "vec_3d_to_SO3", d * radii[:, None], 1e-5, 1e-4)
     near_pi = d[:512] * (np.pi - 1e-4)
     r = rr.vec_3d_to_SO3(torch.as_tensor(near_pi, dtype=torch.float32).to(DEV)).cpu().numpy()
     assert orth_err(r).max() < 1e-5
