@@ -57,5 +57,11 @@ for name, m64 in families():
     cols = [(r32[:, :, i] * r32[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
     orth = torch.stack(cols, 1).norm(dim=1)
     ok = gap > 1e-9
-    print("%-44s orth %.2e (f64 %.1e)   max err*gap %.2e   median err %.2e   (rows with gap > 1e-9: %d)" %
-          (name, orth.max().item(), orth64, (err * gap)[ok].max().item() if ok.any() else float("nan"), err.median().item(), int(ok.sum())), flush=True)
+    # backward on the same rows: float32 kernel against the float64 kernel, scaled by gap^2 (the denominators are s_i + s_j)
+    gup = torch.randn(n, 3, 3, device=dev, generator=g)
+    x32 = m32.clone().requires_grad_(True); rr.symmetric_orthogonalization(x32).backward(gup)
+    x64 = m32.double().requires_grad_(True); rr.symmetric_orthogonalization(x64).backward(gup.double())
+    gerr = (x32.grad.double() - x64.grad).abs().flatten(1).amax(1) * s[:, 0] * gap * gap
+    gfin = bool(torch.isfinite(x32.grad).all())
+    print("%-44s bwd finite %s, max |dM32-dM64| s1 gap^2 %.1e | orth %.2e (f64 %.1e)   max err*gap %.2e   median err %.2e   (rows with gap > 1e-9: %d)" %
+          (name, gfin, gerr[ok].max().item() if ok.any() else float("nan"), orth.max().item(), orth64, (err * gap)[ok].max().item() if ok.any() else float("nan"), err.median().item(), int(ok.sum())), flush=True)
