@@ -263,10 +263,15 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         int extra = 0;
         while (true) {
             const T g01 = dot(a0, a1);
-            if (!wave_any(R::any(R::gt(g01 * g01, n0 * n1 * R::splat(K::tol2))))) break;   // NaN / zero rows compare false
-            rotate(a0, a1);
-            rotate(a0, a2);
-            rotate(a1, a2);
+            const typename R::mask need = R::gt(g01 * g01, n0 * n1 * R::splat(K::tol2));   // NaN / zero rows compare false
+            if (!wave_any(R::any(need))) break;
+            // The branch is wave-uniform, the update is per matrix: a row keeps its three-sweep columns unless IT failed
+            // the test, so its result does not depend on which other rows happen to share the wave.
+            V3<T> b0 = a0, b1 = a1, b2 = a2;
+            rotate(b0, b1);
+            rotate(b0, b2);
+            rotate(b1, b2);
+            a0 = sel<T>(need, b0, a0); a1 = sel<T>(need, b1, a1); a2 = sel<T>(need, b2, a2);
             n0 = dot(a0, a0); n1 = dot(a1, a1); n2 = dot(a2, a2);
             if (MAX_EXTRA == 1 || ++extra >= MAX_EXTRA) break;      // (compile-time exit for the float32 kernels)
         }

@@ -183,6 +183,31 @@ def test_numerically_rank_deficient_input_still_gives_rotations(rr, dtype):
         assert torch.isfinite(x.grad).all(), name               # floored denominators: large but finite
 
 
+def test_a_row_does_not_depend_on_its_neighbours(rr):
+    """Batch invariance, bit for bit: proj(x)[i] == proj(x[i:i+1]) whatever else is in the batch, whichever kernel
+    (packed streaming engine, one-row-per-lane tile kernel, aligned or not) ends up processing the row.  The adaptive
+    sweep is decided per wave but applied per matrix, so LAPACK-like per-matrix semantics hold."""
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    n = 100_000
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    gup = torch.randn(n, 3, 3, device=DEV, generator=gen)
+    full_x = x.clone().requires_grad_(True)
+    full = rr.symmetric_orthogonalization(full_x)
+    full.backward(gup)
+    for lo, hi in ((0, 1), (63, 65), (1000, 1064), (12_345, 54_321), (n - 7, n)):
+        for offset in (0, 1):                                   # 16-byte aligned, and 4-byte aligned only
+            buf = torch.empty((hi - lo) * 9 + offset, device=DEV)
+            part_x = buf[offset:].view(hi - lo, 9)
+            part_x.copy_(x[lo:hi])
+            part_x.requires_grad_(True)
+            part = rr.symmetric_orthogonalization(part_x)
+            part.backward(gup[lo:hi])
+            assert torch.equal(part, full[lo:hi]), (lo, hi, offset)
+            assert torch.equal(part_x.grad, full_x.grad[lo:hi]), (lo, hi, offset)
+    shuffled = torch.randperm(n, device=DEV, generator=gen)
+    assert torch.equal(rr.symmetric_orthogonalization(x[shuffled]), full.detach()[shuffled])
+
+
 def test_nan_rows_stay_local(rr):
     x = torch.randn(300, 9, device=DEV)
     x[7, 4] = float("nan")
