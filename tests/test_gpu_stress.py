@@ -116,3 +116,76 @@ def test_angle_error_near_zero_and_pi(rr):
     ref = so.angle_error_np(r1.cpu().numpy(), r2.cpu().numpy())                 # float64 on the same float32 matrices
     assert np.abs(got - ref).max() < 1e-9
     assert np.abs(got[1000:1500] - np.degrees(1e-3)).max() < 0.02 and np.abs(got[-500:] - 180).max() < 0.05
+
+
+# ------------------------------------------------------------------------------------------------
+# memory safety: outputs sit between sentinel bands; nothing outside [out, out + size) may change
+# ------------------------------------------------------------------------------------------------
+def _guarded(nelem, dtype, offset_elems=0):
+    """(view of nelem elements, whole buffer, slice bounds) with 4 KiB of sentinel on both sides."""
+    itemsize = torch.empty((), dtype=dtype).element_size()
+    pad = 4096 // itemsize
+    whole = torch.full((pad + offset_elems + nelem + pad,), 7, dtype=dtype, device=DEV)
+    lo = pad + offset_elems
+    return whole[lo:lo + nelem], whole, lo, lo + nelem
+
+
+def _intact(whole, lo, hi):
+    return bool((whole[:lo] == 7).all()) and bool((whole[hi:] == 7).all())
+
+
+@pytest.mark.parametrize("b", [1, 2, 63, 64, 65, 127, 128, 129, 1000, 4097])
+@pytest.mark.parametrize("offset", [0, 1])
+def test_no_entry_point_writes_outside_its_outputs(b, offset):
+    import ctypes
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    st = P(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: P(t.data_ptr())
+    gen = torch.Generator(device=DEV).manual_seed(b)
+    m = torch.randn(b, 9, device=DEV, generator=gen)
+    g = torch.randn(b, 9, device=DEV, generator=gen)
+    checks = []
+
+    def out(nelem, dtype=torch.float32):
+        view, whole, lo, hi = _guarded(nelem, dtype, offset)
+        checks.append((whole, lo, hi))
+        return view
+
+    r = out(b * 9); flip = out(b, torch.uint8)
+    assert lib.so3_project_fwd_f32(p(m), p(r), p(flip), b, st) == 0
+    rt = r.clone().view(b, 9)
+    dm = out(b * 9)
+    assert lib.so3_project_bwd_f32(p(m), p(g), p(dm), b, st) == 0
+    r2 = out(b * 9); dm2 = out(b * 9); ls = out(1, torch.float64)
+    assert lib.so3_frob_fwd_bwd_f32(p(m), p(rt), p(r2), p(dm2), p(ls), b, st) == 0
+    mb = m.bfloat16(); dmb = out(b * 9, torch.bfloat16); r3 = out(b * 9)
+    assert lib.so3_frob_fwd_bwd_bf16(p(mb), p(rt), p(r3), p(dmb), p(ls), b, st) == 0
+    deg = out(b, torch.float64); sc = out(2, torch.float64); fl = out(1, torch.int32)
+    assert lib.so3_angle_error(p(rt), p(rt), p(deg), p(sc), p(fl), 0, b, st) == 0
+    th = out(b)
+    assert lib.so3_geodesic_f32(p(rt), p(rt), p(th), b, st) == 0
+    for name, w in (("quat", 4), ("euler", 3), ("ortho5d", 5), ("expmap", 3), ("ortho6d", 6)):
+        x = torch.randn(b, w, device=DEV, generator=gen)
+        ro = out(b * 9); dx = out(b * w)
+        assert getattr(lib, "so3_%s_fwd_f32" % name)(p(x), p(ro), b, st) == 0
+        assert getattr(lib, "so3_%s_bwd_f32" % name)(p(x), p(g), p(dx), b, st) == 0
+    o12 = torch.randn(b, 12, device=DEV, generator=gen); ti = torch.eye(4, device=DEV).repeat(b, 1, 1).contiguous()
+    tp = out(b * 16); do = out(b * 12); g16 = torch.randn(b, 16, device=DEV, generator=gen)
+    fx = ctypes.c_float(444.4)
+    assert lib.so3_se3_update_f32(p(o12), p(ti), p(tp), fx, fx, b, st) == 0
+    assert lib.so3_se3_update_bwd_f32(p(o12), p(ti), p(g16), p(do), fx, fx, b, st) == 0
+    nb, npts = min(b, 300), 70
+    pts = torch.randn(nb, npts, 3, device=DEV, generator=gen)
+    rk = out(nb * 9); hk = out(nb * 9)
+    assert lib.so3_kabsch_f32(p(pts), p(pts), p(rk), p(hk), nb, npts, st) == 0
+    qo = out(nb * npts * 3); no = out(nb * npts * 3); cen = out(nb * 3); scl = out(nb)
+    assert lib.so3_rotate_clouds_f32(p(pts), p(rt), p(qo), 1, nb, npts, st) == 0
+    assert lib.so3_pc_normalize_f32(p(pts), p(no), p(cen), p(scl), nb, npts, st) == 0
+    tg = torch.eye(4, device=DEV).repeat(nb, 1, 1).contiguous(); dt = out(nb * 16); dists = out(nb); l3 = out(3, torch.float64)
+    assert lib.so3_add_l1_f32(p(tg), p(tg), p(pts), p(dists), p(l3), p(dt), ctypes.c_float(1.0), nb, npts, st) == 0
+    assert lib.so3_add_l1_disentangled_f32(p(tg), p(tg), p(pts), p(l3), p(dt), ctypes.c_float(1.0), nb, npts, st) == 0
+    torch.cuda.synchronize()
+    for i, (whole, lo, hi) in enumerate(checks):
+        assert _intact(whole, lo, hi), "output #%d was written outside its bounds (B = %d, offset = %d)" % (i, b, offset)
