@@ -189,3 +189,42 @@ def test_no_entry_point_writes_outside_its_outputs(b, offset):
     torch.cuda.synchronize()
     for i, (whole, lo, hi) in enumerate(checks):
         assert _intact(whole, lo, hi), "output #%d was written outside its bounds (B = %d, offset = %d)" % (i, b, offset)
+
+
+def test_fused_training_step_on_bf16_and_degenerate_rows(rr):
+    """frobenius_head (K3) on bf16-rounded inputs -- where exact ties and rank-deficient rows are common -- against the
+    unfused float64 kernels on exactly the same (rounded) numbers."""
+    gen = torch.Generator(device=DEV).manual_seed(41)
+    n = 300_000
+    base = torch.randn(n, 9, device=DEV, generator=gen)
+    fam = {
+        "gaussian": base,
+        "coarse (3 significant bits)": (base * 4).round() / 4,
+        "outer products": (torch.randn(n, 3, 1, device=DEV, generator=gen) @ torch.randn(n, 1, 3, device=DEV, generator=gen)).reshape(n, 9),
+        "near a rotation": rr.symmetric_orthogonalization(base).reshape(n, 9) + 0.01 * torch.randn(n, 9, device=DEV, generator=gen),
+        "equal entries": torch.randn(n, 1, device=DEV, generator=gen).expand(n, 9).contiguous(),
+    }
+    target = rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen))
+    for name, m in fam.items():
+        xb = m.bfloat16().requires_grad_(True)
+        loss, r = rr.frobenius_head(xb, target)
+        loss.backward()
+        cols = [(r[:, :, i] * r[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
+        assert torch.stack(cols, 1).norm(dim=1).max().item() < 1e-5, name
+        assert torch.isfinite(xb.grad).all() and torch.isfinite(loss), name
+        x64 = xb.detach().double().requires_grad_(True)                      # the same bf16 numbers, float64 kernels
+        r64 = rr.symmetric_orthogonalization(x64)
+        loss64 = (target.double() - r64).flatten(1).norm(dim=1).mean()
+        loss64.backward()
+        s = torch.linalg.svdvals(x64.detach().view(-1, 3, 3))
+        det = torch.linalg.det(x64.detach().view(-1, 3, 3))
+        gap = torch.where(det < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0].clamp_min(1e-300)
+        ok = gap > 1e-3                                                      # where R (and so the loss) is well determined
+        if ok.any():
+            per_row = (target.double() - r.double()).flatten(1).norm(dim=1)
+            per_row64 = (target.double() - r64.detach()).flatten(1).norm(dim=1)
+            assert (per_row - per_row64)[ok].abs().max().item() < 2e-3, name            # |dR| <~ 1e-6 / gap
+            gerr = (xb.grad.double() - x64.grad).abs().flatten(1).amax(1) * s[:, 0] * gap * gap * n
+            # bf16 gradient storage: 3 significant digits of each entry
+            ref_mag = x64.grad.abs().flatten(1).amax(1) * s[:, 0] * gap * gap * n
+            assert (gerr[ok] <= 1e-2 * ref_mag[ok] + 1e-4).all(), name
