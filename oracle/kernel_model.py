@@ -1,0 +1,81 @@
+"""ctypes loader of oracle/kernel_model.cpp: the kernels' own templates compiled for the host.  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(_HERE, "kernel_model.cpp")
+HDR = os.path.join(_HERE, "..", "poseestimation_amd", "csrc", "so3_device.h")
+LIB = os.path.join(_HERE, "libso3model.so")
+_lib = None
+
+
+def clangxx():
+    for cand in (os.environ.get("CLANGXX"), "/opt/rocm/lib/llvm/bin/clang++", shutil.which("amdclang++"), shutil.which("clang++")):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def build(force: bool = False) -> str:
+    cxx = clangxx()
+    if cxx is None:
+        raise RuntimeError("kernel_model needs clang++ (ext_vector_type); none found")
+    stale = force or not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in (SRC, HDR))
+    if stale:
+        subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC])
+        os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(np.asarray(a, dt).reshape(-1, 9))
+
+
+def project(m, packed=False, want_flip=False):
+    m = _c(m, np.float32)
+    r = np.empty_like(m)
+    flip = np.zeros(m.shape[0], np.uint8)
+    if packed:
+        lib().model_project_packed_f32(_p(m), _p(r), ctypes.c_int64(m.shape[0]))
+    else:
+        lib().model_project_f32(_p(m), _p(r), _p(flip), ctypes.c_int64(m.shape[0]))
+    r = r.reshape(-1, 3, 3)
+    return (r, flip.astype(bool)) if want_flip else r
+
+
+def project_bwd(m, g):
+    m, g = _c(m, np.float32), _c(g, np.float32)
+    d = np.empty_like(m)
+    lib().model_project_bwd_f32(_p(m), _p(g), _p(d), ctypes.c_int64(m.shape[0]))
+    return d.reshape(-1, 3, 3)
+
+
+def project_f64(m):
+    m = _c(m, np.float64)
+    r = np.empty_like(m)
+    lib().model_project_f64(_p(m), _p(r), ctypes.c_int64(m.shape[0]))
+    return r.reshape(-1, 3, 3)
+
+
+def project_bwd_f64(m, g):
+    m, g = _c(m, np.float64), _c(g, np.float64)
+    d = np.empty_like(m)
+    lib().model_project_bwd_f64(_p(m), _p(g), _p(d), ctypes.c_int64(m.shape[0]))
+    return d.reshape(-1, 3, 3)

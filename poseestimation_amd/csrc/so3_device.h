@@ -29,9 +29,38 @@
 //                v_pk_mul_f32 / v_pk_add_f32 (which do two lanes' worth of work per issue slot) restores
 //                the full rate without relying on the scheduler to interleave two scalar streams.
 #pragma once
+// SO3_HOST_MODEL: the same templates compiled for the host (oracle/kernel_model.cpp: the CPU test suite runs the
+// kernel's own algorithm on adversarial input without a GPU).  Only the hardware instructions below differ:
+// libm stands in for v_rsq_f32 / v_sqrt_f32 / v_rcp_f32 (correctly rounded instead of 1 ulp) and a "wave" is one lane.
+#ifdef SO3_HOST_MODEL
+#include <algorithm>
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 namespace so3 {
+
+namespace hw {
+#ifdef SO3_HOST_MODEL
+using std::min;
+inline float rsq(float x) { return 1.0f / std::sqrt(x); }
+inline float sqrt(float x) { return std::sqrt(x); }
+inline float rcp(float x) { return 1.0f / x; }
+inline int frexp_exp(float x) { int e = 0; if (x != 0.0f && std::isfinite(x)) std::frexp(x, &e); return e; }
+inline int frexp_exp(double x) { int e = 0; if (x != 0.0 && std::isfinite(x)) std::frexp(x, &e); return e; }
+inline bool any_lane(bool p) { return p; }
+#else
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }       // v_rsq_f32, 1 ulp
+__device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }     // v_sqrt_f32, 1 ulp
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32, 1 ulp
+__device__ __forceinline__ int frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }   // 0 for 0, inf and NaN
+__device__ __forceinline__ int frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+#endif
+}  // namespace hw
 
 #ifndef SO3_REUSE_NORMS
 #define SO3_REUSE_NORMS 0   // 1 breaks orthogonality for s2/s1 < 1e-2 (tools/illcond_check.py): kept off
@@ -80,14 +109,14 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ float abs(float a) { return fabsf(a); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float copysign(float a, float b) { return copysignf(a, b); }
-    static __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }     // v_rsq_f32, 1 ulp
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32, 1 ulp
-    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+    static __device__ __forceinline__ float rsq(float x) { return hw::rsq(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return hw::sqrt(x); }
+    static __device__ __forceinline__ float rcp(float x) { return hw::rcp(x); }
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }                     // full-range libm forms
     static __device__ __forceinline__ float cos(float x) { return cosf(x); }
     static __device__ __forceinline__ void sincos(float x, float &s, float &c) { sincosf(x, &s, &c); }   // one range reduction
     // exponent that brings x into [0.5, 1), clamped so that 2^e stays finite (denormal input)
-    static __device__ __forceinline__ int neg_frexp_exp(float x) { return min(-__builtin_amdgcn_frexp_expf(x), 126); }
+    static __device__ __forceinline__ int neg_frexp_exp(float x) { using namespace hw; return min(-hw::frexp_exp(x), 126); }
     static __device__ __forceinline__ float ldexp(float x, int e) { return ldexpf(x, e); }
     static __device__ __forceinline__ float sel(bool c, float a, float b) { return c ? a : b; }
     static __device__ __forceinline__ bool le(float a, float b) { return a <= b; }
@@ -109,9 +138,9 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ f32x2 abs(f32x2 a) { return __builtin_elementwise_abs(a); }
     static __device__ __forceinline__ f32x2 max(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
     static __device__ __forceinline__ f32x2 copysign(f32x2 a, f32x2 b) { return f32x2{copysignf(a.x, b.x), copysignf(a.y, b.y)}; }
-    static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
-    static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)}; }
-    static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+    static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{hw::rsq(x.x), hw::rsq(x.y)}; }
+    static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return f32x2{hw::sqrt(x.x), hw::sqrt(x.y)}; }
+    static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{hw::rcp(x.x), hw::rcp(x.y)}; }
     static __device__ __forceinline__ f32x2 sin(f32x2 x) { return f32x2{sinf(x.x), sinf(x.y)}; }
     static __device__ __forceinline__ f32x2 cos(f32x2 x) { return f32x2{cosf(x.x), cosf(x.y)}; }
     static __device__ __forceinline__ void sincos(f32x2 x, f32x2 &s, f32x2 &c) {
@@ -122,7 +151,8 @@ template <> struct Tr<f32x2> {
         c = f32x2{c0, c1};
     }
     static __device__ __forceinline__ i32x2 neg_frexp_exp(f32x2 x) {
-        return i32x2{min(-__builtin_amdgcn_frexp_expf(x.x), 126), min(-__builtin_amdgcn_frexp_expf(x.y), 126)};
+        using namespace hw;
+        return i32x2{min(-hw::frexp_exp(x.x), 126), min(-hw::frexp_exp(x.y), 126)};
     }
     static __device__ __forceinline__ f32x2 ldexp(f32x2 x, i32x2 e) { return f32x2{ldexpf(x.x, e.x), ldexpf(x.y, e.y)}; }
     static __device__ __forceinline__ f32x2 sel(bool2 c, f32x2 a, f32x2 b) { return f32x2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
@@ -149,7 +179,7 @@ template <> struct Tr<double> {           // one matrix per lane in float64 (so3
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }          // correctly rounded
     static __device__ __forceinline__ double rsq(double x) { return 1.0 / __builtin_sqrt(x); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-    static __device__ __forceinline__ int neg_frexp_exp(double x) { return min(-__builtin_amdgcn_frexp_exp(x), 1022); }
+    static __device__ __forceinline__ int neg_frexp_exp(double x) { using namespace hw; return min(-hw::frexp_exp(x), 1022); }
     static __device__ __forceinline__ double ldexp(double x, int e) { return ::ldexp(x, e); }
     static __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
     static __device__ __forceinline__ bool le(double a, double b) { return a <= b; }
@@ -200,7 +230,7 @@ template <class T> __device__ __forceinline__ void rotate(V3<T> &p, V3<T> &q) {
 }
 
 // True if the predicate holds on any lane of the wave (the result is wave-uniform: a scalar branch).
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ bool wave_any(bool p) { return hw::any_lane(p); }
 
 // A unit vector orthogonal to the unit vector u: e_k x u, k = index of the smallest |u_k| (z first).
 template <class S> __device__ __forceinline__ V3<S> any_perp(V3<S> u) {

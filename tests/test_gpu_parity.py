@@ -208,6 +208,28 @@ def test_a_row_does_not_depend_on_its_neighbours(rr):
     assert torch.equal(rr.symmetric_orthogonalization(x[shuffled]), full.detach()[shuffled])
 
 
+def test_device_rows_match_the_host_model_of_the_same_templates(rr):
+    """csrc/so3_device.h compiled for the host (oracle/kernel_model.cpp) against the device: same algorithm, the only
+    difference being 1-ulp v_rsq/v_sqrt/v_rcp versus correctly rounded libm."""
+    from oracle import kernel_model as km
+    from oracle import so3_oracle as so
+    if km.clangxx() is None:
+        pytest.skip("clang++ is not available")
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((200_000, 9)).astype(np.float32)
+    x[:1000] = (rng.standard_normal((1000, 3, 1)) @ rng.standard_normal((1000, 1, 3))).reshape(1000, 9)   # rank one
+    x[1000:2000] = rng.integers(-3, 4, (1000, 9))
+    r_dev, flip_dev = rr.symmetric_orthogonalization_with_flip(dev(x))
+    r_mod, flip_mod = km.project(x, want_flip=True)
+    assert np.array_equal(flip_dev.cpu().numpy(), flip_mod)
+    _, s, d = so.symmetric_orthogonalization_np(x, return_parts=True)
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / np.maximum(s[:, 0], 1e-300)
+    diff = np.abs(r_dev.cpu().numpy() - r_mod).reshape(len(x), -1).max(1)
+    ok = gap > 1e-6
+    assert (diff * gap)[ok].max() < 3e-6                      # a different rounding of rsq may flip the adaptive-sweep decision
+    assert np.median(diff[ok]) < 2e-7
+
+
 def test_nan_rows_stay_local(rr):
     x = torch.randn(300, 9, device=DEV)
     x[7, 4] = float("nan")

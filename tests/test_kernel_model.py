@@ -1,0 +1,105 @@
+"""The kernels' own templates (csrc/so3_device.h) compiled for the host (oracle/kernel_model.cpp) and driven on the CPU:
+golden vectors, adversarial families, batch invariance of the packed path, backward, float64 variant.  No GPU needed;
+tests/test_gpu_parity.py checks that the device produces the same rows."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, orth_err
+
+so = pytest.importorskip("oracle.so3_oracle")
+
+
+@pytest.fixture(scope="module")
+def km():
+    from oracle import kernel_model
+    if kernel_model.clangxx() is None:
+        pytest.skip("clang++ (for ext_vector_type) is not available")
+    kernel_model.build()
+    return kernel_model
+
+
+def _families(n, rng):
+    a = rng.standard_normal((n, 3, 3))
+    q1 = so.symmetric_orthogonalization_np(rng.standard_normal((n, 9)))
+    q2 = so.symmetric_orthogonalization_np(rng.standard_normal((n, 9)))
+
+    def with_s(s):
+        return q1 @ (s[:, :, None] * q2)
+    yield "gaussian", a
+    for e in (1e-1, 1e-4, 1e-7):
+        s = np.ones((n, 3)); s[:, 1] -= e * rng.random(n); s[:, 2] -= 2 * e * rng.random(n)
+        yield "clustered %.0e" % e, with_s(s)
+    for e in (1e-2, 1e-4, 1e-6):
+        yield "graded %.0e" % e, with_s(np.stack((np.ones(n), np.full(n, e), np.full(n, e * e)), 1))
+    yield "rotation + noise", q1 + 1e-3 * a
+    yield "symmetric", a + a.transpose(0, 2, 1)
+    yield "small integers", rng.integers(-3, 4, (n, 3, 3)).astype(np.float64)
+    yield "outer products", rng.standard_normal((n, 3, 1)) @ rng.standard_normal((n, 1, 3))
+    yield "integer outer products", (rng.integers(-3, 4, (n, 3, 1)) @ rng.integers(-3, 4, (n, 1, 3))).astype(np.float64)
+    yield "nine equal entries", np.broadcast_to(rng.standard_normal((n, 1, 1)), (n, 3, 3)).copy()
+    yield "rank two", np.concatenate((a[:, :2], a[:, :1] + a[:, 1:2]), 1)
+    yield "scaled 1e18", 1e18 * a
+    yield "scaled 1e-18", 1e-18 * a
+
+
+def test_model_against_golden_vectors(km):
+    g = load_golden("g1_gaussian256.npz")
+    r, flip = km.project(g["x"], want_flip=True)
+    assert np.array_equal(flip, g["det"] < 0)
+    assert orth_err(r).max() < 1e-5 and np.abs(r - g["r_f64"]).max() < 2e-5
+    g2 = load_golden("g2_adversarial.npz")
+    r2 = km.project(g2["x"])
+    assert orth_err(r2).max() < 1e-5 and np.abs(np.linalg.det(r2.astype(np.float64)) - 1).max() < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_model_on_adversarial_families(km, dtype):
+    rng = np.random.default_rng(2024)
+    n = 20000
+    for name, m in _families(n, rng):
+        m32 = m.astype(np.float32)
+        if dtype == "f32":
+            r = km.project(m32).astype(np.float64)
+            assert np.array_equal(km.project(m32, packed=True).astype(np.float64), r), name      # packed path: same rows
+            tol_orth, tol_cond, tol_opt = 1e-5, 1e-5, 2e-6
+        else:
+            r = km.project_f64(m32.astype(np.float64))
+            tol_orth, tol_cond, tol_opt = 1e-12, 1e-11, 1e-12
+        assert orth_err(r).max() < tol_orth and np.abs(np.linalg.det(r) - 1).max() < 10 * tol_orth, name
+        ref, s, d = so.symmetric_orthogonalization_np(m32, return_parts=True)
+        gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / np.maximum(s[:, 0], 1e-300)
+        ok = gap > 1e-6
+        if ok.any():
+            assert (np.abs(r - ref).reshape(n, -1).max(1) * gap)[ok].max() < tol_cond, name
+        # optimality (defined even where R is not unique): tr(R^T M) = s1 + s2 +- s3
+        best = s[:, 0] + s[:, 1] + np.where(np.linalg.det(m32.astype(np.float64)) < 0, -s[:, 2], s[:, 2])
+        got = (r * m32.astype(np.float64)).sum((1, 2))
+        assert ((best - got) / np.maximum(s[:, 0], 1e-300)).max() < tol_opt, name
+
+
+def test_model_special_rows(km):
+    x = np.zeros((6, 9), np.float32)
+    x[1] = np.eye(3).ravel()
+    x[2] = np.diag([1.0, 1.0, -1.0]).ravel()                 # reflection -> identity, as the reference
+    x[3] = np.diag([2.0, 2.0, 2.0]).ravel()
+    x[4] = np.nan
+    x[5] = [0, 1, 0, 0, 0, 1, 1, 0, 0]                        # a permutation that is a rotation: returned as is
+    r = km.project(x)
+    assert np.array_equal(r[0], np.eye(3)) and np.array_equal(r[1], np.eye(3)) and np.abs(r[2] - np.eye(3)).max() < 1e-7
+    assert np.abs(r[3] - np.eye(3)).max() < 1e-7 and np.isnan(r[4]).all() and np.abs(r[5] - x[5].reshape(3, 3)).max() < 1e-7
+
+
+def test_model_backward_against_the_closed_form(km):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((50000, 9)).astype(np.float32)
+    g = rng.standard_normal((50000, 9)).astype(np.float32)
+    ref = so.projection_backward_np(x, g)
+    _, s, d = so.symmetric_orthogonalization_np(x, return_parts=True)
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0]
+    err = np.abs(km.project_bwd(x, g) - ref).reshape(len(x), -1).max(1) * s[:, 0] * gap * gap
+    assert np.median(err) < 1e-6 and err.max() < 2e-5
+    err64 = np.abs(km.project_bwd_f64(x.astype(np.float64), g.astype(np.float64)) - ref).reshape(len(x), -1).max(1) * s[:, 0] * gap * gap
+    assert err64.max() < 1e-11
+    # rank-deficient rows: floored denominators, finite gradients
+    low = (rng.standard_normal((1000, 3, 1)) @ rng.standard_normal((1000, 1, 3))).astype(np.float32)
+    assert np.isfinite(km.project_bwd(low, g[:1000])).all()
