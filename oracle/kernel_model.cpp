@@ -7,7 +7,7 @@
 #define SO3_HOST_MODEL 1
 #include <stdint.h>
 
-#include "../poseestimation_amd/csrc/so3_device.h"
+#include "../poseestimation_amd/csrc/so3_rows.h"      // includes so3_device.h; engine and K1..K4 store paths are device-only
 
 extern "C" {
 
@@ -66,4 +66,40 @@ void model_project_bwd_f64(const double *M, const double *G, double *dM, int64_t
     }
 }
 
+}  // extern "C"
+
+// ---- the pure per-row operations of so3_rows.h (heads f2 / f5, SE(3) update f1), one row at a time ----------------
+namespace {
+template <class Op> void run_rows(Op op, const float *in0, const float *in1, const float *in2, float *out, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        so3::Rows<float, Op> rows;
+        so3::RowCtx<1> ctx{};
+        for (int i = 0; i < Op::kIn0N; ++i) rows.a[i] = in0[b * Op::kIn0N + i];
+        if (Op::kIn1 != 0) for (int i = 0; i < Op::kIn1N; ++i) rows.b[i] = in1[b * Op::kIn1N + i];
+        if (Op::kIn2 != 0) for (int i = 0; i < Op::kIn2N; ++i) rows.c[i] = in2[b * Op::kIn2N + i];
+        op.template compute<float, 1>(rows, ctx);
+        for (int i = 0; i < Op::kOut0N; ++i) out[b * Op::kOut0N + i] = rows.o0[i];
+    }
+}
+}  // namespace
+
+extern "C" {
+#define MODEL_HEAD(NAME, FWD, BWD)                                                                             \
+    void model_##NAME##_fwd(const float *X, float *R, int64_t B) { run_rows(FWD{}, X, nullptr, nullptr, R, B); } \
+    void model_##NAME##_bwd(const float *X, const float *G, float *dX, int64_t B) { run_rows(BWD{}, X, G, nullptr, dX, B); }
+MODEL_HEAD(quat, so3::OpQuat<false>, so3::OpQuat<true>)
+MODEL_HEAD(euler, so3::OpEuler<false>, so3::OpEuler<true>)
+MODEL_HEAD(ortho5d, so3::OpOrtho5d<false>, so3::OpOrtho5d<true>)
+MODEL_HEAD(expmap, so3::OpExpMap<false>, so3::OpExpMap<true>)
+MODEL_HEAD(ortho6d, so3::OpOrtho6d, so3::OpOrtho6dBwd)
+#undef MODEL_HEAD
+
+void model_se3_update(const float *out12, const float *Tinit, float *Tpred, float fx, float fy, int64_t B) {
+    so3::OpSe3Update op; op.inv_fx = 1.0f / fx; op.inv_fy = 1.0f / fy;
+    run_rows(op, out12, Tinit, nullptr, Tpred, B);
+}
+void model_se3_update_bwd(const float *out12, const float *Tinit, const float *G, float *dout12, float fx, float fy, int64_t B) {
+    so3::OpSe3UpdateBwd op; op.inv_fx = 1.0f / fx; op.inv_fy = 1.0f / fy;
+    run_rows(op, out12, Tinit, G, dout12, B);
+}
 }  // extern "C"

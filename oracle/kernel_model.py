@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "kernel_model.cpp")
-HDR = os.path.join(_HERE, "..", "poseestimation_amd", "csrc", "so3_device.h")
+HDRS = [os.path.join(_HERE, "..", "poseestimation_amd", "csrc", h) for h in ("so3_device.h", "so3_rows.h")]
 LIB = os.path.join(_HERE, "libso3model.so")
 _lib = None
 
@@ -26,7 +26,7 @@ def build(force: bool = False) -> str:
     cxx = clangxx()
     if cxx is None:
         raise RuntimeError("kernel_model needs clang++ (ext_vector_type); none found")
-    stale = force or not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in (SRC, HDR))
+    stale = force or not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in [SRC] + HDRS)
     if stale:
         subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC])
         os.replace(LIB + ".tmp", LIB)
@@ -79,3 +79,38 @@ def project_bwd_f64(m, g):
     d = np.empty_like(m)
     lib().model_project_bwd_f64(_p(m), _p(g), _p(d), ctypes.c_int64(m.shape[0]))
     return d.reshape(-1, 3, 3)
+
+
+HEAD_WIDTH = {"quat": 4, "euler": 3, "ortho5d": 5, "expmap": 3, "ortho6d": 6}
+
+
+def head(name, x):
+    x = np.ascontiguousarray(np.asarray(x, np.float32).reshape(-1, HEAD_WIDTH[name]))
+    r = np.empty((x.shape[0], 9), np.float32)
+    getattr(lib(), "model_%s_fwd" % name)(_p(x), _p(r), ctypes.c_int64(x.shape[0]))
+    return r.reshape(-1, 3, 3)
+
+
+def head_bwd(name, x, g):
+    x = np.ascontiguousarray(np.asarray(x, np.float32).reshape(-1, HEAD_WIDTH[name]))
+    g = _c(g, np.float32)
+    d = np.empty_like(x)
+    getattr(lib(), "model_%s_bwd" % name)(_p(x), _p(g), _p(d), ctypes.c_int64(x.shape[0]))
+    return d
+
+
+def se3_update(out12, t_init, fx, fy):
+    o = np.ascontiguousarray(np.asarray(out12, np.float32).reshape(-1, 12))
+    t = np.ascontiguousarray(np.asarray(t_init, np.float32).reshape(-1, 16))
+    r = np.empty_like(t)
+    lib().model_se3_update(_p(o), _p(t), _p(r), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_int64(o.shape[0]))
+    return r.reshape(-1, 4, 4)
+
+
+def se3_update_bwd(out12, t_init, g, fx, fy):
+    o = np.ascontiguousarray(np.asarray(out12, np.float32).reshape(-1, 12))
+    t = np.ascontiguousarray(np.asarray(t_init, np.float32).reshape(-1, 16))
+    g = np.ascontiguousarray(np.asarray(g, np.float32).reshape(-1, 16))
+    d = np.empty_like(o)
+    lib().model_se3_update_bwd(_p(o), _p(t), _p(g), _p(d), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_int64(o.shape[0]))
+    return d

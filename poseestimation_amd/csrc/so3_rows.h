@@ -21,12 +21,15 @@
 //   * Reductions (loss, sum of angles) stay in a per-lane float64 register until the wave retires; one atomic
 //     per WORKGROUP then publishes them (same-address float64 atomics cost ~12 ns each).
 #pragma once
+#ifndef SO3_HOST_MODEL              // (oracle/kernel_model.cpp compiles the pure per-row operations for the host)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "so3_device.h"
 
 namespace so3 {
+#ifndef SO3_HOST_MODEL
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -117,6 +120,8 @@ template <int BYTES> __device__ __forceinline__ rsrc_t row_rsrc(void *base, int6
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, exists ? kUnitRows * BYTES : 0, kRsrcFlags);
 }
 
+#endif  // !SO3_HOST_MODEL
+
 template <int NPL> struct LaneT;
 template <> struct LaneT<1> { typedef float type; };
 template <> struct LaneT<2> { typedef f32x2 type; };
@@ -136,6 +141,7 @@ template <int NPL> struct RowCtx {
     bool flag;              // per-lane sticky flag (K4: cosine out of range)
 };
 
+#ifndef SO3_HOST_MODEL
 // ---- the engine ----------------------------------------------------------------------------------------
 // Op provides: kIn0, kIn1, kIn2, kOut0, kOut1 (element bytes, 0 = absent), pointers in0, in1, in2, out0, out1,
 //   kIn0N .. kOut1N (elements per row, 9 unless overridden),
@@ -292,6 +298,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     }
 }
 
+#endif  // !SO3_HOST_MODEL
+
 // ---- the operations --------------------------------------------------------------------------------------
 struct OpBase {
     static constexpr int kIn2 = 0;                                         // most operations have at most two inputs
@@ -302,6 +310,7 @@ struct OpBase {
     __device__ __forceinline__ void finish(double, bool) const {}
 };
 
+#ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
 // K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206).  SWEEPS < 0: copy (diagnostic).
 template <int IN_BYTES, bool FLIP, int SWEEPS = kSweeps, bool ADAPT = true>
 struct OpProject : OpBase {
@@ -509,6 +518,8 @@ struct OpGeodesic : OpBase {
         }
     }
 };
+
+#endif  // !SO3_HOST_MODEL
 
 // ---- next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36) --------------------------------
 // x = a/|a|,  z = (x x b)/|x x b|,  y = z x x,  R = [x y z] (columns); a, b = the two halves of the 6-vector.

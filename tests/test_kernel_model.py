@@ -103,3 +103,46 @@ def test_model_backward_against_the_closed_form(km):
     # rank-deficient rows: floored denominators, finite gradients
     low = (rng.standard_normal((1000, 3, 1)) @ rng.standard_normal((1000, 1, 3))).astype(np.float32)
     assert np.isfinite(km.project_bwd(low, g[:1000])).all()
+
+
+@pytest.mark.parametrize("name", ["quat", "euler", "ortho5d", "expmap"])
+def test_model_heads_against_golden_and_oracle(km, name):
+    """Rows f2 / f5: the head operations of csrc/so3_rows.h on the host, against the reference's own outputs (G10) and
+    float64 autograd through the restatement."""
+    g = load_golden("g10_heads.npz")
+    x, gr = g[name + "_x"], g[name + "_g"]
+    assert np.abs(km.head(name, x) - g[name + "_r"]).max() < 5e-6
+    ref = so.head_backward_np(name, x.astype(np.float64), gr.astype(np.float64))
+    scale = np.maximum(np.abs(ref).max(axis=1), 1.0)
+    err = np.abs(km.head_bwd(name, x, gr) - ref).max(axis=1) / scale
+    ref_err = np.abs(g[name + "_dx"] - ref).max(axis=1) / scale
+    assert np.median(err) < 2e-6 and err.max() < max(2e-5, 2.0 * ref_err.max())
+    rng = np.random.default_rng(5)
+    xs = rng.standard_normal((20000, km.HEAD_WIDTH[name])) * rng.choice([1e-3, 1.0, 30.0], (20000, 1))
+    e = np.abs(km.head(name, xs) - so.head_np(name, xs.astype(np.float32))).reshape(20000, -1).max(1)
+    assert np.median(e) < 3e-7 and np.quantile(e, 0.999) < 2e-5
+
+
+def test_model_ortho6d_and_se3_update(km):
+    g7 = load_golden("g7_ortho6d.npz")
+    assert np.abs(km.head("ortho6d", g7["p"]) - g7["r"]).max() < 2e-6
+    ref = g7["dp_f64"]
+    rel = np.abs(km.head_bwd("ortho6d", g7["p"], g7["g"]) - ref).max(1) / (1e-3 + np.abs(ref).max(1))
+    assert np.median(rel) < 1e-6 and rel.max() < 2e-4
+    rng = np.random.default_rng(8)
+    b = 5000
+    out = rng.standard_normal((b, 12)).astype(np.float32)
+    out[:, 11] = 1 + 0.05 * rng.standard_normal(b)
+    t = np.tile(np.eye(4, dtype=np.float32), (b, 1, 1))
+    t[:, :3, :3] = so.symmetric_orthogonalization_np(rng.standard_normal((b, 9)))
+    t[:, :3, 3] = [0.0, 0.0, 2.0] + 0.2 * rng.standard_normal((b, 3))
+    fx = fy = 50 / (36 / 320)
+    tp = km.se3_update(out, t, fx, fy)
+    ref = so.se3_update_np(out, t, fx, fy)
+    _, s, d = so.symmetric_orthogonalization_np(out[:, :9], return_parts=True)
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0]
+    assert (np.abs(tp - ref).reshape(b, -1).max(1) * gap).max() < 5e-6
+    gup = rng.standard_normal((b, 4, 4)).astype(np.float32)
+    dref = so.se3_update_backward_np(out, t, gup, fx, fy)
+    derr = np.abs(km.se3_update_bwd(out, t, gup, fx, fy) - dref).max(1) * np.minimum(1.0, s[:, 0] * gap * gap) / np.maximum(np.abs(dref).max(1), 1.0)
+    assert np.median(derr) < 1e-6 and derr.max() < 5e-5
