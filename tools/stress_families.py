@@ -9,7 +9,8 @@ from poseestimation_amd import rotation_representation as rr
 
 dev = "cuda:0"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-g = torch.Generator(device=dev).manual_seed(77)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 77
+g = torch.Generator(device=dev).manual_seed(seed)
 
 
 def rot(k):
@@ -57,11 +58,12 @@ for name, m64 in families():
     cols = [(r32[:, :, i] * r32[:, :, j]).sum(1) - (1.0 if i == j else 0.0) for i in range(3) for j in range(3)]
     orth = torch.stack(cols, 1).norm(dim=1)
     ok = gap > 1e-9
-    # backward on the same rows: float32 kernel against the float64 kernel, scaled by gap^2 (the denominators are s_i + s_j)
+    # backward on the same rows: float32 kernel against the float64 kernel, scaled by gap^2 (the denominators are s_i + s_j);
+    # reported over rows with gap > 1e-4 (below that float32 cannot tell s2 from s3 and the flip case is not differentiable)
     gup = torch.randn(n, 3, 3, device=dev, generator=g)
     x32 = m32.clone().requires_grad_(True); rr.symmetric_orthogonalization(x32).backward(gup)
     x64 = m32.double().requires_grad_(True); rr.symmetric_orthogonalization(x64).backward(gup.double())
     gerr = (x32.grad.double() - x64.grad).abs().flatten(1).amax(1) * s[:, 0] * gap * gap
     gfin = bool(torch.isfinite(x32.grad).all())
     print("%-44s bwd finite %s, max |dM32-dM64| s1 gap^2 %.1e | orth %.2e (f64 %.1e)   max err*gap %.2e   median err %.2e   (rows with gap > 1e-9: %d)" %
-          (name, gfin, gerr[ok].max().item() if ok.any() else float("nan"), orth.max().item(), orth64, (err * gap)[ok].max().item() if ok.any() else float("nan"), err.median().item(), int(ok.sum())), flush=True)
+          (name, gfin, gerr[gap > 1e-4].max().item() if (gap > 1e-4).any() else float("nan"), orth.max().item(), orth64, (err * gap)[ok].max().item() if ok.any() else float("nan"), err.median().item(), int(ok.sum())), flush=True)
