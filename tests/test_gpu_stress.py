@@ -228,3 +228,56 @@ def test_fused_training_step_on_bf16_and_degenerate_rows(rr):
             # bf16 gradient storage: 3 significant digits of each entry
             ref_mag = x64.grad.abs().flatten(1).amax(1) * s[:, 0] * gap * gap * n
             assert (gerr[ok] <= 1e-2 * ref_mag[ok] + 1e-4).all(), name
+
+
+def test_every_entry_point_is_graph_capturable():
+    """Enqueue-only contract for the whole ABI: a refiner step, an evaluation step and the point-cloud path recorded into
+    one hipGraph (memsets of the loss accumulators included) replay to the values of the eager calls."""
+    import ctypes
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    p = lambda t: P(t.data_ptr())
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    b, npts = 1000, 300
+    out12 = torch.randn(b, 12, device=DEV, generator=gen); out12[:, 11] = 1.0
+    t_init = torch.eye(4, device=DEV).repeat(b, 1, 1).contiguous(); t_init[:, 2, 3] = 2.0
+    t_gt = t_init.clone(); t_gt[:, :3, 3] += 0.05
+    pts = torch.randn(b, npts, 3, device=DEV, generator=gen)
+    fx = ctypes.c_float(444.4)
+    bufs = {k: torch.zeros(s, device=DEV, dtype=d) for k, (s, d) in {
+        "tp": ((b, 16), torch.float32), "dt": ((b, 16), torch.float32), "do": ((b, 12), torch.float32), "l3": ((3,), torch.float64),
+        "r": ((b, 9), torch.float32), "sc": ((2,), torch.float64), "fl": ((1,), torch.int32), "ls": ((1,), torch.float64),
+        "dm": ((b, 9), torch.float32), "rk": ((b, 9), torch.float32), "q": ((b, npts, 3), torch.float32), "dq": ((b, 4), torch.float32),
+        "rq": ((b, 9), torch.float32)}.items()}
+
+    def enqueue(st):
+        rc = 0
+        rc |= lib.so3_se3_update_f32(p(out12), p(t_init), p(bufs["tp"]), fx, fx, b, st)
+        rc |= lib.so3_add_l1_disentangled_f32(p(bufs["tp"]), p(t_gt), p(pts), p(bufs["l3"]), p(bufs["dt"]), ctypes.c_float(1.0 / b), b, npts, st)
+        rc |= lib.so3_se3_update_bwd_f32(p(out12), p(t_init), p(bufs["dt"]), p(bufs["do"]), fx, fx, b, st)
+        rc |= lib.so3_project_angle_error_f32(p(pts), p(pts), p(bufs["r"]), None, p(bufs["sc"]), p(bufs["fl"]), 0, b, st)   # first 9 floats of each cloud row as M
+        rc |= lib.so3_frob_loss_f32(p(bufs["r"]), p(bufs["r"]), p(bufs["dm"]), p(bufs["ls"]), b, st)
+        rc |= lib.so3_rotate_clouds_f32(p(pts), p(bufs["r"]), p(bufs["q"]), 0, b, npts, st)
+        rc |= lib.so3_kabsch_f32(p(pts), p(bufs["q"]), p(bufs["rk"]), None, b, npts, st)
+        rc |= lib.so3_quat_fwd_f32(p(bufs["tp"]), p(bufs["rq"]), b, st)                                 # first 4 floats of every T row as a quaternion
+        rc |= lib.so3_quat_bwd_f32(p(bufs["tp"]), p(bufs["r"]), p(bufs["dq"]), b, st)
+        return rc
+
+    st = P(torch.cuda.current_stream().cuda_stream)
+    assert enqueue(st) == 0
+    torch.cuda.synchronize()
+    eager = {k: v.clone() for k, v in bufs.items()}
+    for v in bufs.values():
+        v.zero_()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        assert enqueue(P(torch.cuda.current_stream().cuda_stream)) == 0
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    for k in bufs:
+        a, e = bufs[k].double(), eager[k].double()
+        assert torch.allclose(a, e, rtol=1e-12, atol=0, equal_nan=True) or (a - e).abs().max().item() < 1e-9 * max(1.0, e.abs().max().item()), k
+    assert (bufs["rk"] - bufs["r"]).abs().max().item() < 5e-5          # and Kabsch recovers the rotation it was given
