@@ -207,8 +207,14 @@ def main():
                         step(i)
             stream = side
             torch.cuda.synchronize()
-            graph.replay()                     # one untimed replay: graph upload / first-touch effects
-            torch.cuda.synchronize()
+            # Untimed replays: graph upload / first-touch effects, and the shader clock, which needs ~20 ms of load to
+            # come out of its idle state (tools/k1_ramp.py).  One replay when K = 1000; more only for a short graph.
+            t_pre = time.perf_counter()
+            for _ in range(200):
+                graph.replay()
+                torch.cuda.synchronize()
+                if time.perf_counter() - t_pre >= 0.015:
+                    break
         except Exception as exc:               # submission mode only: the same kernels are then launched eagerly
             print(f"[bench] hipGraph capture failed ({exc!r}); falling back to eager launches", file=sys.stderr)
             graph = None

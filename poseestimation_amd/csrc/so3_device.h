@@ -94,6 +94,7 @@ struct bool2 {
 };
 __device__ __forceinline__ bool2 operator&(bool2 a, bool2 b) { return bool2{a.x && b.x, a.y && b.y}; }
 __device__ __forceinline__ bool2 operator|(bool2 a, bool2 b) { return bool2{a.x || b.x, a.y || b.y}; }
+__device__ __forceinline__ bool2 operator^(bool2 a, bool2 b) { return bool2{a.x != b.x, a.y != b.y}; }
 
 // ---- scalar-type traits ------------------------------------------------------------------------------
 template <class T> struct Tr;
@@ -313,18 +314,20 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     // orthogonalised against it -- with a numerically zero x first (rank-one input) v1 would be noise and would drag
     // the one meaningful direction with it.  R does not depend on the order of the pair (u3 and v3 flip together);
     // s3' = u3 . z does, through the handedness of (x, y, z): `swapped` undoes it.
+    // Three comparisons give a total preorder (column 2 enters them shrunk by the tie factor, so it loses near-ties):
+    //   a column is the largest if it wins both of its comparisons and the middle one if it wins exactly one.
     const T n2t = n2 * R::splat(K::tie);
-    const typename R::mask z2 = R::le(n2t, n0) & R::le(n2t, n1);         // min is column 2
-    const typename R::mask z0 = R::le(n0, n1);                           // (else) min is column 0, otherwise column 1
-    const typename R::mask g12 = R::ge(n1, n2), g20 = R::ge(n2, n0);
-    const typename R::mask nz2 = R::mnot(z2), nz0 = R::mnot(z0);
-    const typename R::mask x0 = nz0 & (z2 | R::mnot(g20)), x1 = z0 & (z2 | g12);
-    const typename R::mask y0 = (z2 & z0) | (nz2 & nz0 & g20), y1 = (z2 & nz0) | (nz2 & z0 & R::mnot(g12));
-    const typename R::mask swapped = (z2 & z0) | (nz2 & z0 & R::mnot(g12)) | (nz2 & nz0 & R::mnot(g20));
+    const typename R::mask c01 = R::ge(n0, n1), c02 = R::ge(n0, n2t), c12 = R::ge(n1, n2t);
+    const typename R::mask nc01 = R::mnot(c01);
+    const typename R::mask x0 = c01 & c02, x1 = nc01 & c12;                      // else column 2
+    const typename R::mask y0 = c01 ^ c02, y1 = R::mnot(c01 ^ c12);              // else column 2
     const V3<T> x = sel<T>(x0, a0, sel<T>(x1, a1, a2));
     const V3<T> y = sel<T>(y0, a0, sel<T>(y1, a1, a2));
-    const V3<T> z = sel<T>(z2, a2, sel<T>(z0, a0, a1));
     const T nx = R::sel(x0, n0, R::sel(x1, n1, n2));
+    // (x, y, z) is an odd permutation of the columns for (1,0,2), (0,2,1), (2,1,0)
+    const typename R::mask z0m = nc01 & R::mnot(c02), z2m = c02 & c12;
+    const typename R::mask swapped = (x1 & y0) | (x0 & R::mnot(y0 | y1)) | (R::mnot(x0 | x1) & y1);
+    const V3<T> z = sel<T>(z2m, a2, sel<T>(z0m, a0, a1));
 
     const T inx = R::rsq(nx);
     V3<T> u1 = scale<T>(x, inx);
@@ -366,8 +369,8 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
 #if SO3_REUSE_NORMS
     const T pt = R::splat(S(0));
 #endif
-    const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, R::max(tiny, lost * qy * qy)) | R::le(nt1, tiny)
-                                        | R::le(nr2, R::max(tiny, lost * pt * pt));
+    const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, R::fma(lost * qy, qy, tiny)) | R::le(nt1, tiny)
+                                        | R::le(nr2, R::fma(lost * pt, pt, tiny));
     if (__builtin_expect(R::any(degenerate), 0)) {
 #pragma unroll
         for (int i = 0; i < R::kLanes; ++i) {
