@@ -190,6 +190,13 @@ def test_a_row_does_not_depend_on_its_neighbours(rr):
     gen = torch.Generator(device=DEV).manual_seed(77)
     n = 100_000
     x = torch.randn(n, 9, device=DEV, generator=gen)
+    # degenerate rows among the ordinary ones: zeros, exact rank one, huge and tiny scales (absolute constants of the
+    # algorithm -- the 1e-18 in the rotation, the rank thresholds -- must not make a row depend on its wave-mates)
+    x[5::97] = 0.0
+    x[11::89] = (torch.randint(-3, 4, (len(x[11::89]), 3, 1), device=DEV, generator=gen).float()
+                 @ torch.randint(-3, 4, (len(x[11::89]), 1, 3), device=DEV, generator=gen).float()).reshape(-1, 9)
+    x[17::83] *= 1e18
+    x[23::79] *= 1e-18
     gup = torch.randn(n, 3, 3, device=DEV, generator=gen)
     full_x = x.clone().requires_grad_(True)
     full = rr.symmetric_orthogonalization(full_x)
