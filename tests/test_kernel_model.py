@@ -146,3 +146,27 @@ def test_model_ortho6d_and_se3_update(km):
     dref = so.se3_update_backward_np(out, t, gup, fx, fy)
     derr = np.abs(km.se3_update_bwd(out, t, gup, fx, fy) - dref).max(1) * np.minimum(1.0, s[:, 0] * gap * gap) / np.maximum(np.abs(dref).max(1), 1.0)
     assert np.median(derr) < 1e-6 and derr.max() < 5e-5
+
+
+def test_model_property_any_finite_float32_matrix_gives_the_optimal_rotation(km):
+    """Property test over arbitrary finite float32 entries (subnormals, 1e38, exact zeros, repeated values ...):
+    the result is a rotation and attains max tr(R^T M) = s1 + s2 +- s3."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=600, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(hnp.arrays(np.float32, (9,), elements=st.floats(width=32, allow_nan=False, allow_infinity=False)))
+    def prop(m):
+        r = km.project(m.reshape(1, 9))[0].astype(np.float64)
+        assert np.isfinite(r).all()
+        assert np.linalg.norm(r.T @ r - np.eye(3)) < 1e-5 and abs(np.linalg.det(r) - 1) < 1e-5
+        mm = m.reshape(3, 3).astype(np.float64)
+        if np.abs(mm).max() > 0:
+            mm = mm / np.abs(mm).max()
+            s = np.linalg.svd(mm, compute_uv=False)
+            best = s[0] + s[1] + (s[2] if np.linalg.det(mm) >= 0 else -s[2])
+            assert (best - (r * mm).sum()) / s[0] < 5e-6
+
+    prop()
