@@ -281,3 +281,30 @@ def test_every_entry_point_is_graph_capturable():
         a, e = bufs[k].double(), eager[k].double()
         assert torch.allclose(a, e, rtol=1e-12, atol=0, equal_nan=True) or (a - e).abs().max().item() < 1e-9 * max(1.0, e.abs().max().item()), k
     assert (bufs["rk"] - bufs["r"]).abs().max().item() < 5e-5          # and Kabsch recovers the rotation it was given
+
+
+def test_property_arbitrary_finite_float32_batches(rr):
+    """hypothesis over whole batches of arbitrary finite float32 values (subnormals, 1e38, zeros, repeats): every row of the
+    device result is a rotation attaining max tr(R^T M); the batch size is ragged (engine + tile kernel)."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(hnp.arrays(np.float32, (193, 9), elements=st.floats(width=32, allow_nan=False, allow_infinity=False)))
+    def prop(m):
+        r = rr.symmetric_orthogonalization(torch.from_numpy(m).to(DEV)).cpu().numpy().astype(np.float64)
+        assert np.isfinite(r).all()
+        assert orth_err(r).max() < 1e-5 and np.abs(np.linalg.det(r) - 1).max() < 1e-5
+        mm = m.reshape(-1, 3, 3).astype(np.float64)
+        mx = np.abs(mm).reshape(len(mm), -1).max(1)
+        ok = mx > 0
+        if not ok.any():
+            return
+        mm = mm[ok] / mx[ok, None, None]
+        s = np.linalg.svd(mm, compute_uv=False)
+        best = s[:, 0] + s[:, 1] + np.where(np.linalg.det(mm) >= 0, s[:, 2], -s[:, 2])
+        assert ((best - (r[ok] * mm).sum((1, 2))) / s[:, 0]).max() < 5e-6
+
+    prop()
