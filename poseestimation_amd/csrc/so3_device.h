@@ -68,10 +68,10 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #ifndef SO3_SWEEPS
 #define SO3_SWEEPS 3
 #endif
-// Sweep schedule: kSweeps fixed cyclic sweeps, then ONE more sweep if any matrix held by the wave still has
-// a relative off-orthogonality above kResidualTol (a wave-uniform branch).  On Gaussian input 99.93 % of the
-// rows are below 1e-5 after three sweeps and all are at round-off (2e-7) after four (tools/proto_jacobi.py),
-// so about one wave round in twelve takes the extra sweep.
+// Sweep schedule: kSweeps fixed cyclic sweeps, then -- if any matrix held by the wave still has a relative
+// off-orthogonality of its (0,1) pair above kResidualTol (a wave-uniform branch) -- one more rotation of that pair,
+// kept by the matrices that failed.  On Gaussian input 99.93 % of the rows are below 1e-5 after three sweeps
+// (tools/proto_jacobi.py), so about one wave round in eight takes the branch.
 constexpr int kSweeps = SO3_SWEEPS;
 constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|^2 |a_1|^2)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
@@ -298,10 +298,16 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
             if (!wave_any(R::any(need))) break;
             // The branch is wave-uniform, the update is per matrix: a row keeps its three-sweep columns unless IT failed
             // the test, so its result does not depend on which other rows happen to share the wave.
+            // float32: one more rotation of the pair that was tested is enough -- the other two residuals are already
+            // second order (gamma_12 = 0, gamma_02 = -s_12 gamma_01), and on 16 adversarial families the repaired rows end
+            // up as close to float64 LAPACK as after a full fourth sweep (|dR| gap/s1 <= 4.5e-7 either way).
+            // float64 (MAX_EXTRA > 1) keeps whole sweeps: it iterates down to 1e-14.
             V3<T> b0 = a0, b1 = a1, b2 = a2;
             rotate(b0, b1);
-            rotate(b0, b2);
-            rotate(b1, b2);
+            if (MAX_EXTRA > 1) {
+                rotate(b0, b2);
+                rotate(b1, b2);
+            }
             a0 = sel<T>(need, b0, a0); a1 = sel<T>(need, b1, a1); a2 = sel<T>(need, b2, a2);
             n0 = dot(a0, a0); n1 = dot(a1, a1); n2 = dot(a2, a2);
             if (MAX_EXTRA == 1 || ++extra >= MAX_EXTRA) break;      // (compile-time exit for the float32 kernels)
