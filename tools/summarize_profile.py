@@ -28,7 +28,7 @@ kt = list(csv.DictReader(open(one("kt/*/*kernel_trace.csv"))))
 k1 = [r for r in kt if KEY in r["Kernel_Name"]]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in k1]
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 1000 --warmup 50 --no-cpu-baseline (one hipGraph of 1000 launches + warm-up launches)",
+    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary (one hipGraph of 1000 launches + warm-up launches)",
     "kernel": k1[0]["Kernel_Name"][:120], "dispatches": len(d),
     "avg_us": statistics.mean(d), "median_us": statistics.median(d), "min_us": min(d), "max_us": max(d),
     "first_50_avg_us": statistics.mean(d[:50]), "last_100_avg_us": statistics.mean(d[-100:]),
