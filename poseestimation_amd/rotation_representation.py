@@ -53,6 +53,23 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~4 us per call)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev: torch.device):
+        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def _stream(dev: torch.device):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -101,7 +118,7 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
         b = m.shape[0]
         fn, _, out_dtype = _head_fns(m.dtype)
         r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(fn(_ptr(m), _ptr(r), None, b, _stream(dev)), "so3_project_fwd")
         ctx.save_for_backward(m)
         ctx.in_shape = x.shape
@@ -117,7 +134,7 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
         g = grad_r.reshape(-1, 9).contiguous().to(g_dtype)
         b = m.shape[0]
         dm = torch.empty_like(m)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(fn(_ptr(m), _ptr(g), _ptr(dm), b, _stream(dev)), "so3_project_bwd")
         return dm.to(ctx.in_dtype).view(ctx.in_shape)
 
@@ -129,6 +146,15 @@ def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
     Returns [batch_size, 3, 3] rotations R = U diag(1,1,det(UV^T)) V^T, differentiable: float32 for float32,
     bfloat16 and float16 input, float64 for float64 input.
     """
+    if isinstance(x, torch.Tensor) and not (x.requires_grad and torch.is_grad_enabled()):
+        # inference / evaluation loops: no autograd node to build
+        dev = _require_device(x)
+        m = _head_input(x)
+        fn, _, out_dtype = _head_fns(m.dtype)
+        r = torch.empty((m.shape[0], 3, 3), dtype=out_dtype, device=dev)
+        with _on_device(dev):
+            _lib.check(fn(_ptr(m), _ptr(r), None, m.shape[0], _stream(dev)), "so3_project_fwd")
+        return r
     return _SymmetricOrthogonalization.apply(x)
 
 
@@ -141,7 +167,7 @@ def symmetric_orthogonalization_with_flip(x: torch.Tensor):
     fn, _, out_dtype = _head_fns(m.dtype)
     r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
     flip = torch.empty((b,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(fn(_ptr(m), _ptr(r), _ptr(flip), b, _stream(dev)), "so3_project_fwd")
     return r, flip.bool()
 
@@ -158,7 +184,7 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
     sc = torch.empty((2,), dtype=torch.float64, device=dev) if want_sum else None
     flag = torch.empty((1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_angle_error(_ptr(a), _ptr(b_), _ptr(deg), _ptr(sc), _ptr(flag),
                                                1 if radians else 0, n, _stream(dev)), "so3_angle_error")
     return deg, sc, flag
@@ -208,7 +234,7 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
     sc = None if want_deg else torch.empty((2,), dtype=torch.float64, device=dev)
     flag = torch.empty((1,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_project_angle_error_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
                    "so3_project_angle_error_f32")
     if check and int(flag.item()) != 0:
@@ -227,7 +253,7 @@ def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tens
         raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
     n = a.shape[0]
     theta = torch.empty((n,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_geodesic_f32(_ptr(a), _ptr(b_), _ptr(theta), n, _stream(dev)), "so3_geodesic_f32")
     return theta
 
@@ -246,7 +272,7 @@ class _LossFrobenius(torch.autograd.Function):
         need_grad = r_pred.requires_grad or r_true.requires_grad
         g = torch.empty_like(p) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_frob_loss_f32(_ptr(p), _ptr(t), _ptr(g), _ptr(loss_sum), b, _stream(dev)), "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
@@ -289,7 +315,7 @@ class _FrobeniusHead(torch.autograd.Function):
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
         lib = _lib.load()
         fn = lib.so3_frob_fwd_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(fn(_ptr(m), _ptr(t), _ptr(r), _ptr(dm), _ptr(loss_sum), b, _stream(dev)), "so3_frob_fwd_bwd")
         loss = loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
         ctx.dm = dm
@@ -337,7 +363,7 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
     b, n, _ = p.shape
     r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
     h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_kabsch_f32(_ptr(p), _ptr(q), _ptr(r), _ptr(h), b, n, _stream(dev)), "so3_kabsch_f32")
     return (r, h) if return_h else r
 
@@ -356,7 +382,7 @@ def rotate_point_clouds(pc: torch.Tensor, R: torch.Tensor, transposed: bool = Fa
     r = R.detach().reshape(-1, 9).contiguous().float()
     b, n, _ = p.shape
     out = torch.empty((b, 3, n) if transposed else (b, n, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_rotate_clouds_f32(_ptr(p), _ptr(r), _ptr(out), 1 if transposed else 0, b, n, _stream(dev)), "so3_rotate_clouds_f32")
     return out
 
@@ -372,7 +398,7 @@ def pc_normalize(pc: torch.Tensor):
         raise RuntimeError(f"pc_normalize: expected (N, 3) or (B, N, 3) with N >= 1, got {tuple(pc.shape)}")
     b, n, _ = p.shape
     out, cen, sc = torch.empty_like(p), torch.empty((b, 3), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_pc_normalize_f32(_ptr(p), _ptr(out), _ptr(cen), _ptr(sc), b, n, _stream(dev)), "so3_pc_normalize_f32")
     return (out[0], cen[0], sc[0]) if single else (out, cen, sc)
 
@@ -397,7 +423,7 @@ def rotations_from_axis_angle_draws(theta: torch.Tensor, axis: torch.Tensor) -> 
     if a.shape[0] != t.shape[0]:
         raise RuntimeError("rotations_from_axis_angle_draws: theta (B,) and axis (B,3) disagree")
     r = torch.empty((t.shape[0], 3, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_rotations_axis_angle_f32(_ptr(t), _ptr(a), _ptr(r), t.shape[0], _stream(dev)), "so3_rotations_axis_angle_f32")
     return r
 
@@ -413,7 +439,7 @@ def kabsch_rotation_synthetic(P: torch.Tensor, R_gt: torch.Tensor, sigma: float 
     b, n, _ = p.shape
     r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
     h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(_lib.load().so3_kabsch_synth_f32(_ptr(p), _ptr(g), float(sigma), int(seed) & 0xFFFFFFFF, _ptr(r), _ptr(h), b, n, _stream(dev)),
                    "so3_kabsch_synth_f32")
     return (r, h) if return_h else r
@@ -439,7 +465,7 @@ class _Se3Update(torch.autograd.Function):
         t = t_init.detach().reshape(-1, 16).contiguous().float()
         b = o.shape[0]
         tp = torch.empty((b, 4, 4), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_se3_update_f32(_ptr(o), _ptr(t), _ptr(tp), fx, fy, b, _stream(dev)), "so3_se3_update_f32")
         ctx.save_for_backward(o, t)
         ctx.meta = (model_output.shape, model_output.dtype, fx, fy)
@@ -453,7 +479,7 @@ class _Se3Update(torch.autograd.Function):
         dev = o.device
         g = grad_t.reshape(-1, 16).contiguous().float()
         d = torch.empty_like(o)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_se3_update_bwd_f32(_ptr(o), _ptr(t), _ptr(g), _ptr(d), fx, fy, o.shape[0], _stream(dev)), "so3_se3_update_bwd_f32")
         full = torch.zeros(shape, dtype=torch.float32, device=dev)
         full[:, :12] = d
@@ -500,7 +526,7 @@ class _AddL1(torch.autograd.Function):
         dists = None if use_batch_mean else torch.empty((b,), dtype=torch.float32, device=dev)
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if use_batch_mean else None
         scale = 1.0 / max(b, 1) if use_batch_mean else 1.0
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_add_l1_f32(_ptr(tg), _ptr(tp), _ptr(pts), _ptr(dists), _ptr(loss_sum), _ptr(dt), scale, b, n,
                                                   _stream(dev)), "so3_add_l1_f32")
         ctx.dt, ctx.per_sample, ctx.in_dtype = dt, not use_batch_mean, t_pred.dtype
@@ -525,7 +551,7 @@ class _AddL1Disentangled(torch.autograd.Function):
         dev, b, n, tg, tp, pts = _add_l1_args(t_gt, t_pred, points)
         dt = torch.empty((b, 4, 4), dtype=torch.float32, device=dev) if t_pred.requires_grad else None
         loss_sum = torch.empty((3,), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_add_l1_disentangled_f32(_ptr(tp), _ptr(tg), _ptr(pts), _ptr(loss_sum), _ptr(dt), 1.0 / max(b, 1),
                                                                b, n, _stream(dev)), "so3_add_l1_disentangled_f32")
         ctx.dt, ctx.in_dtype = dt, t_pred.dtype
@@ -574,7 +600,7 @@ def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None,
     lib = _lib.load()
     stats = torch.empty((num_classes, len(STAT_FIELDS)), dtype=torch.float64, device=dev)
     work = torch.empty((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         _lib.check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), _stream(dev)), "so3_angle_stats")
     return {name: stats[:, i] for i, name in enumerate(STAT_FIELDS)}
 
@@ -591,7 +617,7 @@ class _Ortho6d(torch.autograd.Function):
         x = poses.detach().reshape(-1, 6).contiguous().float()
         b = x.shape[0]
         r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_ortho6d_fwd_f32(_ptr(x), _ptr(r), b, _stream(dev)), "so3_ortho6d_fwd_f32")
         ctx.save_for_backward(x)
         ctx.in_shape, ctx.in_dtype = poses.shape, poses.dtype
@@ -604,7 +630,7 @@ class _Ortho6d(torch.autograd.Function):
         dev = x.device
         g = grad_r.reshape(-1, 9).contiguous().float()
         dx = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             _lib.check(_lib.load().so3_ortho6d_bwd_f32(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_ortho6d_bwd_f32")
         return dx.to(ctx.in_dtype).view(ctx.in_shape)
 
@@ -628,7 +654,7 @@ def _make_head(symbol: str, width: int):
             x = x_in.detach().contiguous().float()
             b = x.shape[0]
             r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 _lib.check(getattr(_lib.load(), "so3_%s_fwd_f32" % symbol)(_ptr(x), _ptr(r), b, _stream(dev)), "so3_%s_fwd_f32" % symbol)
             ctx.save_for_backward(x)
             ctx.in_dtype = x_in.dtype
@@ -641,7 +667,7 @@ def _make_head(symbol: str, width: int):
             dev = x.device
             g = grad_r.reshape(-1, 9).contiguous().float()
             dx = torch.empty_like(x)
-            with torch.cuda.device(dev):
+            with _on_device(dev):
                 _lib.check(getattr(_lib.load(), "so3_%s_bwd_f32" % symbol)(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_%s_bwd_f32" % symbol)
             return dx.to(ctx.in_dtype)
 
