@@ -16,8 +16,7 @@ void model_project_f32(const float *M, float *R, uint8_t *flip, int64_t B) {
     for (int64_t b = 0; b < B; ++b) {
         float m[9], r[9];
         for (int i = 0; i < 9; ++i) m[i] = M[9 * b + i];
-        const auto f = so3::signed_svd<false, float>(m);
-        so3::rotation_from(f, r);
+        so3::project_rotation<float>(m, r);
         for (int i = 0; i < 9; ++i) R[9 * b + i] = r[i];
         if (flip) flip[b] = so3::det_negative(m) ? 1 : 0;
     }
@@ -30,9 +29,29 @@ void model_project_packed_f32(const float *M, float *R, int64_t B) {
         const int64_t b1 = b + 1 < B ? b + 1 : b;
         T m[9], r[9];
         for (int i = 0; i < 9; ++i) m[i] = T{M[9 * b + i], M[9 * b1 + i]};
-        const auto f = so3::signed_svd<false, T>(m);
-        so3::rotation_from(f, r);
+        so3::project_rotation<T>(m, r);
         for (int i = 0; i < 9; ++i) { R[9 * b + i] = r[i].x; R[9 * b1 + i] = r[i].y; }
+    }
+}
+
+// the Jacobi path alone (what hard rows and the backward kernels run)
+void model_project_jacobi_f32(const float *M, float *R, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        float m[9], r[9];
+        for (int i = 0; i < 9; ++i) m[i] = M[9 * b + i];
+        const auto f = so3::signed_svd<false, float>(m);
+        so3::rotation_from(f, r);
+        for (int i = 0; i < 9; ++i) R[9 * b + i] = r[i];
+    }
+}
+
+// the fast path alone: R as it leaves quat_rotation and the hard flag (hard rows' R is whatever the path produced)
+void model_project_quat_f32(const float *M, float *R, uint8_t *hard, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        float m[9], r[9];
+        for (int i = 0; i < 9; ++i) m[i] = M[9 * b + i];
+        hard[b] = so3::quat_rotation<float>(m, r) ? 1 : 0;
+        for (int i = 0; i < 9; ++i) R[9 * b + i] = r[i];
     }
 }
 

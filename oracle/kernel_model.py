@@ -48,6 +48,23 @@ def _c(a, dt):
     return np.ascontiguousarray(np.asarray(a, dt).reshape(-1, 9))
 
 
+def project_jacobi(m):
+    """The Jacobi path alone (hard rows of K1, and what K2/K3 recompute)."""
+    m = _c(m, np.float32)
+    r = np.empty_like(m)
+    lib().model_project_jacobi_f32(_p(m), _p(r), ctypes.c_int64(m.shape[0]))
+    return r.reshape(-1, 3, 3)
+
+
+def project_quat(m):
+    """The quaternion fast path alone: (R, hard).  Rows with hard set are redone by the Jacobi path in the product."""
+    m = _c(m, np.float32)
+    r = np.empty_like(m)
+    hard = np.zeros(m.shape[0], np.uint8)
+    lib().model_project_quat_f32(_p(m), _p(r), _p(hard), ctypes.c_int64(m.shape[0]))
+    return r.reshape(-1, 3, 3), hard.astype(bool)
+
+
 def project(m, packed=False, want_flip=False):
     m = _c(m, np.float32)
     r = np.empty_like(m)

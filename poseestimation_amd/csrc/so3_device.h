@@ -436,6 +436,222 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
     rotation_rows<T>(f.u1, f.u2, f.v1, f.v2, r);
 }
 
+// =====================================================================================================================
+// K1 forward, fast path: the rotation as the dominant eigenvector of Davenport's 4x4 matrix.
+//
+// R = argmax_{R in SO(3)} tr(R^T M) is exactly U diag(1,1,det(UV^T)) V^T (rotation_representation.py:199-205), and with
+// R = R(q), q a unit quaternion (w,x,y,z), tr(R^T M) = q^T K q for the symmetric traceless
+//     K = [ tr M          m21-m12        m02-m20        m10-m01      ]
+//         [  .         m00-m11-m22       m01+m10        m02+m20      ]
+//         [  .             .          -m00+m11-m22      m12+m21      ]
+//         [  .             .              .          -m00-m11+m22    ]
+// whose eigenvalues are s1+s2+s3', s1-s2-s3', -s1+s2-s3', -s1-s2+s3' (s3' = det-signed): the gap between the two largest,
+// 2(s2+s3'), is the conditioning of R itself.  Per matrix:
+//   1. power-of-two prescale (as signed_svd);
+//   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2)  by Laguerre's iteration from
+//      the upper bound sqrt(3)|M|_F (all roots real: monotone from above, cubic), closed by one Newton step;
+//   3. q = the largest column of adj(lambda I - K) = (product of the three gaps) q q^T -- no division, no pivoting;
+//   4. one refinement: lambda <- Rayleigh quotient of q (error squared), q again from the adjugate;
+//   5. R(q) -- orthogonal by construction.
+// About 320 packed + 100 plain VALU instructions and 26 transcendentals per PAIR of matrices, against 390 / 135 / 45 for
+// the three Jacobi sweeps and the frames above (tools/proto/qpath2.py is the numpy float32 prototype: 1M Gaussian rows
+// median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
+//
+// What the fast path cannot do it says so: a row is HARD when (a) the product of the three gaps, tr adj(lambda I - K), is
+// below kQuatTau lambda^3 (ill-conditioned, rank-deficient, ties: everything where the reference's answer is a matter of
+// LAPACK's ordering), or (b) the Rayleigh quotient moved lambda by more than kQuatConv times a lower bound of the gap
+// (Laguerre had not converged; the quotient is <= lambda_max <= the Laguerre iterate, so the move bounds BOTH errors), or
+// (c) anything is not finite.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
+// time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
+#ifndef SO3_QUAT_LAGUERRE
+#define SO3_QUAT_LAGUERRE 4          // Laguerre iterations (then one Newton step)
+#endif
+constexpr float kQuatTau = 1e-3f;       // first pass
+constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
+constexpr int kQuatExtra = 2;           // how many further refinements a row may take
+constexpr float kQuatConv = 4e-4f;
+#ifndef SO3_QUAT_CURV
+#define SO3_QUAT_CURV 0.5f
+#endif
+constexpr float kQuatCurv = SO3_QUAT_CURV;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
+
+template <class T> struct Sym4 {        // symmetric 4x4, upper triangle
+    T a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
+};
+
+// The largest column of adj(lam I - K) and the trace of the adjugate.
+template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T> &k, T lam, T (&q)[4], T &trace) {
+    typedef Tr<T> R;
+    const T n00 = lam - k.a00, n11 = lam - k.a11, n22 = lam - k.a22, n33 = lam - k.a33;
+    const T n01 = -k.a01, n02 = -k.a02, n03 = -k.a03, n12 = -k.a12, n13 = -k.a13, n23 = -k.a23;
+    // 2x2 minors of rows (0,1) and of rows (2,3); s5 = c0 by symmetry
+    const T s0 = R::fma(n00, n11, -(n01 * n01)), s1 = R::fma(n00, n12, -(n01 * n02)), s2 = R::fma(n00, n13, -(n01 * n03));
+    const T s3 = R::fma(n01, n12, -(n11 * n02)), s4 = R::fma(n01, n13, -(n11 * n03)), s5 = R::fma(n02, n13, -(n12 * n03));
+    const T c5 = R::fma(n22, n33, -(n23 * n23)), c4 = R::fma(n12, n33, -(n13 * n23)), c3 = R::fma(n12, n23, -(n13 * n22));
+    const T c2 = R::fma(n02, n33, -(n03 * n23)), c1 = R::fma(n02, n23, -(n03 * n22));
+    const T b00 = R::fma(n13, c3, R::fma(n11, c5, -(n12 * c4)));
+    const T b01 = R::fma(n02, c4, -R::fma(n03, c3, n01 * c5));
+    const T b02 = R::fma(n33, s3, R::fma(n13, s5, -(n23 * s4)));
+    const T b03 = R::fma(n22, s4, -R::fma(n23, s3, n12 * s5));
+    const T b11 = R::fma(n03, c1, R::fma(n00, c5, -(n02 * c2)));
+    const T b12 = R::fma(n23, s2, -R::fma(n33, s1, n03 * s5));
+    const T b13 = R::fma(n23, s1, R::fma(n02, s5, -(n22 * s2)));
+    const T b22 = R::fma(n33, s0, R::fma(n03, s4, -(n13 * s2)));
+    const T b23 = R::fma(n12, s2, -R::fma(n23, s0, n02 * s4));
+    const T b33 = R::fma(n22, s0, R::fma(n02, s3, -(n12 * s1)));
+    trace = (b00 + b11) + (b22 + b33);
+    // adj = (g2 g3 g4) q q^T: its diagonal is proportional to q_j^2 -- take the column of the largest
+    const typename R::mask m01 = R::ge(b00, b11), m23 = R::ge(b22, b33);
+    const T da = R::sel(m01, b00, b11), db = R::sel(m23, b22, b33);
+    const T a0 = R::sel(m01, b00, b01), a1 = R::sel(m01, b01, b11), a2 = R::sel(m01, b02, b12), a3 = R::sel(m01, b03, b13);
+    const T e0 = R::sel(m23, b02, b03), e1 = R::sel(m23, b12, b13), e2 = R::sel(m23, b22, b23), e3 = R::sel(m23, b23, b33);
+    const typename R::mask mab = R::ge(da, db);
+    q[0] = R::sel(mab, a0, e0); q[1] = R::sel(mab, a1, e1); q[2] = R::sel(mab, a2, e2); q[3] = R::sel(mab, a3, e3);
+}
+
+// Rayleigh quotient q^T K q / q^T q.
+template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4]) {
+    typedef Tr<T> R;
+    const T kq0 = R::fma(k.a03, q[3], R::fma(k.a02, q[2], R::fma(k.a01, q[1], k.a00 * q[0])));
+    const T kq1 = R::fma(k.a13, q[3], R::fma(k.a12, q[2], R::fma(k.a11, q[1], k.a01 * q[0])));
+    const T kq2 = R::fma(k.a23, q[3], R::fma(k.a22, q[2], R::fma(k.a12, q[1], k.a02 * q[0])));
+    const T kq3 = R::fma(k.a33, q[3], R::fma(k.a23, q[2], R::fma(k.a13, q[1], k.a03 * q[0])));
+    const T num = R::fma(q[3], kq3, R::fma(q[2], kq2, R::fma(q[1], kq1, q[0] * kq0)));
+    const T den = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
+    return num * R::rcp(den);
+}
+
+// A row is settled when (1) the product of the gaps -- the trace of the adjugate at the refined lambda, which is P'(lambda)
+// -- clears tau lambda^3, (2) the Rayleigh quotient moved lambda by at most kQuatConv times the gap's lower bound
+// trace / (2 lambda)^2, and (3) lambda is the LARGEST root: with P' > 0 (from 1), P'' > 0 and the third derivative
+// 24 lambda > 0 the Budan-Fourier count allows at most one root above lambda.  (Without 3 an exact double root at the top
+// -- small-integer matrices with s2 = s3 and det < 0 -- could throw the iteration below it and on to the third eigenvalue,
+// whose adjugate looks just as healthy.)  (3) is asked with a margin, P'' >= kQuatCurv |M|_F^2, which is criterion (4):
+// with gaps g2 <= g3 <= g4 of lambda to the other eigenvalues, P''/2 = g2 g3 + g2 g4 + g3 g4 <= 3 g3 g4, so the margin
+// bounds the SECOND gap g3 = 2 (s1 + s3') from below.  The adjugate's round-off is eps g4^3 / (g2 g3 g4): a small g2 is the
+// conditioning of R itself, a small g3 (all three singular values close and det < 0: a near-reflection) is a weakness of
+// the quaternion formulation only, and such rows go to the Jacobi path.
+template <class T>
+__device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam_after, T trace, T tau, T twoc2, T f) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    const T l2 = lam_after * lam_after;
+    const typename R::mask separated = R::gt(trace, (l2 * lam_after) * tau);
+    const typename R::mask converged = R::le(R::abs(lam_before - lam_after) * (l2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
+    const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
+    return separated & converged & topmost;
+}
+
+// r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
+template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9]) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    // 1. exact power-of-two prescale: largest |entry| lands in [0.5, 1)
+    T mx = R::max(R::max(R::abs(m_in[0]), R::abs(m_in[1])), R::abs(m_in[2]));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[3]), R::abs(m_in[4])), R::abs(m_in[5])));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[6]), R::abs(m_in[7])), R::abs(m_in[8])));
+    const T sc = R::ldexp(R::splat(S(1)), R::neg_frexp_exp(mx));
+    T m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = m_in[i] * sc;
+    // 2. K (order w, x, y, z)
+    const T tr = (m[0] + m[4]) + m[8];
+    const T two = R::splat(S(2));
+    Sym4<T> k;
+    k.a00 = tr; k.a11 = R::fma(two, m[0], -tr); k.a22 = R::fma(two, m[4], -tr); k.a33 = R::fma(two, m[8], -tr);
+    k.a01 = m[7] - m[5]; k.a02 = m[2] - m[6]; k.a03 = m[3] - m[1];
+    k.a12 = m[1] + m[3]; k.a13 = m[2] + m[6]; k.a23 = m[5] + m[7];
+    // 3. the characteristic quartic  l^4 + c2 l^2 + c1 l + c0
+    T f = m[0] * m[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
+    const T g00 = R::fma(m[4], m[8], -(m[5] * m[7])), g01 = R::fma(m[5], m[6], -(m[3] * m[8])), g02 = R::fma(m[3], m[7], -(m[4] * m[6]));
+    const T g10 = R::fma(m[2], m[7], -(m[1] * m[8])), g11 = R::fma(m[0], m[8], -(m[2] * m[6])), g12 = R::fma(m[1], m[6], -(m[0] * m[7]));
+    const T g20 = R::fma(m[1], m[5], -(m[2] * m[4])), g21 = R::fma(m[2], m[3], -(m[0] * m[5])), g22 = R::fma(m[0], m[4], -(m[1] * m[3]));
+    const T det = R::fma(m[2], g02, R::fma(m[1], g01, m[0] * g00));
+    T cf = g00 * g00;
+    cf = R::fma(g01, g01, cf); cf = R::fma(g02, g02, cf); cf = R::fma(g10, g10, cf); cf = R::fma(g11, g11, cf);
+    cf = R::fma(g12, g12, cf); cf = R::fma(g20, g20, cf); cf = R::fma(g21, g21, cf); cf = R::fma(g22, g22, cf);
+    const T c2 = f * R::splat(S(-2)), c1 = det * R::splat(S(-8)), c0 = R::fma(f, f, cf * R::splat(S(-4)));
+    const T twoc2 = c2 + c2;
+    // 4. lambda_max: Laguerre from above, then Newton
+    T lam = R::sqrt(f * R::splat(S(3)));
+#pragma unroll
+    for (int it = 0; it < SO3_QUAT_LAGUERRE + 1; ++it) {
+        const T l2 = lam * lam;
+        const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
+        const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
+        if (it < SO3_QUAT_LAGUERRE) {
+            const T ddp = R::fma(R::splat(S(12)), l2, twoc2);
+            const T h = R::fma(R::splat(S(9)) * dp, dp, (p * ddp) * R::splat(S(-12)));     // (n-1)((n-1)P'^2 - n P P''), n = 4
+            const T den = dp + R::sqrt(R::max(h, R::splat(S(0))));
+            lam = R::fma(p * R::splat(S(-4)), R::rcp(den), lam);
+        } else {
+            lam = R::fma(-p, R::rcp(dp), lam);
+        }
+    }
+    // 5. eigenvector, Rayleigh quotient, eigenvector
+    T q[4], trace;
+    dominant_column<T>(k, lam, q, trace);
+    T lam2 = rayleigh<T>(k, q);
+    dominant_column<T>(k, lam2, q, trace);
+    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
+    typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
+    // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
+    // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
+    // Laguerre iteration was still on its way and rows with a gap down to ~3e-4 of lambda.  What is left (rank-deficient,
+    // ties, gaps at round-off) is hard.
+#pragma unroll 1
+    for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(settled))); ++extra) {
+        T q3[4], trace3;
+        const T lam3 = rayleigh<T>(k, q);
+        dominant_column<T>(k, lam3, q3, trace3);
+        const typename R::mask settled3 = quat_settled<T>(lam2, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = R::sel(settled, q[i], q3[i]);
+        lam2 = R::sel(settled, lam2, lam3);
+        settled = settled | settled3;
+    }
+    // 7. R(q), q = (w, x, y, z) unnormalised
+    const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
+    const T s2 = R::rcp(nq) * two;
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T xs = x * s2, ys = y * s2, zs = z * s2;
+    const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const T one = R::splat(S(1));
+    r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
+    r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
+    r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
+    const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
+    return R::mnot(settled & finite);
+}
+
+// K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
+// (float64 rows go straight to Jacobi: so3_project_fwd_f64 is not a benchmark path.)
+template <class T> __device__ __forceinline__ void project_rotation(const T (&m)[9], T (&r)[9]) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    const typename R::mask hard = quat_rotation<T>(m, r);
+    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+#pragma unroll
+        for (int i = 0; i < R::kLanes; ++i) {
+            if (R::lane_of(hard, i)) {
+                S mk[9], rk[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) mk[j] = R::get(m[j], i);
+                const auto f = signed_svd<false, S>(mk);
+                rotation_from(f, rk);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) R::set(r[j], i, rk[j]);
+            }
+        }
+    }
+}
+template <> __device__ __forceinline__ void project_rotation<double>(const double (&m)[9], double (&r)[9]) {
+    const auto f = signed_svd<false, double, 4, true, 6>(m);
+    rotation_from(f, r);
+}
+
 // sign(det M) -> flip flag.  A float32 cofactor expansion decides whenever |det| clears its own rounding bound
 // (8 eps times the sum of the |terms|); only the rare rows inside that band (and rows whose products leave the
 // float32 range) pay for the float64 evaluation, where products of floats are exact.

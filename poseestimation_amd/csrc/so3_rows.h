@@ -150,8 +150,16 @@ template <int NPL> struct RowCtx {
 //   kReduce: whether acc/flag are used.
 // WPS = resident waves per SIMD the register budget is sized for (the host launches 256 * WPS * 256 / BLOCK
 // workgroups).  STAMP (diagnostic builds only): per wave {s_memrealtime entry, exit, s_memtime entry,
-// cycles | XCC << 28 | HW_ID << 32, cycles waiting for prefetched units, cycles until the first unit arrived}.
-template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false>
+// cycles | XCC << 28 | HW_ID << 32, cycles waiting for prefetched units | rounds done << 48, cycles until the first unit arrived}.
+//
+// Which wave takes which round.  DYN = false: wave w of the grid takes rounds w, w + W, w + 2W, ... (static).
+// DYN = true: ONE workgroup per CU (BLOCK = 64 * 4 * WPS fills it), workgroup b owns rounds b, b + G, b + 2G, ...
+// (G = gridDim.x) and its waves CLAIM them one at a time from a ticket counter in LDS.  Why: 1M rows are 7.6 rounds
+// per SIMD, and with the static deal the dispatcher happens to put the waves that hold one round more than the others
+// on the same CUs -- in-kernel stamps showed SIMDs with 9 rounds next to SIMDs with 6, and the 9s set the kernel's time.
+// With tickets a SIMD that is ahead simply takes the next round: 7 or 8 per SIMD wherever the workgroups land.
+// PF = rounds in flight in registers per wave (see the loop).
+template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false, bool DYN = false, int PF = 1>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
@@ -168,102 +176,140 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) char lds[kWaves][NPL][kSlot];
     __shared__ double red[kWaves];
     __shared__ int red_flag[kWaves];
+    __shared__ unsigned next_ticket;
 
-    unsigned long long t_real0 = 0, t_mem0 = 0, stall_cycles = 0, first_wait = 0;
+    unsigned long long t_real0 = 0, t_mem0 = 0, stall_cycles = 0, first_wait = 0, rounds_done = 0;
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
     char(*slot)[kSlot] = lds[wave_in_block];
-    const int64_t nwaves = static_cast<int64_t>(gridDim.x) * kWaves;
     const int64_t nrounds = (nunits + NPL - 1) / NPL;
-    int64_t t = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
-    const int64_t wave_id = t;
+    // static: round t, then t + stride.  dynamic: ticket k of this workgroup is round blockIdx + k * gridDim.
+    const int64_t stride = DYN ? static_cast<int64_t>(gridDim.x) : static_cast<int64_t>(gridDim.x) * kWaves;
+    int64_t t = DYN ? static_cast<int64_t>(blockIdx.x) + wave_in_block * stride : static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
+    const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
+    if (DYN) {
+        if (threadIdx.x == 0) next_ticket = kWaves;         // tickets 0 .. kWaves-1 are the waves' first rounds
+        __syncthreads();
+    }
     RowCtx<NPL> ctx;
     ctx.lane = lane;
     ctx.acc = 0.0;
     ctx.flag = false;
     if (t < nrounds) {
-        f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads], in2[NPL][I2::kLoads];
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const int64_t u = t * NPL + k;                  // a phantom unit re-reads the round's first one
-            const int64_t ue = u < nunits ? u : t * NPL;
-            I0::fetch(in0[k], I0::rsrc(op.in0, ue, true), lane);
-            if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, true), lane);
-            if constexpr (Op::kIn2 != 0) I2::fetch(in2[k], I2::rsrc(op.in2, ue, true), lane);
-        }
-        if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            I0::to_lds(slot[k], in0[k], lane);
-            if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
-            if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, in2[k], lane);
-        }
-        while (true) {
-            wave_lds_fence();
-            Rows<T, Op> rows;
+        // PF rounds are in flight in registers behind the round that sits in LDS.  One round ahead (PF = 1) leaves the
+        // memory pipe short of requests whenever the wave's arithmetic outlasts a load's latency: with K1's arithmetic the
+        // kernel took the copy's time PLUS 0.4 of the arithmetic's.  Two rounds ahead cost 6 * NPL more VGPRs per input.
+        struct Flight {
+            f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads], in2[NPL][I2::kLoads];
+        };
+        Flight buf[PF];
+        int64_t held[PF];                                   // the round each buffer holds (>= nrounds: none, empty loads)
+        int64_t cursor = t;
+        auto next_round = [&]() -> int64_t {
+            if (DYN) {
+                unsigned k = 0;
+                if (lane == 0) k = __hip_atomic_fetch_add(&next_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(k)) * stride;
+            }
+            cursor += stride;
+            return cursor;
+        };
+        auto issue = [&](Flight &b, int64_t tr) {           // past the last round the descriptors are empty: the loads
+            const bool live = tr < nrounds;                 // return 0 and cost no traffic
+            const int64_t tf = live ? tr : t;
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                I0::read_row(slot[k], lane, k, rows.a);
-                if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, rows.b);
-                if constexpr (Op::kIn2 != 0) I2::read_row(slot[k] + I0::kSlotBytes + I1::kSlotBytes, lane, k, rows.c);
+                const int64_t u = tf * NPL + k;             // a phantom second unit (odd tail) re-reads the round's first
+                const int64_t ue = u < nunits ? u : tf * NPL;
+                I0::fetch(b.in0[k], I0::rsrc(op.in0, ue, live), lane);
+                if constexpr (Op::kIn1 != 0) I1::fetch(b.in1[k], I1::rsrc(op.in1, ue, live), lane);
+                if constexpr (Op::kIn2 != 0) I2::fetch(b.in2[k], I2::rsrc(op.in2, ue, live), lane);
             }
-            wave_lds_fence();
-            const int64_t tn = t + nwaves;
-            const bool more = tn < nrounds;
-            const int64_t tf = more ? tn : t;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {                 // prefetch: in flight during the arithmetic below.
-                const int64_t u = tf * NPL + k;             // After the last round the descriptor is empty: the
-                const int64_t ue = u < nunits ? u : tf * NPL;   // loads return 0 and cost no traffic.
-                I0::fetch(in0[k], I0::rsrc(op.in0, ue, more), lane);
-                if constexpr (Op::kIn1 != 0) I1::fetch(in1[k], I1::rsrc(op.in1, ue, more), lane);
-                if constexpr (Op::kIn2 != 0) I2::fetch(in2[k], I2::rsrc(op.in2, ue, more), lane);
-            }
+        };
+        auto land = [&](const Flight &b) {                  // registers -> the wave's LDS slot
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                ctx.unit[k] = t * NPL + k;
-                ctx.exists[k] = ctx.unit[k] < nunits;       // wave-uniform
+                I0::to_lds(slot[k], b.in0[k], lane);
+                if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, b.in1[k], lane);
+                if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, b.in2[k], lane);
             }
-            op.template compute<T, NPL>(rows, ctx);
-            if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) {
-                    if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, rows.o0);
-                    if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, rows.o1);
-                }
-                wave_lds_fence();
-                f32x4 v0[NPL][O0::kLoads], v1[NPL][O1::kLoads];
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) {
-                    if constexpr (Op::kOut0 != 0) O0::from_lds(v0[k], slot[k], lane);
-                    if constexpr (Op::kOut1 != 0) O1::from_lds(v1[k], slot[k] + O0::kSlotBytes, lane);
-                }
-                wave_lds_fence();
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) {             // a phantom unit's stores are dropped (empty descriptor)
-                    const int64_t ue = ctx.exists[k] ? ctx.unit[k] : 0;
-                    if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, ue, ctx.exists[k]), v0[k], lane);
-                    if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, ue, ctx.exists[k]), v1[k], lane);
-                }
-            }
-            if (!more) break;
-            // The prefetched units land in LDS here, at the END of the body: the loads are older than this
-            // round's stores, so the wait the compiler places is vmcnt(#stores), not a drain of the stores.
-            unsigned long long w0 = 0;
+        };
+        // STAMP builds: wall-clock (100 MHz) begin / end of the arithmetic of the wave's first four rounds
+        auto phase = [&](int ph) {
             if (STAMP) {
                 __builtin_amdgcn_sched_barrier(0);
-                w0 = __builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_s_waitcnt(0x0F70 | 6);
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (rounds_done < 4 && lane == 0)
+                    stamps[6 * static_cast<int64_t>(gridDim.x) * kWaves + 40 * wave_id + 10 * rounds_done + ph] = now;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            for (int k = 0; k < NPL; ++k) {                 // (constant trip count: fully unrolled without a pragma)
-                I0::to_lds(slot[k], in0[k], lane);
-                if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, in1[k], lane);
-                if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, in2[k], lane);
+        };
+        // the first round travels through the last buffer, the next PF - 1 through the others; buffer 0 is then the oldest
+        issue(buf[PF - 1], t);
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) { held[i] = next_round(); issue(buf[i], held[i]); }
+        if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
+        land(buf[PF - 1]);
+        held[PF - 1] = next_round();
+        issue(buf[PF - 1], held[PF - 1]);
+        bool done = false;
+        while (!done) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {                  // buffer p holds the round after the one in LDS
+                wave_lds_fence();
+                Rows<T, Op> rows;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    I0::read_row(slot[k], lane, k, rows.a);
+                    if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, rows.b);
+                    if constexpr (Op::kIn2 != 0) I2::read_row(slot[k] + I0::kSlotBytes + I1::kSlotBytes, lane, k, rows.c);
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    ctx.unit[k] = t * NPL + k;
+                    ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform
+                }
+                phase(3);
+                op.template compute<T, NPL>(rows, ctx);
+                phase(4);
+                if (STAMP) ++rounds_done;
+                if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) {
+                        if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, rows.o0);
+                        if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, rows.o1);
+                    }
+                    wave_lds_fence();
+                    f32x4 v0[NPL][O0::kLoads], v1[NPL][O1::kLoads];
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) {
+                        if constexpr (Op::kOut0 != 0) O0::from_lds(v0[k], slot[k], lane);
+                        if constexpr (Op::kOut1 != 0) O1::from_lds(v1[k], slot[k] + O0::kSlotBytes, lane);
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) {         // a phantom unit's stores are dropped (empty descriptor)
+                        const int64_t ue = ctx.exists[k] ? ctx.unit[k] : 0;
+                        if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, ue, ctx.exists[k]), v0[k], lane);
+                        if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, ue, ctx.exists[k]), v1[k], lane);
+                    }
+                }
+                if (held[p] >= nrounds) { done = true; break; }
+                // The oldest buffer lands in LDS here, at the END of the body: its loads are older than this round's
+                // stores (and than the younger buffers' loads), so the wait is vmcnt(#younger), never a drain.
+                unsigned long long w0 = 0;
+                if (STAMP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    w0 = __builtin_amdgcn_s_memtime();
+                }
+                land(buf[p]);
+                if (STAMP) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
+                t = held[p];
+                held[p] = next_round();
+                issue(buf[p], held[p]);
             }
-            if (STAMP) { __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
-            t = tn;
         }
     }
     if (Op::kReduce) {
@@ -281,7 +327,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             op.finish(total, f != 0);
         }
     }
-    if (STAMP && wave_id < nrounds) {
+    if (STAMP && (DYN || wave_id < nrounds)) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
             stamps[6 * wave_id + 0] = t_real0;
@@ -292,7 +338,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
             stamps[6 * wave_id + 3] = ((__builtin_amdgcn_s_memtime() - t_mem0) & 0xFFFFFFFull)
                                       | (static_cast<unsigned long long>(xcc & 0xF) << 28) | (static_cast<unsigned long long>(hw) << 32);
-            stamps[6 * wave_id + 4] = stall_cycles;
+            stamps[6 * wave_id + 4] = stall_cycles | (rounds_done << 48);
             stamps[6 * wave_id + 5] = first_wait;
         }
     }
@@ -311,8 +357,10 @@ struct OpBase {
 };
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
-// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206).  SWEEPS < 0: copy (diagnostic).
-template <int IN_BYTES, bool FLIP, int SWEEPS = kSweeps, bool ADAPT = true>
+// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206).  SWEEPS = kFastPath (the product): quaternion
+// fast path + Jacobi for hard rows (project_rotation); SWEEPS >= 0: Jacobi only, SWEEPS < 0: copy (both diagnostic).
+constexpr int kFastPath = 100;
+template <int IN_BYTES, bool FLIP, int SWEEPS = kFastPath, bool ADAPT = true>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     uint8_t *flip = nullptr;
@@ -323,6 +371,8 @@ struct OpProject : OpBase {
         if constexpr (SWEEPS < 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) r[i] = m[i];
+        } else if constexpr (SWEEPS == kFastPath) {
+            project_rotation<T>(m, r);
         } else {
             const auto f = signed_svd<false, T, SWEEPS, ADAPT>(m);
             rotation_from(f, r);
@@ -465,8 +515,7 @@ struct OpProjectAngle : OpBase {
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProjectAngle> &rows, RowCtx<NPL> &ctx) const {
         T r[9];
-        const auto f = signed_svd<false, T>(rows.a);
-        rotation_from(f, r);
+        project_rotation<T>(rows.a, r);
         if (WANT_R) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];
@@ -765,8 +814,7 @@ struct OpSe3Update : OpBase {
         T m[9], dr[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) m[i] = o[i];
-        const auto f = signed_svd<false, T>(m);               // utility.py:105
-        rotation_from(f, dr);
+        project_rotation<T>(m, dr);                            // utility.py:105
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll

@@ -120,8 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_project_fwd(const void *__restrict__
     float m[9], r[9];
     const bool active = static_cast<int>(threadIdx.x) < n;
     lane_get(tile, active, m);
-    const auto f = so3::signed_svd<false>(m);
-    so3::rotation_from(f, r);
+    so3::project_rotation<float>(m, r);
     if (FLIP && active) flip[first + threadIdx.x] = so3::det_negative(m) ? 1 : 0;
     lane_put(tile, r);          // each lane overwrites only the nine words it alone has read
     __syncthreads();
@@ -400,9 +399,8 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
         }
     }
     const bool active = lane < nc;
-    const auto f = so3::signed_svd<false>(h);
     float r[9];
-    so3::rotation_from(f, r);
+    so3::project_rotation<float>(h, r);
     if (active) {
         float *out = R + (c0 + lane) * 9;
 #pragma unroll
@@ -514,9 +512,8 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
         }
     }
     const bool active = lane < nc;
-    const auto f = so3::signed_svd<false>(h);
     float r[9];
-    so3::rotation_from(f, r);
+    so3::project_rotation<float>(h, r);
     if (active) {
         float *out = R + (c0 + lane) * 9;
 #pragma unroll
@@ -1010,15 +1007,30 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
     do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
 #define SO3_MAX_B (INT64_C(2147483647) * kBlock)
 
+// Compute units of the current device (queried once per device; 256 on an MI355X in SPX mode, fewer in CPX / DPX partitions).
+inline int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 // Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads.
-template <int NPL, int WPS, int BLOCK, class Op>
+// DYN: one workgroup per CU (BLOCK must be 64 * 4 * WPS), rounds claimed from a ticket counter; PF: rounds in flight.
+template <int NPL, int WPS, int BLOCK, bool DYN = false, int PF = 1, class Op>
 void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     constexpr int kWaves = BLOCK / 64;
+    static_assert(!DYN || BLOCK == 64 * 4 * WPS, "a ticketed workgroup fills its CU");
     const int64_t rounds = (nunits + NPL - 1) / NPL;
-    const int64_t want = (rounds + kWaves - 1) / kWaves;
-    const int64_t cap = 256LL * 4 * WPS / kWaves;              // 256 CUs x 4 SIMDs x WPS wave slots
+    const int64_t want = DYN ? rounds : (rounds + kWaves - 1) / kWaves;
+    const int64_t cap = DYN ? device_cus() : static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;   // CUs x 4 SIMDs x WPS wave slots
     const dim3 grid(static_cast<unsigned>(want < cap ? want : cap)), block(BLOCK);
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), grid, block, 0, s, op, nunits, nullptr);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), grid, block, 0, s, op, nunits, nullptr);
 }
 
 // Rows [0, 64*nunits) go to the engine when every pointer is 16-byte aligned; the rest to the tile kernels.
@@ -1050,6 +1062,15 @@ inline const void *advance_bytes(const void *p, int64_t bytes) { return p ? stat
 inline void *advance_bytes(void *p, int64_t bytes) { return p ? static_cast<char *>(p) + bytes : nullptr; }
 
 // ---- K1 --------------------------------------------------------------------------------------------
+#ifndef SO3_K1_DYN
+#define SO3_K1_DYN 0
+#endif
+#ifndef SO3_K1_PF
+#define SO3_K1_PF 1
+#endif
+constexpr bool K1_DYN = SO3_K1_DYN != 0;
+constexpr int K1_PF = SO3_K1_PF;
+constexpr int K1_BLOCK = K1_DYN ? 768 : 256;
 template <bool BF16>
 int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
@@ -1059,8 +1080,8 @@ int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream)
     constexpr int EB = BF16 ? 2 : 4;
     const int64_t nunits = stream_units(B, {M, R});
     if (nunits > 0) {
-        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256>(op, nunits, s); }
-        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256>(op, nunits, s); }
+        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, K1_BLOCK, K1_DYN, K1_PF>(op, nunits, s); }
+        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, K1_BLOCK, K1_DYN, K1_PF>(op, nunits, s); }
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
@@ -1154,7 +1175,7 @@ int launch_add_l1(const float *Tgt, const float *Tpred, const float *points, flo
         if (e != hipSuccess) return fail(static_cast<int>(e), what);
     }
     if (B == 0) return 0;
-    int64_t per_wave = B / (256 * 16);              // enough waves for 256 CUs x 16, at most 64 samples per wave
+    int64_t per_wave = B / (static_cast<int64_t>(device_cus()) * 16);              // enough waves for 256 CUs x 16, at most 64 samples per wave
     if (per_wave < 1) per_wave = 1;
     if (per_wave > 64) per_wave = 64;
     const int64_t waves = (B + per_wave - 1) / per_wave;
@@ -1374,7 +1395,7 @@ int so3_rotate_clouds_f32(const float *P, const float *R, float *out, int transp
     SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 150000000, "so3_rotate_clouds_f32: B/N");
     if (B == 0 || N == 0) return 0;
     SO3_CHECK_ARGS(P != nullptr && R != nullptr && out != nullptr, "so3_rotate_clouds_f32: null pointer");
-    int64_t per_wave = B / (256 * 16);
+    int64_t per_wave = B / (static_cast<int64_t>(device_cus()) * 16);
     if (per_wave < 1) per_wave = 1;
     if (per_wave > 64) per_wave = 64;
     const int64_t waves = (B + per_wave - 1) / per_wave;
@@ -1389,7 +1410,7 @@ int so3_pc_normalize_f32(const float *P, float *out, float *centroid, float *sca
     SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 1 && N <= 150000000, "so3_pc_normalize_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(P != nullptr && out != nullptr, "so3_pc_normalize_f32: null pointer");
-    int64_t per_wave = B / (256 * 16);
+    int64_t per_wave = B / (static_cast<int64_t>(device_cus()) * 16);
     if (per_wave < 1) per_wave = 1;
     if (per_wave > 64) per_wave = 64;
     const int64_t waves = (B + per_wave - 1) / per_wave;
@@ -1475,7 +1496,7 @@ int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t
     SO3_CHECK_ARGS(B >= 0 && B <= (INT64_C(1) << 31) && N >= 0 && N <= 150000000, "so3_kabsch_synth_f32: B/N");
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R != nullptr && Rgt != nullptr && (N == 0 || P != nullptr), "so3_kabsch_synth_f32: null pointer");
-    int64_t cpw = B / (256 * 16);
+    int64_t cpw = B / (static_cast<int64_t>(device_cus()) * 16);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
     const int64_t waves = (B + cpw - 1) / cpw;
@@ -1491,7 +1512,7 @@ int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B
     SO3_CHECK_ARGS(R != nullptr && (N == 0 || (P != nullptr && Q != nullptr)), "so3_kabsch_f32: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     // enough waves to fill 256 CUs x 16 waves, at most 64 clouds per wave (one per lane for the SVD)
-    int64_t cpw = B / (256 * 16);
+    int64_t cpw = B / (static_cast<int64_t>(device_cus()) * 16);
     if (cpw < 1) cpw = 1;
     if (cpw > 64) cpw = 64;
     const int64_t waves = (B + cpw - 1) / cpw;

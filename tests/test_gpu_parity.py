@@ -887,7 +887,13 @@ def test_engine_dtype_paths_at_size(rr, c_oracle):
     lu = rr.loss_frobenius(rt, rr.symmetric_orthogonalization(xu))
     lu.backward()
     assert abs(loss.item() - lu.item()) < 2e-6 and (xl.grad - xu.grad).abs().max().item() < 1e-7
-    assert (rf - r).abs().max().item() < 1e-6
+    # K3 hands out the rotation of its Jacobi frames, K1 the quaternion fast path's: two algorithms, equal up to the
+    # conditioning of the row (s1 / gap) times float32 round-off
+    sv = np.linalg.svd(xb.float().cpu().numpy().reshape(n, 3, 3).astype(np.float64), compute_uv=False)
+    flips = np.linalg.det(xb.float().cpu().numpy().reshape(n, 3, 3).astype(np.float64)) < 0
+    gap = np.where(flips, sv[:, 1] - sv[:, 2], sv[:, 1] + sv[:, 2]) / sv[:, 0]
+    diff = (rf - r).abs().flatten(1).amax(1).cpu().numpy()
+    assert (diff * gap).max() < 3e-6 and np.median(diff) < 3e-7
 
 
 # ------------------------------------------------------------------------------------------------

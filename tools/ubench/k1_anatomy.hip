@@ -27,34 +27,40 @@ __global__ void fill(float *p, int64_t n, unsigned seed) {
     }
 }
 
-template <int NPL, int WPS, int SWEEPS, bool ADAPT, int BLOCK = 256>
+// MODE 0: persistent waves, static deal (round-1 geometry).  MODE 1: one workgroup per CU, rounds claimed from an LDS
+// ticket counter (DYN).  MODE 2: not persistent -- one round per wave, the hardware dispatcher balances.
+template <int NPL, int WPS, int SWEEPS, bool ADAPT, int BLOCK = 256, int MODE = 0, int PF = 1>
 void run(float **in, float **out, unsigned long long *stamps_d) {
+    constexpr bool DYN = MODE == 1;
     const int64_t nunits = ROWS / 64;
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     constexpr int kW = BLOCK / 64;
     const int64_t want = (rounds + kW - 1) / kW;
-    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
+    const unsigned blocks = MODE == 2 ? (unsigned)want : (unsigned)std::min<int64_t>(DYN ? rounds : want, 256LL * 4 * WPS / kW);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     typedef so3::OpProject<4, false, SWEEPS, ADAPT> Op;
     auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
     const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
+    CHECK(hipMemset(stamps_d, 0, 8 * 46 * 8192));
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
-    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, rounds);
+    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, MODE == 1 ? (int64_t)blocks * kW : rounds);
     std::vector<unsigned long long> st6(6 * nw); std::vector<unsigned long long> st(4 * nw);
     CHECK(hipMemcpy(st6.data(), stamps_d, st6.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> rs(40 * nw);
+    CHECK(hipMemcpy(rs.data(), stamps_d + 6 * (int64_t)blocks * kW, rs.size() * 8, hipMemcpyDeviceToHost));
     double stall = 0, fw = 0;
-    for (int64_t w = 0; w < nw; ++w) { for (int j = 0; j < 4; ++j) st[4 * w + j] = st6[6 * w + j]; stall += (double)st6[6 * w + 4]; fw += (double)st6[6 * w + 5]; }
+    for (int64_t w = 0; w < nw; ++w) { for (int j = 0; j < 4; ++j) st[4 * w + j] = st6[6 * w + j]; stall += (double)(st6[6 * w + 4] & 0xFFFFFFFFFFFFull); fw += (double)st6[6 * w + 5]; }
     printf("   [stamped] mean cycles per wave waiting for prefetched units: %.0f ; first unit arrived after %.0f cycles\n", stall / nw, fw / nw);
     unsigned long long r0 = ~0ull, r1 = 0; double life = 0, clk = 0; std::vector<double> starts;
     for (int64_t w = 0; w < nw; ++w) {
@@ -65,22 +71,24 @@ void run(float **in, float **out, unsigned long long *stamps_d) {
     for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st[4 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
     {   // per-wave dump for offline analysis: wave, rounds, start_us, end_us, cycles, hw_id, xcc
-        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_npl%d_wps%d_s%d%s.csv", NPL, WPS, SWEEPS, ADAPT ? "a" : "");
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_pf%d_m%d_b%d_npl%d_wps%d_s%d%s.csv", PF, MODE, BLOCK, NPL, WPS, SWEEPS, ADAPT ? "a" : "");
         FILE *fh = fopen(name, "w");
         if (fh) {
-            fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc\n");
+            fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc,first_wait_cyc,phases\n");
             const int64_t nwv = (int64_t)blocks * kW;
             for (int64_t w = 0; w < nw; ++w) {
-                const int64_t nr = (rounds - w + nwv - 1) / nwv;
-                fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu\n", (long long)w, (long long)nr, (double)(st[4 * w] - r0) * 0.01,
-                        (double)(st[4 * w + 1] - r0) * 0.01, st[4 * w + 3] & 0xFFFFFFFull, st[4 * w + 3] >> 32, (st[4 * w + 3] >> 28) & 0xF);
+                const int64_t nr = (int64_t)(st6[6 * w + 4] >> 48); (void)nwv;
+                fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu,%llu", (long long)w, (long long)nr, (double)(st[4 * w] - r0) * 0.01,
+                        (double)(st[4 * w + 1] - r0) * 0.01, st[4 * w + 3] & 0xFFFFFFFull, st[4 * w + 3] >> 32, (st[4 * w + 3] >> 28) & 0xF, st6[6 * w + 5]);
+                for (int j = 0; j < 40; ++j) fprintf(fh, "%s%.2f", j ? " " : ",", rs[40 * w + j] ? (double)(rs[40 * w + j] - r0) * 0.01 : -1.0);
+                fprintf(fh, "\n");
             }
             fclose(fh);
         }
     }
-    printf("NPL=%d WPS=%d sweeps=%d%s block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("pf=%d mode=%d NPL=%d WPS=%d sweeps=%d%s block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           PF, MODE, NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
 }
 
@@ -91,21 +99,20 @@ int main(int argc, char **argv) {
         CHECK(hipMalloc(&in[i], ROWS * 9 * 4)); CHECK(hipMalloc(&out[i], ROWS * 9 * 4));
         hipLaunchKernelGGL(fill, dim3((ROWS * 9 + 255) / 256), dim3(256), 0, 0, in[i], ROWS * 9, 1234u + i);
     }
-    unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 6 * 8192 * 4));
+    unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 46 * 8192));
     CHECK(hipDeviceSynchronize());
     if (quick) {
-        g_launches = 200;
-        for (int rep = 0; rep < 3; ++rep) run<2, 3, 3, true, 256>(in, out, stamps);
+        g_launches = 1000;
+        for (int rep = 0; rep < 3; ++rep) {
+            run<2, 3, 100, true, 256, 0, 1>(in, out, stamps);
+            run<2, 3, 100, true, 256, 0, 2>(in, out, stamps);
+            run<2, 3, 100, true, 768, 1, 1>(in, out, stamps);
+            run<2, 3, 100, true, 768, 1, 2>(in, out, stamps);
+            run<2, 3, 3, true, 256, 0, 2>(in, out, stamps);
+            run<2, 3, -1, false, 256, 0, 1>(in, out, stamps);
+            run<2, 3, -1, false, 256, 0, 2>(in, out, stamps);
+        }
         return 0;
-    }
-    for (int k : {40, 200, 200}) {
-        g_launches = k;
-        printf("--- %d timed launches per measurement\n", k);
-        run<2, 3, 3, true, 256>(in, out, stamps);
-        run<2, 3, 3, true, 192>(in, out, stamps);
-        run<2, 3, 3, true, 384>(in, out, stamps);
-        run<2, 3, 3, true, 768>(in, out, stamps);
-        run<2, 3, -1, false, 768>(in, out, stamps);
     }
     return 0;
 }
