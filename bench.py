@@ -36,6 +36,7 @@ ROWS_DEFAULT = 1_000_000
 NBUF = 8
 BYTES_PER_PROJECTION = 72          # 36 B read + 36 B written
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K1_KERNEL = "so3::k_rows<so3::OpProject<4,false,100,true>,2,3,256,false,false,1>"     # as rocprofv3 --kernel-trace names it
 
 
 def parse():
@@ -43,7 +44,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--rows", type=int, default=ROWS_DEFAULT, help="rows per GPU")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (default: 1M, config #2; 2M with --config 5)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="2: BASELINE configs[1], 1M rows per GPU (the headline).  5: configs[4], 16M rows sharded over 8 GPUs = 2M rows per GPU, "
+                         "rank r generated with seed r, one RCCL all-reduce of (sum, count) for the mean angle error")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the brief timing of configs #3 and #4")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying one hipGraph of K launches")
@@ -134,7 +138,33 @@ def secondary_configs(lib, dev):
     d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
     ls = torch.empty(1, dtype=torch.float64, device=dev)
     us = timed(lambda i: lib.so3_frob_fwd_bwd_bf16(P(x4.data_ptr()), P(t4.data_ptr()), P(r4.data_ptr()), P(d4.data_ptr()), P(ls.data_ptr()), b, st), 300, 10)
-    out["config4_head_loss_backward_b512_bf16"] = {"us_per_fused_call": us, "note": "launch-latency-bound (9 KB); one memset + one kernel"}
+    out["config4_head_loss_backward_b512_bf16"] = {"us_per_fused_call": us, "note": "launch-latency-bound (9 KB); ONE launch (the one-workgroup kernel writes the loss itself)"}
+    # the same step as a user calls it: through the Python mirror with autograd, and as a recorded hipGraph step
+    from poseestimation_amd import rotation_representation as rr
+    xg = x4.clone().requires_grad_(True)
+    def mirror(_):
+        loss, _r = rr.frobenius_head(xg, t4.view(b, 3, 3))
+        loss.backward()
+        xg.grad = None
+    for i in range(20):
+        mirror(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(200):
+        mirror(i)
+    torch.cuda.synchronize()
+    out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd"] = (time.perf_counter() - t0) / 200 * 1e6
+    step = rr.FrobeniusHeadStep(b, dtype=torch.bfloat16, device=dev)
+    step.x.copy_(x4)
+    step.r_true.copy_(t4.view(b, 3, 3))
+    for i in range(20):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(500):
+        step()
+    torch.cuda.synchronize()
+    out["config4_head_loss_backward_b512_bf16"]["us_per_step_recorded_graph"] = (time.perf_counter() - t0) / 500 * 1e6
     # config #2 again with ONE buffer pair (72 MB: resident in the 256 MiB Infinity Cache) -- labelled, never the headline
     xr = torch.randn(ROWS_DEFAULT, 9, device=dev)
     rr_ = torch.empty(ROWS_DEFAULT, 9, device=dev)
@@ -147,6 +177,14 @@ def secondary_configs(lib, dev):
 
 def main():
     args = parse()
+    # Exactly ONE line goes to stdout.  Native libraries write there too (RCCL prints a version banner when it comes up),
+    # so file descriptor 1 is pointed at stderr for the whole run and the JSON line is written to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before anything initialises HIP (dmabuf IPC only on this pool)
+    if args.rows is None:
+        args.rows = 2_000_000 if args.config == 5 else ROWS_DEFAULT
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -162,7 +200,6 @@ def main():
     if world > 1 or os.environ.get("SO3_BENCH_FORCE_DIST") == "1":    # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist_
         dist = dist_
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -199,6 +236,7 @@ def main():
     # (the C ABI is enqueue-only, hence capturable) and replayed, so the 16-us kernels are not at the mercy
     # of Python's per-launch jitter.  --eager launches each step from the interpreter instead.
     graph = None
+    pre = None
     if not args.eager:
         try:
             torch.cuda.synchronize()
@@ -213,14 +251,44 @@ def main():
                         step(i)
             stream = side
             torch.cuda.synchronize()
-            # Untimed replays: graph upload / first-touch effects, and the shader clock, which needs ~20 ms of load to
-            # come out of its idle state (tools/k1_ramp.py).  One replay when K = 1000; more only for a short graph.
-            t_pre = time.perf_counter()
-            for _ in range(200):
+            # Untimed replays: graph upload / first-touch effects, and the shader clock.  From idle the chip needs ~20 ms of
+            # load before its clock is up (tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
+            # fixed number of warm-up steps would time the ramp, not the kernel.  The timed graph is replayed once (upload,
+            # first touch); then a SHORT graph of the same launches (<= 25 steps, so the ramp is sampled every ~0.4 ms) is
+            # replayed until its time has stopped falling: the mean of the last 8 replays no longer beats the mean of the 8
+            # before it by 0.5 %, after at least 25 ms and at most 60 ms of load.  (`sustained` below is the same graph after
+            # 0.6 s: devices differ in whether that is faster -- clock still rising -- or slower -- power limit reached.)
+            with torch.cuda.stream(side):
                 graph.replay()
+            torch.cuda.synchronize()
+            nshort = min(args.steps, 25)
+            warm = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(warm, stream=side, capture_error_mode="thread_local"):
+                    for i in range(nshort):
+                        step(i)
+            torch.cuda.synchronize()
+            pre = {"replays": 0, "ms": 0.0, "us_per_step_first": None, "us_per_step_last": None,
+                   "policy": "a %d-step graph replayed until the mean of the last 8 replays no longer beats the mean of the 8 before "
+                             "by 0.5 percent (25-60 ms of load)" % nshort}
+            t_pre = time.perf_counter()
+            hist = []
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            while True:
+                with torch.cuda.stream(side):              # a graph replays on the CURRENT stream
+                    a.record(side)
+                    warm.replay()
+                    b.record(side)
                 torch.cuda.synchronize()
-                if time.perf_counter() - t_pre >= 0.015:
+                hist.append(a.elapsed_time(b))
+                spent = time.perf_counter() - t_pre
+                flat = len(hist) >= 16 and sum(hist[-8:]) >= 0.995 * sum(hist[-16:-8])
+                if (flat and spent >= 0.025) or spent >= 0.060:
                     break
+            pre["replays"] = len(hist)
+            pre["us_per_step_first"] = hist[0] * 1e3 / nshort
+            pre["us_per_step_last"] = sum(hist[-8:]) / len(hist[-8:]) * 1e3 / nshort
+            pre["ms"] = (time.perf_counter() - t_pre) * 1e3
         except Exception as exc:               # submission mode only: the same kernels are then launched eagerly
             print(f"[bench] hipGraph capture failed ({exc!r}); falling back to eager launches", file=sys.stderr)
             graph = None
@@ -270,7 +338,7 @@ def main():
         achieved = BYTES_PER_PROJECTION * rows / per_launch_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
-        if os.path.exists(pmc):
+        if rows == ROWS_DEFAULT and os.path.exists(pmc):      # the stored figure belongs to the default row count only
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
@@ -282,30 +350,55 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps,
+            "ms_per_step": wall * 1e3 / args.steps,               # host clock around barrier + synchronize (the contract)
+            "ms_per_step_events": ev_ms / args.steps,             # HIP events on the launch stream: what `roofline` uses
+            "value_events": total_rows * args.steps / (ev_ms * 1e-3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: batch 1M synthetic 3x3 Gaussian -> SO(3) projection, fp32, per GPU",
+            "config": {"workload": ("configs[4]: batch 16M sharded across 8 MI355X (2M rows per GPU, seeds 0-7), RCCL all-reduce of the mean angle error"
+                                    if args.config == 5 else "configs[1]: batch 1M synthetic 3x3 Gaussian -> SO(3) projection, fp32, per GPU"),
                        "rows_per_gpu": rows, "global_rows": total_rows, "buffer_pairs_rotated": NBUF,
                        "parallelism": f"dp{world} (row shards, one all-reduce of (sum,count) for the metric)",
                        "submission": "eager launches" if args.eager else "one hipGraph of K kernel launches, replayed"},
             "mean_angle_error_deg": mean_angle,
             "mean_angle_error_delta_vs_ref_deg": delta,
-            "roofline": {"bound": "hbm", "kernel": "so3::k_rows<OpProject<4,false>,NPL=2,WPS=3,256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": K1_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("stored profile profiles/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                            "this workload, FETCH_SIZE doubled per the gfx950 caveat); not measured in this run") if traffic is not None else None,
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},
+            "pre_timing": pre,
         }
+        if world == 1 and not args.no_secondary and graph is not None:
+            # the same graph held for ~0.6 s: what the kernel sustains once the package sits at its power limit
+            t_hold = time.perf_counter()
+            h0, h1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = max(1, 4000 // args.steps)
+            with torch.cuda.stream(stream):                 # a graph replays on the CURRENT stream
+                while time.perf_counter() - t_hold < 0.6:
+                    for _ in range(max(1, 2000 // args.steps)):
+                        graph.replay()
+                    torch.cuda.synchronize()
+                h0.record(stream)
+                for _ in range(nrep):
+                    graph.replay()
+                h1.record(stream)
+            torch.cuda.synchronize()
+            sus_us = h0.elapsed_time(h1) * 1e3 / (nrep * args.steps)
+            out["sustained"] = {"us_per_step": sus_us, "frac_of_8TBps": BYTES_PER_PROJECTION * rows / (sus_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "note": "same graph after 0.6 s of continuous replay (events over %d launches)" % (nrep * args.steps)}
         if world == 1 and not args.no_secondary:
             del xs, outs
             torch.cuda.empty_cache()
             out["secondary"] = secondary_configs(lib, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
-        print(json.dumps(out), flush=True)
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

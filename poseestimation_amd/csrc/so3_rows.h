@@ -56,20 +56,29 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
     return u;
 }
 
-// ---- one array's unit: geometry and movers ---------------------------------------------------------------
+// ---- one array's share of a round: geometry and movers ----------------------------------------------------
 // EB = element bytes (4: float32, 2: bfloat16, 0: array absent), N = elements per row (9 for 3x3 blocks, 6 for
-// the 6D head's input).  An odd N keeps the stride-N LDS accesses conflict-free; N = 6 is 2-way conflicted.
-template <int EB, int N = 9> struct UnitIO {
-    static constexpr int kBytes = kUnitRows * N * EB;            // 2304 (f32 x 9) / 1152 (bf16 x 9) / 1536 (f32 x 6)
-    static constexpr int kVec4 = kBytes / 16;                    // 144 / 72 / 96
-    static constexpr int kLoads = (kVec4 + 63) / 64;             // 3 / 2 / 2 float4 per lane (last one partial)
-    static constexpr int kSlotBytes = kLoads * 64 * 16;          // 3072 / 2048 / 2048: LDS slot incl. padding
-    static_assert(kBytes % 16 == 0, "a unit must be a whole number of float4");
+// the 6D head's input), G = units per round (NPL).  The G units of a round are neighbours in memory and travel as ONE
+// block: for G = 2 that is 4608 B = 4.5 KiB of float32 (5 loads per lane instead of 2 x 3) or 2304 B of bfloat16
+// (3 loads instead of 2 x 2, all but the last with every lane busy).  An odd N keeps the stride-N LDS accesses
+// conflict-free; N = 6 is 2-way conflicted.
+template <int EB, int N = 9, int G = 1> struct UnitIO {
+    static constexpr int kUnitBytes = kUnitRows * N * EB;        // 2304 (f32 x 9) / 1152 (bf16 x 9) / 1536 (f32 x 6)
+    static constexpr int kBytes = G * kUnitBytes;                // the round's block
+    static constexpr int kVec4 = kBytes / 16;
+    static constexpr int kLoads = (kVec4 + 63) / 64;             // float4 per lane (the last one partial)
+    // The LDS image is ALWAYS float32 (bfloat16 is converted once per block on its way in or out): lanes then read their
+    // rows with ds_read_b32 at a 9-dword stride, conflict-free, whatever the storage type.  (Sub-dword reads of a bf16
+    // image at an 18-byte stride made K1 with bf16 input slower than with float32 input while moving half the bytes.)
+    static constexpr int kUnitImage = kUnitRows * N * 4;         // float32 image of one unit; unit k of the round starts at k * kUnitImage
+    static constexpr int kSlotBytes = kLoads * 64 * 16 * (4 / EB);   // image of the block incl. the partial load's padding
+    static_assert(kBytes % 16 == 0, "a round's block must be a whole number of float4");
 
-    // `unit` is wave-uniform (SGPR) by construction
-    static __device__ __forceinline__ rsrc_t rsrc(const void *base, int64_t unit, bool exists) {
-        char *p = static_cast<char *>(const_cast<void *>(base)) + unit * kBytes;
-        return __builtin_amdgcn_make_buffer_rsrc(p, 0, exists ? kBytes : 0, kRsrcFlags);
+    // `unit` (the round's first) and `count` (how many of its G units exist: 0 past the end, G - 1 for an odd tail) are
+    // wave-uniform (SGPRs) by construction; accesses beyond count units are dropped by the hardware range check
+    static __device__ __forceinline__ rsrc_t rsrc(const void *base, int64_t unit, int count) {
+        char *p = static_cast<char *>(const_cast<void *>(base)) + unit * kUnitBytes;
+        return __builtin_amdgcn_make_buffer_rsrc(p, 0, count * kUnitBytes, kRsrcFlags);
     }
     static __device__ __forceinline__ void fetch(f32x4 (&v)[kLoads], rsrc_t rs, int lane) {
 #pragma unroll
@@ -81,36 +90,52 @@ template <int EB, int N = 9> struct UnitIO {
         for (int j = 0; j < kLoads; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStreamCpol);
     }
+    // registers (storage type, 16 B per lane and load) -> float32 image in LDS
     static __device__ __forceinline__ void to_lds(char *slot, const f32x4 (&v)[kLoads], int lane) {
         f32x4 *t4 = reinterpret_cast<f32x4 *>(slot);
 #pragma unroll
-        for (int j = 0; j < kLoads; ++j) t4[lane + 64 * j] = v[j];
+        for (int j = 0; j < kLoads; ++j) {
+            if constexpr (EB == 4) {
+                t4[lane + 64 * j] = v[j];
+            } else {                                             // 8 bfloat16 -> 8 float32: two 16-byte stores
+                const u32x4 w = __builtin_bit_cast(u32x4, v[j]);
+                const u32x4 lo = {w.x << 16, w.x & 0xFFFF0000u, w.y << 16, w.y & 0xFFFF0000u};
+                const u32x4 hi = {w.z << 16, w.z & 0xFFFF0000u, w.w << 16, w.w & 0xFFFF0000u};
+                t4[2 * (lane + 64 * j)] = __builtin_bit_cast(f32x4, lo);
+                t4[2 * (lane + 64 * j) + 1] = __builtin_bit_cast(f32x4, hi);
+            }
+        }
     }
+    // float32 image in LDS -> registers in the storage type
     static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
         const f32x4 *t4 = reinterpret_cast<const f32x4 *>(slot);
 #pragma unroll
-        for (int j = 0; j < kLoads; ++j) v[j] = t4[lane + 64 * j];
-    }
-    // component k of the lane's row <-> LDS slot, as float
-    template <class T> static __device__ __forceinline__ void read_row(const char *slot, int lane, int k, T (&m)[N]) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            float v;
-            if (EB == 4) v = reinterpret_cast<const float *>(slot)[lane * N + i];
-            else v = bf16_bits_to_f32(reinterpret_cast<const uint16_t *>(slot)[lane * N + i]);
-            Tr<T>::set(m[i], k, v);
+        for (int j = 0; j < kLoads; ++j) {
+            if constexpr (EB == 4) {
+                v[j] = t4[lane + 64 * j];
+            } else {
+                const f32x4 lo = t4[2 * (lane + 64 * j)], hi = t4[2 * (lane + 64 * j) + 1];
+                const u32x4 w = {static_cast<uint32_t>(f32_to_bf16_bits(lo.x)) | static_cast<uint32_t>(f32_to_bf16_bits(lo.y)) << 16,
+                                 static_cast<uint32_t>(f32_to_bf16_bits(lo.z)) | static_cast<uint32_t>(f32_to_bf16_bits(lo.w)) << 16,
+                                 static_cast<uint32_t>(f32_to_bf16_bits(hi.x)) | static_cast<uint32_t>(f32_to_bf16_bits(hi.y)) << 16,
+                                 static_cast<uint32_t>(f32_to_bf16_bits(hi.z)) | static_cast<uint32_t>(f32_to_bf16_bits(hi.w)) << 16};
+                v[j] = __builtin_bit_cast(f32x4, w);
+            }
         }
     }
-    template <class T> static __device__ __forceinline__ void write_row(char *slot, int lane, int k, const T (&m)[N]) {
+    // the lane's row of unit `u` of the round <-> LDS image, as component k of T
+    template <class T> static __device__ __forceinline__ void read_row(const char *slot, int u, int lane, int k, T (&m)[N]) {
+        const float *img = reinterpret_cast<const float *>(slot + u * kUnitImage);
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const float v = Tr<T>::get(m[i], k);
-            if (EB == 4) reinterpret_cast<float *>(slot)[lane * N + i] = v;
-            else reinterpret_cast<uint16_t *>(slot)[lane * N + i] = f32_to_bf16_bits(v);
-        }
+        for (int i = 0; i < N; ++i) Tr<T>::set(m[i], k, img[lane * N + i]);
+    }
+    template <class T> static __device__ __forceinline__ void write_row(char *slot, int u, int lane, int k, const T (&m)[N]) {
+        float *img = reinterpret_cast<float *>(slot + u * kUnitImage);
+#pragma unroll
+        for (int i = 0; i < N; ++i) img[lane * N + i] = Tr<T>::get(m[i], k);
     }
 };
-template <int N> struct UnitIO<0, N> {
+template <int N, int G> struct UnitIO<0, N, G> {
     static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0;
 };
 
@@ -163,17 +188,18 @@ template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false, bool DYN = 
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
-    typedef UnitIO<Op::kIn0, Op::kIn0N> I0;
-    typedef UnitIO<Op::kIn1, Op::kIn1N> I1;
-    typedef UnitIO<Op::kIn2, Op::kIn2N> I2;
-    typedef UnitIO<Op::kOut0, Op::kOut0N> O0;
-    typedef UnitIO<Op::kOut1, Op::kOut1N> O1;
+    typedef UnitIO<Op::kIn0, Op::kIn0N, NPL> I0;
+    typedef UnitIO<Op::kIn1, Op::kIn1N, NPL> I1;
+    typedef UnitIO<Op::kIn2, Op::kIn2N, NPL> I2;
+    typedef UnitIO<Op::kOut0, Op::kOut0N, NPL> O0;
+    typedef UnitIO<Op::kOut1, Op::kOut1N, NPL> O1;
     constexpr int kWaves = BLOCK / 64;
-    // LDS slot of one unit: the input slots side by side; outputs are staged over them once the rows are in registers
+    // LDS slot of a wave: the images of the round's input blocks side by side; outputs are staged over them once the
+    // rows are in registers
     constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes + I2::kSlotBytes;
     constexpr int kOutBytes = O0::kSlotBytes + O1::kSlotBytes;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
-    __shared__ __attribute__((aligned(16))) char lds[kWaves][NPL][kSlot];
+    __shared__ __attribute__((aligned(16))) char lds[kWaves][kSlot];
     __shared__ double red[kWaves];
     __shared__ int red_flag[kWaves];
     __shared__ unsigned next_ticket;
@@ -182,7 +208,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
-    char(*slot)[kSlot] = lds[wave_in_block];
+    char *slot = lds[wave_in_block];
     const int64_t nrounds = (nunits + NPL - 1) / NPL;
     // static: round t, then t + stride.  dynamic: ticket k of this workgroup is round blockIdx + k * gridDim.
     const int64_t stride = DYN ? static_cast<int64_t>(gridDim.x) : static_cast<int64_t>(gridDim.x) * kWaves;
@@ -201,7 +227,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         // memory pipe short of requests whenever the wave's arithmetic outlasts a load's latency: with K1's arithmetic the
         // kernel took the copy's time PLUS 0.4 of the arithmetic's.  Two rounds ahead cost 6 * NPL more VGPRs per input.
         struct Flight {
-            f32x4 in0[NPL][I0::kLoads], in1[NPL][I1::kLoads], in2[NPL][I2::kLoads];
+            f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
         };
         Flight buf[PF];
         int64_t held[PF];                                   // the round each buffer holds (>= nrounds: none, empty loads)
@@ -215,25 +241,21 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             cursor += stride;
             return cursor;
         };
-        auto issue = [&](Flight &b, int64_t tr) {           // past the last round the descriptors are empty: the loads
-            const bool live = tr < nrounds;                 // return 0 and cost no traffic
-            const int64_t tf = live ? tr : t;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                const int64_t u = tf * NPL + k;             // a phantom second unit (odd tail) re-reads the round's first
-                const int64_t ue = u < nunits ? u : tf * NPL;
-                I0::fetch(b.in0[k], I0::rsrc(op.in0, ue, live), lane);
-                if constexpr (Op::kIn1 != 0) I1::fetch(b.in1[k], I1::rsrc(op.in1, ue, live), lane);
-                if constexpr (Op::kIn2 != 0) I2::fetch(b.in2[k], I2::rsrc(op.in2, ue, live), lane);
-            }
+        auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
+            const int64_t left = nunits - tr * NPL;
+            return tr < nrounds ? static_cast<int>(left < NPL ? left : NPL) : 0;
         };
-        auto land = [&](const Flight &b) {                  // registers -> the wave's LDS slot
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                I0::to_lds(slot[k], b.in0[k], lane);
-                if constexpr (Op::kIn1 != 0) I1::to_lds(slot[k] + I0::kSlotBytes, b.in1[k], lane);
-                if constexpr (Op::kIn2 != 0) I2::to_lds(slot[k] + I0::kSlotBytes + I1::kSlotBytes, b.in2[k], lane);
-            }
+        auto issue = [&](Flight &b, int64_t tr) {           // past the last round the descriptors are empty: the loads
+            const int cnt = units_of(tr);                   // return 0 and cost no traffic
+            const int64_t u = cnt > 0 ? tr * NPL : 0;
+            I0::fetch(b.in0, I0::rsrc(op.in0, u, cnt), lane);
+            if constexpr (Op::kIn1 != 0) I1::fetch(b.in1, I1::rsrc(op.in1, u, cnt), lane);
+            if constexpr (Op::kIn2 != 0) I2::fetch(b.in2, I2::rsrc(op.in2, u, cnt), lane);
+        };
+        auto land = [&](const Flight &b) {                  // registers -> the wave's LDS slot (float32 images)
+            I0::to_lds(slot, b.in0, lane);
+            if constexpr (Op::kIn1 != 0) I1::to_lds(slot + I0::kSlotBytes, b.in1, lane);
+            if constexpr (Op::kIn2 != 0) I2::to_lds(slot + I0::kSlotBytes + I1::kSlotBytes, b.in2, lane);
         };
         // STAMP builds: wall-clock (100 MHz) begin / end of the arithmetic of the wave's first four rounds
         auto phase = [&](int ph) {
@@ -261,40 +283,38 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 Rows<T, Op> rows;
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
-                    I0::read_row(slot[k], lane, k, rows.a);
-                    if constexpr (Op::kIn1 != 0) I1::read_row(slot[k] + I0::kSlotBytes, lane, k, rows.b);
-                    if constexpr (Op::kIn2 != 0) I2::read_row(slot[k] + I0::kSlotBytes + I1::kSlotBytes, lane, k, rows.c);
+                    ctx.unit[k] = t * NPL + k;
+                    ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail,
+                    const int u = ctx.exists[k] ? k : 0;    // whose lanes work on the round's first unit instead (results dropped)
+                    I0::read_row(slot, u, lane, k, rows.a);
+                    if constexpr (Op::kIn1 != 0) I1::read_row(slot + I0::kSlotBytes, u, lane, k, rows.b);
+                    if constexpr (Op::kIn2 != 0) I2::read_row(slot + I0::kSlotBytes + I1::kSlotBytes, u, lane, k, rows.c);
                 }
                 wave_lds_fence();
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) {
-                    ctx.unit[k] = t * NPL + k;
-                    ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform
-                }
                 phase(3);
+#ifdef SO3_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
                 op.template compute<T, NPL>(rows, ctx);
+#ifdef SO3_SETPRIO
+                __builtin_amdgcn_s_setprio(SO3_SETPRIO);     // experiment: the wave's memory phase outranks its mates' arithmetic
+#endif
                 phase(4);
                 if (STAMP) ++rounds_done;
                 if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
 #pragma unroll
                     for (int k = 0; k < NPL; ++k) {
-                        if constexpr (Op::kOut0 != 0) O0::write_row(slot[k], lane, k, rows.o0);
-                        if constexpr (Op::kOut1 != 0) O1::write_row(slot[k] + O0::kSlotBytes, lane, k, rows.o1);
+                        if constexpr (Op::kOut0 != 0) O0::write_row(slot, k, lane, k, rows.o0);
+                        if constexpr (Op::kOut1 != 0) O1::write_row(slot + O0::kSlotBytes, k, lane, k, rows.o1);
                     }
                     wave_lds_fence();
-                    f32x4 v0[NPL][O0::kLoads], v1[NPL][O1::kLoads];
-#pragma unroll
-                    for (int k = 0; k < NPL; ++k) {
-                        if constexpr (Op::kOut0 != 0) O0::from_lds(v0[k], slot[k], lane);
-                        if constexpr (Op::kOut1 != 0) O1::from_lds(v1[k], slot[k] + O0::kSlotBytes, lane);
-                    }
+                    f32x4 v0[O0::kLoads], v1[O1::kLoads];
+                    if constexpr (Op::kOut0 != 0) O0::from_lds(v0, slot, lane);
+                    if constexpr (Op::kOut1 != 0) O1::from_lds(v1, slot + O0::kSlotBytes, lane);
                     wave_lds_fence();
-#pragma unroll
-                    for (int k = 0; k < NPL; ++k) {         // a phantom unit's stores are dropped (empty descriptor)
-                        const int64_t ue = ctx.exists[k] ? ctx.unit[k] : 0;
-                        if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, ue, ctx.exists[k]), v0[k], lane);
-                        if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, ue, ctx.exists[k]), v1[k], lane);
-                    }
+                    const int cnt = units_of(t);            // an odd tail's phantom unit is cut off by the descriptor
+                    if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, t * NPL, cnt), v0, lane);
+                    if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, t * NPL, cnt), v1, lane);
                 }
                 if (held[p] >= nrounds) { done = true; break; }
                 // The oldest buffer lands in LDS here, at the END of the body: its loads are older than this round's

@@ -213,6 +213,65 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
     if (threadIdx.x == 0) atomicAdd(loss_sum, total);
 }
 
+// K3 for a batch that fits ONE workgroup (config #4: B = 512): one row per thread, rows read and written straight from
+// global memory (9 KB in all: latency-bound, not a streaming problem), the loss reduced inside the workgroup and written
+// with a plain store -- no zero-fill launch before the kernel and no atomic.  The call is then a single launch.
+constexpr int kSmallBatch = 1024;
+template <bool BF16, bool WANT_R, bool WANT_DM>
+__global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restrict__ M, const float *__restrict__ Rtrue,
+                                                            float *__restrict__ R, void *__restrict__ dM,
+                                                            double *__restrict__ loss_sum, int B, float inv_b) {
+    __shared__ double red[kSmallBatch / 64];
+    const int b = threadIdx.x;
+    const bool active = b < B;
+    float m[9], t[9], r[9], g[9], dm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        m[i] = (i & 3) == 0 ? 1.f : 0.f;              // idle lanes: identity
+        t[i] = m[i];
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            m[i] = BF16 ? bf16_to_f32(static_cast<const uint16_t *>(M)[b * 9 + i]) : static_cast<const float *>(M)[b * 9 + i];
+            t[i] = Rtrue[b * 9 + i];
+        }
+    }
+    const auto f = so3::signed_svd<WANT_DM>(m);
+    so3::rotation_from(f, r);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        g[i] = r[i] - t[i];
+        n2 = fmaf(g[i], g[i], n2);
+    }
+    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+    const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;        // zero difference -> zero gradient
+    if (WANT_DM) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] *= gs;
+        so3::project_backward(f, g, dm);
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (WANT_DM) {
+                if (BF16) static_cast<uint16_t *>(dM)[b * 9 + i] = f32_to_bf16(dm[i]);
+                else static_cast<float *>(dM)[b * 9 + i] = dm[i];
+            }
+            if (WANT_R) R[b * 9 + i] = r[i];
+        }
+    }
+    const double v = wave_sum(active ? static_cast<double>(nrm) : 0.0);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
+        *loss_sum = total;
+    }
+}
+
 // ---- K3', stand-alone Frobenius loss (3D-Pose/loss.py:7-11) for callers that already hold R_pred -----
 // loss_sum += sum_b ||Rtrue_b - Rpred_b||_F ;  optional dRpred_b = (Rpred_b - Rtrue_b) / (B ||.||_F).
 // Element-wise over flat float4s is not possible (the norm is per 9-float row), so the same 256-row tile
@@ -1130,6 +1189,15 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_fwd_bwd: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (B > 0 && B <= kSmallBatch) {                    // one workgroup, one launch: the kernel writes loss_sum itself
+        SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
+        const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
+        const float inv = 1.0f / static_cast<float>(B);
+#define SMALL(WR, WD) hipLaunchKernelGGL((k_frob_small<BF16, WR, WD>), grid, block, 0, s, M, Rtrue, R, dM, loss_sum, static_cast<int>(B), inv)
+        if (R && dM) SMALL(true, true); else if (R) SMALL(true, false); else if (dM) SMALL(false, true); else SMALL(false, false);
+#undef SMALL
+        return check_launch("so3_frob_fwd_bwd");
+    }
     hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
     if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
     if (B == 0) return 0;

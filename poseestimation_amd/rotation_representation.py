@@ -21,6 +21,7 @@ no CPU path: a CPU tensor, or a missing libso3proj.so, raises.
 from __future__ import annotations
 
 import ctypes
+import math
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -190,13 +191,35 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
     return deg, sc, flag
 
 
+def _is_f64(*ts) -> bool:
+    return any(isinstance(t, torch.Tensor) and t.dtype == torch.float64 for t in ts)
+
+
+def _cos_f64(r1: torch.Tensor, r2: torch.Tensor) -> torch.Tensor:
+    """(tr(R1^T R2) - 1) / 2 in float64 (rotation_representation.py:232-236 / :212-216: the two traces are equal)."""
+    a = _as_blocks(r1).double()
+    b = _as_blocks(r2).double()
+    if a.shape != b.shape:
+        raise RuntimeError(f"angle_error: shape mismatch {tuple(r1.shape)} vs {tuple(r2.shape)}")
+    return ((a * b).sum(1) - 1.0) / 2.0
+
+
 def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> torch.Tensor:
     """Geodesic angle between rotations, float64 degrees, shape (B,).
 
     Raises ValueError("angle out of range, ...") when any cosine is outside [-1.1, 1.1], exactly as
     the reference does; that needs one device->host read (the reference's two `torch.any` cost two).
     `check=False` skips the read (and the raise) for benchmarking / graph capture.
+
+    float64 arguments (the reference casts to float64 before the product, :232-233): K4 reads float32 data, so
+    double tensors take the reference's own expression in float64 on the device instead of being rounded.
     """
+    if _is_f64(t_R1, t_R2):
+        _require_device(t_R1, t_R2)
+        cos = _cos_f64(t_R1, t_R2)
+        if check and bool(((cos < -1.1) | (cos > 1.1)).any().item()):
+            raise ValueError(_RANGE_MSG)
+        return torch.acos(cos.clamp(-1.0, 1.0)) * (180.0 / math.pi)
     deg, _, flag = _angle_call(t_R1, t_R2, True, False)
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
@@ -220,6 +243,8 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
 
     reduce="none": (B,) float64 degrees;  reduce="mean": 0-dim float64 mean;  reduce="sum_count": the (sum, count)
     pair for a multi-GPU all-reduce.  return_rotation=True also returns R.  Not differentiable (evaluation path)."""
+    if reduce not in ("none", "mean", "sum_count"):
+        raise ValueError("reduce must be 'none', 'mean' or 'sum_count'")
     dev = _require_device(x, R_true)
     m = _head_input(x.detach())
     if m.dtype != torch.float32:
@@ -229,7 +254,8 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     if t.shape[0] != n:
         raise RuntimeError(f"head_angle_error: {n} predictions vs {t.shape[0]} targets")
     want_deg = reduce == "none"
-    need_r = return_rotation or (n % 64 != 0)
+    # the fused kernel handles whole 64-row units of 16-byte aligned arrays; anything else goes K1 -> R -> K4
+    need_r = return_rotation or (n % 64 != 0) or (m.data_ptr() % 16 != 0) or (t.data_ptr() % 16 != 0)
     r = torch.empty((n, 3, 3), dtype=torch.float32, device=dev) if need_r else None
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
     sc = None if want_deg else torch.empty((2,), dtype=torch.float64, device=dev)
@@ -240,14 +266,15 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
     out = deg if want_deg else (sc if reduce == "sum_count" else sc[0] / sc[1])
-    if reduce not in ("none", "mean", "sum_count"):
-        raise ValueError("reduce must be 'none', 'mean' or 'sum_count'")
     return (out, r) if return_rotation else out
 
 
 def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
-    """Geodesic distance in radians, float32, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,)."""
+    """Geodesic distance in radians, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,); the arguments' dtype as the
+    reference (rotation_representation.py:209-227): float32 through K4', float64 through the same expression in float64."""
     dev = _require_device(m1, m2)
+    if _is_f64(m1, m2):
+        return torch.acos(_cos_f64(m1, m2).clamp(-1.0, 1.0))
     a, b_ = _f32_blocks(m1), _f32_blocks(m2)
     if a.shape != b_.shape:
         raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
@@ -294,7 +321,16 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
     """mean_b ||R_true - R_pred||_F (not squared), differentiable w.r.t. both arguments.
 
     Stand-alone form for callers that already hold R_pred (one kernel for the loss and its gradient).
-    A training step should use `frobenius_head`, which fuses head, loss and backward into one launch."""
+    A training step should use `frobenius_head`, which fuses head, loss and backward into one launch.
+
+    Returns the arguments' dtype as the reference (3D-Pose/loss.py:7-11): float32 through K3'; if either argument is
+    float64 (e.g. the float64 head's output) the reference's three operations run in float64 on the device."""
+    if _is_f64(R_pred, R_true):
+        _require_device(R_pred, R_true)
+        p, t = R_pred.reshape(-1, 3, 3), R_true.reshape(-1, 3, 3)
+        if p.shape != t.shape:
+            raise RuntimeError(f"loss_frobenius: shape mismatch {tuple(R_pred.shape)} vs {tuple(R_true.shape)}")
+        return torch.linalg.matrix_norm(t - p, ord="fro").mean()
     return _LossFrobenius.apply(R_pred, R_true)
 
 
@@ -303,8 +339,6 @@ class _FrobeniusHead(torch.autograd.Function):
     def forward(ctx, x, r_true, want_r):
         dev = _require_device(x, r_true)
         m = _head_input(x.detach())
-        if m.dtype == torch.float64:
-            m = m.float()                      # the fused training-step kernel is float32 / bfloat16 only
         t = _f32_blocks(r_true.detach())
         b = m.shape[0]
         if t.shape[0] != b:
@@ -317,7 +351,8 @@ class _FrobeniusHead(torch.autograd.Function):
         fn = lib.so3_frob_fwd_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
         with _on_device(dev):
             _lib.check(fn(_ptr(m), _ptr(t), _ptr(r), _ptr(dm), _ptr(loss_sum), b, _stream(dev)), "so3_frob_fwd_bwd")
-        loss = loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        torch.mul(loss_sum[0], 1.0 / max(b, 1), out=loss)           # float64 sum -> float32 mean in one kernel
         ctx.dm = dm
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -332,8 +367,10 @@ class _FrobeniusHead(torch.autograd.Function):
         dm = ctx.dm
         if dm is None:
             return None, None, None
-        if dm.dtype == ctx.in_dtype:                      # one in-place scaling launch; the buffer is ours
-            return dm.mul_(grad_loss).view(ctx.in_shape), None, None
+        # out of place: a second backward over the same graph (retain_graph, several losses) must see the stored gradient
+        # unscaled, and the tensor handed out must not alias it
+        if dm.dtype == ctx.in_dtype:
+            return (dm * grad_loss).view(ctx.in_shape), None, None
         return (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape), None, None
 
 
@@ -342,9 +379,66 @@ def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool 
 
     One kernel computes R, the loss and d(loss)/dx; `loss.backward()` then only scales the stored
     gradient.  Returns (loss, R) -- R is detached (use it for metrics) -- or loss alone.
+    float64 x: the fused kernel is float32 / bfloat16 only, so the float64 head and the float64 loss are composed
+    (same values and dtypes as the reference's two calls).
     """
+    if _is_f64(x):
+        r64 = symmetric_orthogonalization(x)
+        loss64 = loss_frobenius(R_true.to(torch.float64), r64)
+        return (loss64, r64.detach()) if return_rotation else loss64
     loss, r = _FrobeniusHead.apply(x, R_true, return_rotation)
     return (loss, r) if return_rotation else loss
+
+
+class FrobeniusHeadStep:
+    """The tail of a training step -- head, Frobenius loss and d(loss)/dx (3D-Pose/main.py:60,85,90) -- for a FIXED batch
+    shape, recorded once into a hipGraph and replayed: config #4 (B = 512) is launch-bound, and through autograd the
+    Python and engine bookkeeping around the 5-us kernel costs twenty times the kernel.
+
+        step = FrobeniusHeadStep(512, dtype=torch.bfloat16, device="cuda:0")
+        step.x.copy_(network_output); step.r_true.copy_(targets)      # or write into them directly
+        loss, dx, r = step()                                          # one graph replay; tensors are reused between calls
+        network_output.backward(dx)                                   # continue into the backbone
+
+    `x`, `r_true` are the static inputs; `loss` (0-dim float32 mean), `dx` (like x) and `r` (B,3,3) are overwritten by
+    every call.  The C ABI is enqueue-only with caller-owned buffers, which is what makes it capturable."""
+
+    def __init__(self, batch: int, dtype: torch.dtype = torch.float32, device="cuda", return_rotation: bool = True):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("FrobeniusHeadStep needs a HIP device (there is no CPU fallback)")
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("FrobeniusHeadStep: float32 or bfloat16 input")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.batch = int(batch)
+        self.x = torch.zeros((self.batch, 9), dtype=dtype, device=dev)
+        self.r_true = torch.eye(3, device=dev).repeat(self.batch, 1, 1)
+        self.dx = torch.empty_like(self.x)
+        self.r = torch.empty((self.batch, 3, 3), dtype=torch.float32, device=dev) if return_rotation else None
+        self._sum = torch.empty((1,), dtype=torch.float64, device=dev)
+        self.loss = torch.empty((), dtype=torch.float32, device=dev)
+        lib = _lib.load()
+        fn = lib.so3_frob_fwd_bwd_bf16 if dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
+        def record():
+            _lib.check(fn(_ptr(self.x), _ptr(self.r_true), _ptr(self.r), _ptr(self.dx), _ptr(self._sum), self.batch,
+                          ctypes.c_void_p(side.cuda_stream)), "so3_frob_fwd_bwd")
+            torch.mul(self._sum[0], 1.0 / max(self.batch, 1), out=self.loss)        # float64 sum -> float32 mean, one kernel
+
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            record()                                                                 # warm-up outside the capture
+            side.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph, stream=side, capture_error_mode="thread_local"):
+                record()
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def __call__(self):
+        self._graph.replay()
+        return self.loss, self.dx, self.r
 
 
 # --------------------------------------------------------------------------------------------

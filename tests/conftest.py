@@ -15,6 +15,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _seeded_rng():
+    """Every test starts from the same RNG state: thresholds on random data must not depend on which tests ran before."""
+    import torch
+    torch.manual_seed(20240)
+    yield
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -11,9 +11,9 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run_bench(*extra):
+def _run_bench(*extra, env=None):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "3", "--cpu-rows", "20000", *extra]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines                      # exactly ONE JSON line on stdout
@@ -38,6 +38,30 @@ def test_bench_json_contract(mode):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "projections/s" and "sample" in c
     assert abs(d["mean_angle_error_delta_vs_ref_deg"]) < 1e-4                      # the parity half of the metric
+    # both clocks are reported: the host clock of the contract and the HIP events the roofline uses
+    assert d["ms_per_step_events"] <= d["ms_per_step"] and abs(r["avg_launch_us"] - d["ms_per_step_events"] * 1e3) < 1e-6
+    assert r["traffic"] is None or "stored profile" in r["traffic_source"]
+    if mode == "graph":
+        assert d["pre_timing"]["replays"] >= 1 and d["pre_timing"]["ms"] <= 200.0
+
+
+def test_bench_under_an_initialised_process_group_rccl_one_rank():
+    """The N > 1 path of bench.py with one rank, in a fresh child process: RCCL comes up (backend "nccl" on the GPU),
+    the K launches are captured into a hipGraph while the process group (and its watchdog thread) exists, and the
+    (sum, count) pair goes through a real all-reduce.  Replaces 3D-Pose/main_DDP.py:39-60.  (Two and more ranks are the
+    driver's to launch; host logic for world_size 2 is covered on CPU with gloo in tests/test_distributed_gloo.py.)"""
+    env = dict(os.environ, SO3_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _run_bench("--no-cpu-baseline", "--no-secondary", env=env)
+    assert d["n_gpus"] == 1 and d["value"] > 1e7 and "hipGraph" in d["config"]["submission"]
+    assert abs(d["mean_angle_error_delta_vs_ref_deg"]) < 1e-4                      # the all-reduced metric, vs the reference's number
+
+
+def test_bench_config5_shape_on_one_rank():
+    """--config 5 = BASELINE configs[4]: 2M rows per GPU (16M over 8), rank r seeded with r; one rank of it fits here."""
+    d = _run_bench("--config", "5", "--no-cpu-baseline", "--no-secondary")
+    assert d["config"]["rows_per_gpu"] == 2_000_000 and d["config"]["workload"].startswith("configs[4]")
+    assert 120.0 < d["mean_angle_error_deg"] < 133.0                               # Haar-like pairs: 126.5 degrees
 
 
 def test_smoke_entry_point():

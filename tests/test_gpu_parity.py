@@ -458,6 +458,163 @@ def test_config3_kabsch_recovers_rotations(rr):
     assert (r - via_head).abs().max().item() < 5e-6
 
 
+@pytest.mark.parametrize("sigma", [0.0, 0.01])
+def test_config3_at_its_own_geometry_65536_clouds_of_1024(rr, c_oracle, sigma):
+    """BASELINE config #3 as bench.py runs it: 65 536 clouds x 1024 points, i.e. 16 clouds per wave in `k_kabsch`
+    (clouds_per_wave = B / (CUs * 16): the keep-loop that parks cloud j's H in lane j runs with j up to 15 here).
+    Data contract: point_cloud/main.py:171-181 (q = R_gt p, no translation), rotations from prepare.py:21-49.
+    Checked against the C oracle on EVERY cloud (max |R - R_ref| <= 5e-6)."""
+    b, n = 65536, 1024
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    p = torch.rand(b, n, 3, device=DEV, generator=gen) - 0.5
+    r_gt = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
+    q = torch.bmm(p, r_gt.transpose(1, 2))
+    if sigma:
+        q = q + sigma * torch.randn(b, n, 3, device=DEV, generator=gen)
+    r, h = rr.kabsch_rotation(p, q, return_h=True)
+    ro, ho = c_oracle.kabsch(p.cpu().numpy(), q.cpu().numpy(), want_h=True)
+    assert np.abs(h.cpu().numpy() - ho).max() < 2e-5 * np.abs(ho).max()        # 1024-term float32 sums vs float64
+    assert np.abs(r.cpu().numpy() - ro).max() < 5e-6
+    assert orth_err(r.cpu().numpy()).max() < 1e-5
+    if sigma == 0.0:
+        assert (r - r_gt).abs().max().item() < 5e-6                              # the round trip
+    # the same clouds with the second cloud made in the kernel (row f4): q = R_gt p + sigma n(seed, cloud, point)
+    from oracle import so3_oracle as so
+    rs, hs = rr.kabsch_rotation_synthetic(p, r_gt, sigma=sigma, seed=11, return_h=True)
+    assert orth_err(rs.cpu().numpy()).max() < 1e-5
+    if sigma == 0.0:
+        assert (rs - r_gt).abs().max().item() < 5e-6 and (rs - r).abs().max().item() < 5e-6
+    # the generator is stateless in (seed, cloud, point): restate it for the first and the last 48 clouds (three waves' worth)
+    for lo in (0, b - 48):
+        ids = np.arange(lo, lo + 48)
+        pn = p[lo:lo + 48].cpu().numpy().astype(np.float64)
+        qn = np.einsum("bac,bic->bia", r_gt[lo:lo + 48].cpu().numpy().astype(np.float64), pn)
+        if sigma:
+            cb, pi, cc = np.meshgrid(ids, np.arange(n), np.arange(3), indexing="ij")
+            qn = qn + sigma * so.synth_normal_np(11, cb, pi, cc)
+        href = so.cross_covariance_np(pn, qn)
+        assert np.abs(hs[lo:lo + 48].cpu().numpy() - href).max() < 3e-5 * np.abs(href).max()
+        assert np.abs(rs[lo:lo + 48].cpu().numpy() - so.symmetric_orthogonalization_np(href)).max() < 5e-6
+
+
+@pytest.mark.parametrize("b,n", [(65536, 64), (262144, 64), (300_000, 33)])
+def test_many_small_clouds_sixteen_and_sixty_four_per_wave(rr, c_oracle, b, n):
+    """The per-wave loops of every cloud kernel at the geometries large batches select: 16 clouds (samples) per wave at
+    B = 65 536 and the cap of 64 at B >= 262 144 (clouds_per_wave = B / (CUs * 16)); 300 000 x 33 adds a ragged last wave
+    and a point count that is not a multiple of the lane count.  Everything against the CPU oracles on all clouds."""
+    from oracle import so3_oracle as so
+    gen = torch.Generator(device=DEV).manual_seed(b + n)
+    p = torch.rand(b, n, 3, device=DEV, generator=gen) - 0.5
+    r_gt = rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV)
+    pn, rn = p.cpu().numpy(), r_gt.cpu().numpy()
+    # a7: pairing (rotate) and normalisation
+    q = rr.rotate_point_clouds(p, r_gt)
+    assert np.abs(q.cpu().numpy() - so.rotate_clouds_np(pn, rn)).max() < 2e-6
+    qt = rr.rotate_point_clouds(p, r_gt, transposed=True)
+    assert np.abs(qt.cpu().numpy() - so.rotate_clouds_np(pn, rn).transpose(0, 2, 1)).max() < 2e-6
+    nn, cc, ss = rr.pc_normalize(p)
+    on, oc, os_ = so.pc_normalize_np(pn)
+    assert np.abs(nn.cpu().numpy() - on).max() < 2e-6 and np.abs(cc.cpu().numpy() - oc).max() < 1e-6
+    assert np.abs(ss.cpu().numpy() - os_).max() < 2e-6
+    # K5 and its synthesising variant
+    r, h = rr.kabsch_rotation(p, q, return_h=True)
+    ro, ho = c_oracle.kabsch(pn, q.cpu().numpy(), want_h=True)
+    assert np.abs(h.cpu().numpy() - ho).max() < 1e-5 * np.abs(ho).max()
+    assert np.quantile(np.abs(r.cpu().numpy() - ro), 0.999) < 5e-6 and (r - r_gt).abs().max().item() < 3e-5   # 33/64 points: H less well conditioned
+    rs = rr.kabsch_rotation_synthetic(p, r_gt, sigma=0.0, seed=3)
+    assert (rs - r).abs().max().item() < 3e-5
+    # f6: ADD-L1 with one wave handling 16 / 64 samples
+    def poses(rot):
+        t = torch.eye(4, device=DEV).repeat(b, 1, 1)
+        t[:, :3, :3] = rot
+        t[:, :3, 3] = torch.randn(b, 3, device=DEV, generator=gen)
+        return t
+    t_gt, t_pred = poses(r_gt), poses(rr.get_sampled_rotation_matrices_by_axisAngle(b, DEV))
+    d = rr.compute_ADD_L1_loss(t_gt, t_pred, p, use_batch_mean=False)
+    pts_gt = torch.bmm(p.double(), t_gt[:, :3, :3].double().transpose(1, 2)) + t_gt[:, None, :3, 3].double()
+    pts_pr = torch.bmm(p.double(), t_pred[:, :3, :3].double().transpose(1, 2)) + t_pred[:, None, :3, 3].double()
+    ref = (pts_gt - pts_pr).abs().mean(dim=(1, 2))                              # Iterative/loss.py:24-25, float64
+    assert (d.double() - ref).abs().max().item() < 3e-6
+
+
+def test_g13_output_dtypes_follow_the_reference(rr):
+    """loss_frobenius / compute_geodesic_distance_from_two_matrices / angle_error for float32 and float64 arguments:
+    dtypes and values as the reference returned them (3D-Pose/loss.py:7-11, rotation_representation.py:209-242)."""
+    g = load_golden("g13_dtype_fidelity.npz")
+    for tag, dt, tol in (("f32", torch.float32, 2e-6), ("f64", torch.float64, 1e-12)):
+        a = dev(g["r1"], dt).requires_grad_(True)
+        b = dev(g["r2"], dt)
+        loss = rr.loss_frobenius(a, b)
+        loss.backward()
+        geo = rr.compute_geodesic_distance_from_two_matrices(a.detach(), b)
+        ang = rr.angle_error(a.detach(), b)
+        assert [str(loss.dtype), str(a.grad.dtype), str(geo.dtype), str(ang.dtype)] == [str(x) for x in g["dtypes_" + tag]]
+        assert abs(loss.item() - float(g["loss_" + tag])) < tol and np.abs(a.grad.cpu().numpy() - g["dloss_" + tag]).max() < tol
+        # float32 acos near 0 and pi is conditioned like 1/sin(theta): judge the float32 path against the float64 answer
+        gerr = np.abs(geo.cpu().numpy().astype(np.float64) - g["geo_f64"]) * np.sin(g["geo_f64"])
+        assert gerr.max() < (2e-6 if dt == torch.float32 else 1e-12)
+        assert np.abs(ang.cpu().numpy() - g["ang_" + tag]).max() < (1e-9 if dt == torch.float32 else 1e-9)
+    # the float64 head's output keeps its precision through the loss and the fused spelling
+    x = torch.randn(300, 9, device=DEV, dtype=torch.float64, requires_grad=True)
+    t = dev(g["r2"], torch.float64)
+    l2 = rr.loss_frobenius(rr.symmetric_orthogonalization(x), t)
+    l3, r3 = rr.frobenius_head(x, t)
+    assert l2.dtype == torch.float64 and l3.dtype == torch.float64 and r3.dtype == torch.float64 and abs(l2.item() - l3.item()) < 1e-14
+    with pytest.raises(ValueError, match="angle out of range"):
+        rr.angle_error(1.7 * t, t)
+
+
+def test_fused_head_backward_twice_over_one_graph(rr):
+    """loss.backward(retain_graph=True) twice with an upstream factor != 1: the stored gradient must not be scaled in
+    place (the second pass would return dm * g * g) and the returned tensor must not alias it."""
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(640, 9, device=DEV, generator=gen, requires_grad=True)
+    t = rr.symmetric_orthogonalization(torch.randn(640, 9, device=DEV, generator=gen))
+    loss, _ = rr.frobenius_head(x, t)
+    (3.0 * loss).backward(retain_graph=True)
+    g1 = x.grad.clone()
+    x.grad = None
+    (3.0 * loss).backward()
+    assert torch.equal(g1, x.grad)
+    x2 = x.detach().clone().requires_grad_(True)
+    rr.loss_frobenius(t, rr.symmetric_orthogonalization(x2)).backward()
+    assert (g1 - 3.0 * x2.grad).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1000), (torch.bfloat16, 3000)])
+def test_recorded_training_step_matches_the_autograd_spelling(rr, dtype, b):
+    """FrobeniusHeadStep (one hipGraph replay: config #4's launch-bound step) against frobenius_head + backward; sizes on
+    both sides of the one-workgroup kernel's limit (1024 rows)."""
+    gen = torch.Generator(device=DEV).manual_seed(b)
+    x = torch.randn(b, 9, device=DEV, generator=gen).to(dtype)
+    t = rr.symmetric_orthogonalization(torch.randn(b, 9, device=DEV, generator=gen))
+    step = rr.FrobeniusHeadStep(b, dtype=dtype, device=DEV)
+    for rep in range(2):                                                         # replayed twice: buffers are reused
+        step.x.copy_(x)
+        step.r_true.copy_(t)
+        loss, dx, r = step()
+        xa = x.clone().requires_grad_(True)
+        la, ra = rr.frobenius_head(xa, t)
+        la.backward()
+        assert loss.dtype == torch.float32 and loss.dim() == 0 and abs(loss.item() - la.item()) < 1e-6
+        assert dx.dtype == dtype and (dx.float() - xa.grad.float()).abs().max().item() <= (0 if dtype == torch.float32 else 1e-3)
+        assert (r - ra).abs().max().item() == 0
+        x = -x                                                                   # new data for the second replay
+
+
+def test_fused_evaluation_on_an_offset_view(rr):
+    """head_angle_error on a contiguous view whose base pointer is not 16-byte aligned (x[1:65]: 64 rows, 36 B off)."""
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    x = torch.randn(200, 9, device=DEV, generator=gen)
+    t = rr.symmetric_orthogonalization(torch.randn(200, 9, device=DEV, generator=gen))
+    for lo, hi in ((1, 65), (3, 131), (0, 64)):
+        d = rr.head_angle_error(x[lo:hi], t[lo:hi])
+        ref = rr.angle_error(rr.symmetric_orthogonalization(x[lo:hi]), t[lo:hi])
+        assert (d - ref).abs().max().item() < 1e-9
+    with pytest.raises(ValueError, match="reduce must be"):
+        rr.head_angle_error(x[:64], t[:64], reduce="median")
+
+
 # ------------------------------------------------------------------------------------------------
 # the C ABI itself: streams, nullable outputs, error codes
 # ------------------------------------------------------------------------------------------------
@@ -549,10 +706,15 @@ def test_g7_ortho6d_head_forward_backward(rr, pa):
     assert pa.transform_output["6D"][0] == 6 and pa.transform_output["6D"][1] is rr.compute_rotation_matrix_from_ortho6d
     with pytest.raises(AssertionError):
         rr.compute_rotation_matrix_from_ortho6d(torch.zeros(4, 9, device=DEV))
+    gen6 = torch.Generator(device=DEV).manual_seed(66)
     for b in (1, 63, 64, 65, 1000, 100_003):
-        x = torch.randn(b, 6, device=DEV)
+        x = torch.randn(b, 6, device=DEV, generator=gen6)
         out = rr.compute_rotation_matrix_from_ortho6d(x).cpu().numpy()
-        assert np.abs(out - so.ortho6d_np(x.cpu().numpy())).max() < 5e-6
+        # Gram-Schmidt is as well conditioned as the two 3-vectors are far from parallel: scale the error by sin(angle)
+        xn = x.cpu().numpy().astype(np.float64)
+        sin = np.linalg.norm(np.cross(xn[:, :3], xn[:, 3:]), axis=1) / (np.linalg.norm(xn[:, :3], axis=1) * np.linalg.norm(xn[:, 3:], axis=1))
+        err = np.abs(out - so.ortho6d_np(x.cpu().numpy())).reshape(b, -1).max(1)
+        assert (err * sin).max() < 2e-6 and np.median(err) < 5e-7
         assert orth_err(out).max() < 1e-5
     big = torch.randn(1_000_000, 6, device=DEV, requires_grad=True)
     rb = rr.compute_rotation_matrix_from_ortho6d(big)

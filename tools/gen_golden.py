@@ -214,7 +214,28 @@ def g10_heads():
     save("g10_heads.npz", **out)
 
 
+def g13_dtype_fidelity():
+    """Output dtypes and float64 values of the loss and the two metrics (3D-Pose/loss.py:7-11,
+    rotation_representation.py:209-242) for float32 and float64 arguments."""
+    torch.manual_seed(13)
+    r1 = rr.symmetric_orthogonalization(torch.randn(300, 9).double())
+    r2 = rr.symmetric_orthogonalization(torch.randn(300, 9).double())
+    out = {"r1": r1, "r2": r2}
+    for tag, cast in (("f32", torch.float32), ("f64", torch.float64)):
+        a, b = r1.to(cast), r2.to(cast)
+        ar = a.clone().requires_grad_(True)
+        loss = loss_frobenius(ar, b)
+        loss.backward()
+        geo = rr.compute_geodesic_distance_from_two_matrices(a, b)
+        ang = rr.angle_error(a, b)
+        out.update({"loss_" + tag: loss.detach(), "dloss_" + tag: ar.grad, "geo_" + tag: geo, "ang_" + tag: ang,
+                    "dtypes_" + tag: np.array([str(loss.dtype), str(ar.grad.dtype), str(geo.dtype), str(ang.dtype)])})
+    save("g13_dtype_fidelity.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g13":
+        return g13_dtype_fidelity()
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         return g9_sampler()
     if len(sys.argv) > 1 and sys.argv[1] == "g7":        # regenerate one fixture without touching the others
@@ -233,6 +254,7 @@ def main():
     g10_heads()
     g11_add_l1()
     g12_clouds()
+    g13_dtype_fidelity()
     # ---- G1: config #1, 256 Gaussian rows ------------------------------------------------------
     torch.manual_seed(0)
     x = torch.randn(256, 9)
