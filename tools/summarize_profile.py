@@ -28,10 +28,14 @@ kt = list(csv.DictReader(open(one("kt/*/*kernel_trace.csv"))))
 k1 = [r for r in kt if KEY in r["Kernel_Name"]]
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in k1]
 summary = {
-    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary (one hipGraph of 1000 launches + warm-up launches)",
+    "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 1000 --warmup 50 --no-cpu-baseline --no-secondary "
+               "(50 warm-up launches, the 1000-launch graph once untimed, short-graph clock warm-up, the timed replay, one launch for the parity metric)",
     "kernel": k1[0]["Kernel_Name"][:120], "dispatches": len(d),
     "avg_us": statistics.mean(d), "median_us": statistics.median(d), "min_us": min(d), "max_us": max(d),
     "first_50_avg_us": statistics.mean(d[:50]), "last_100_avg_us": statistics.mean(d[-100:]),
+    # the timed graph replay is the last block of 1000 dispatches before the single launch of the parity metric
+    "timed_replay_avg_us": statistics.mean(d[-1001:-1]) if len(d) > 1001 else None,
+    "timed_replay_median_us": statistics.median(d[-1001:-1]) if len(d) > 1001 else None,
     "vgpr": k1[0].get("VGPR_Count"), "sgpr": k1[0].get("SGPR_Count"), "lds_bytes": k1[0].get("LDS_Block_Size"),
     "grid": k1[0].get("Grid_Size"), "workgroup": k1[0].get("Workgroup_Size"),
     "algorithmic_bytes_per_launch": 72_000_000,
@@ -57,3 +61,16 @@ traffic = {
 json.dump(traffic, open(os.path.join(root, "k1_pmc_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(root, f"{tag}_k1_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)); print(json.dumps(traffic, indent=1))
+
+# 4. every kernel of the library under --kernel-trace --stats (tools/bench_all.py), if that pass was made
+try:
+    rows = list(csv.DictReader(open(one("kt_all/*/*kernel_stats.csv"))))
+    with open(os.path.join(root, f"{tag}_all_kernels_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+        for r in rows:
+            if any(k in r["Name"] for k in ("so3::", "k_kabsch", "k_add_l1", "k_rotate_clouds", "k_pc_normalize", "k_stats", "k_project", "k_frob", "k_angle", "k_geodesic", "k_op_rows")):
+                w.writerow([" ".join(r["Name"].split())[:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    print("wrote", f"{tag}_all_kernels_stats.csv")
+except (IndexError, OSError) as exc:
+    print("no kt_all pass:", exc)
