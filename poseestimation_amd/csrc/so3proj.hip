@@ -941,122 +941,173 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 }
 
 // ---- next row f3: per-class evaluation statistics of K4's angles (3D-Pose/test_per_class.py:174-216) ----------
-// One reduction pass (count, sum, sum of squares, max, three accuracy thresholds) and an EXACT median by radix
-// select on the float64 bit patterns (non-negative doubles order like their bits): 8 passes of 8 bits, each a
-// histogram kernel over the rows still matching the selected prefix plus a one-workgroup scan that picks the
-// digit.  Two selections run side by side (the lower and upper middle element; numpy averages them).
+// Count, sum, sum of squares, max and three accuracy thresholds, and an EXACT median by radix select on the float64 bit
+// patterns (non-negative doubles order like their bits): 8 passes of 8 bits over the rows still matching the selected
+// prefix; two selections run side by side (the lower and upper middle element; numpy averages them).  One kernel per
+// pass (round 2; round 1 took 20 launches and 430 us): the first pass also gathers the statistics, every pass ends with
+// the LAST workgroup to arrive (a ticket per pass) picking the digit for every class -- a wave per (selection, class),
+// 256 bins in four loads per lane and a wave prefix sum -- and the last pass writes the result.  The grid is two
+// workgroups per CU: round 1's 2048 workgroups each flushed their private histograms with same-address global atomics,
+// which is what its kernels spent their time on.
 constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
 constexpr int kMaxClasses = 64;
-struct StatWork {                                  // layout of the caller's workspace
+constexpr int kStatPasses = 8;
+struct StatWork {                                  // layout of the caller's workspace (zero-filled by the call)
     double acc[kMaxClasses][8];                    // count, sum, sumsq, max, n30, n15, n7.5, nan_count
     unsigned long long prefix[2][kMaxClasses];     // selected high bits so far (lower / upper middle)
     long long krem[2][kMaxClasses];                // rank still to find inside the prefix
     unsigned int hist[2][kMaxClasses][256];
+    unsigned int tickets[kStatPasses];             // workgroups that have finished pass p
 };
 
-__global__ void k_stats_init(StatWork *w, int ncls) {
-    for (int i = threadIdx.x; i < ncls * 8; i += blockDim.x) w->acc[i / 8][i % 8] = 0.0;     // angles are >= 0: 0 is the identity of max too
-    for (int i = threadIdx.x; i < 2 * kMaxClasses; i += blockDim.x) { w->prefix[i / kMaxClasses][i % kMaxClasses] = 0; w->krem[i / kMaxClasses][i % kMaxClasses] = 0; }
-    for (int i = threadIdx.x; i < 2 * kMaxClasses * 256; i += blockDim.x) (&w->hist[0][0][0])[i] = 0;
+__device__ __forceinline__ unsigned int coherent_u32(const unsigned int *p) {     // other workgroups' atomics, read past L1
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-__global__ __launch_bounds__(kBlock) void k_stats_reduce(const double *__restrict__ deg, const int32_t *__restrict__ cls,
-                                                         int ncls, StatWork *w, int64_t B) {
-    __shared__ double sacc[kMaxClasses][8];
-    for (int i = threadIdx.x; i < ncls * 8; i += kBlock) sacc[i / 8][i % 8] = 0.0;
-    __syncthreads();
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < B; i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        const double a = deg[i];
-        const int c = cls ? cls[i] : 0;
-        if (c < 0 || c >= ncls) continue;
-        atomicAdd(&sacc[c][0], 1.0);
-        if (a != a) { atomicAdd(&sacc[c][7], 1.0); continue; }
-        atomicAdd(&sacc[c][1], a);
-        atomicAdd(&sacc[c][2], a * a);
-        atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][3]), static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)));
-        if (a < 30.0) atomicAdd(&sacc[c][4], 1.0);
-        if (a < 15.0) atomicAdd(&sacc[c][5], 1.0);
-        if (a < 7.5) atomicAdd(&sacc[c][6], 1.0);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < ncls * 8; i += kBlock) {
-        const int c = i / 8, f = i % 8;
-        if (f == 3) atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][3]), static_cast<unsigned long long>(__double_as_longlong(sacc[c][3])));
-        else if (sacc[c][f] != 0.0) atomicAdd(&w->acc[c][f], sacc[c][f]);
-    }
-}
-
-__global__ void k_stats_ranks(StatWork *w, int ncls) {      // middle ranks among the non-NaN rows of each class
-    const int c = threadIdx.x;
-    if (c >= ncls) return;
-    const long long n = static_cast<long long>(w->acc[c][0] - w->acc[c][7]);
-    w->krem[0][c] = n > 0 ? (n - 1) / 2 : 0;
-    w->krem[1][c] = n > 0 ? n / 2 : 0;
+__device__ __forceinline__ double coherent_f64(const double *p) {
+    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // LDS: workgroup-private histograms first (early passes put almost every row into one or two digits -- the
 // exponent bytes -- and a million same-address global atomics would serialise), then one flush per bin.
+// 1024-thread workgroups, two rows per thread and trip: at 1M rows and two workgroups per CU every thread loads its
+// rows once, up front (the loop of round 1 walked eight dependent load latencies per pass).  The selected prefixes sit
+// in LDS (they were a dependent global load per row), the first pass's float64 sums go to sixteen lane-private slots per
+// class and field (64 lanes on 10 classes were six-way conflicts on ds_add_f64).
 constexpr int kStatLdsClasses = 16;
-template <bool LDS>
-__global__ __launch_bounds__(kBlock) void k_stats_hist(const double *__restrict__ deg, const int32_t *__restrict__ cls,
-                                                       int ncls, StatWork *w, int64_t B, int shift) {
+constexpr int kStatBlock = 1024;
+constexpr int kStatSlots = 16;
+template <bool LDS, bool FIRST>
+__global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restrict__ deg, const int32_t *__restrict__ cls,
+                                                           int ncls, StatWork *w, int64_t B, int pass, double *__restrict__ stats) {
     __shared__ unsigned int sh[LDS ? 2 : 1][LDS ? kStatLdsClasses : 1][LDS ? 256 : 1];
-    if (LDS) {
-        for (int i = threadIdx.x; i < 2 * kStatLdsClasses * 256; i += kBlock) (&sh[0][0][0])[i] = 0;
-        __syncthreads();
-    }
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < B; i += static_cast<int64_t>(gridDim.x) * kBlock) {
-        const double a = deg[i];
-        const int c = cls ? cls[i] : 0;
-        if (c < 0 || c >= ncls || a != a) continue;
+    __shared__ double sacc[FIRST ? (LDS ? kStatLdsClasses : kMaxClasses) : 1][8][FIRST && LDS ? kStatSlots : 1];
+    __shared__ unsigned long long spre[2][kMaxClasses];
+    __shared__ int is_last;
+    constexpr int kSlots = LDS ? kStatSlots : 1;
+    const int shift = 56 - 8 * pass;
+    if (LDS) for (int i = threadIdx.x; i < 2 * kStatLdsClasses * 256; i += kStatBlock) (&sh[0][0][0])[i] = 0;
+    if (FIRST) for (int i = threadIdx.x; i < ncls * 8 * kSlots; i += kStatBlock) (&sacc[0][0][0])[i] = 0.0;
+    for (int i = threadIdx.x; i < 2 * ncls; i += kStatBlock) spre[i / ncls][i % ncls] = FIRST ? 0ull : w->prefix[i / ncls][i % ncls];
+    __syncthreads();
+    const int slot = threadIdx.x & (kSlots - 1);
+    auto row = [&](double a, int c) {
+        if (c < 0 || c >= ncls) return;
+        if (FIRST) {
+            atomicAdd(&sacc[c][0][slot], 1.0);
+            if (a != a) { atomicAdd(&sacc[c][7][slot], 1.0); return; }
+            atomicAdd(&sacc[c][1][slot], a);
+            atomicAdd(&sacc[c][2][slot], a * a);
+            atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][3][slot]), static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)));
+            if (a < 30.0) atomicAdd(&sacc[c][4][slot], 1.0);
+            if (a < 15.0) atomicAdd(&sacc[c][5][slot], 1.0);
+            if (a < 7.5) atomicAdd(&sacc[c][6][slot], 1.0);
+        } else if (a != a) {
+            return;
+        }
         const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a));
         const unsigned long long hi = shift >= 56 ? 0ull : key >> (shift + 8);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-            if (hi == w->prefix[t][c]) {
+            if (hi == spre[t][c]) {
                 if (LDS) atomicAdd(&sh[t][c][(key >> shift) & 0xFF], 1u);
                 else atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
             }
+    };
+    // two rows per thread and trip: one 16-byte and one 8-byte load (B even part), the odd last row by itself
+    const int64_t pairs = B / 2;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kStatBlock + threadIdx.x; i < pairs; i += static_cast<int64_t>(gridDim.x) * kStatBlock) {
+        const double2 a = reinterpret_cast<const double2 *>(deg)[i];
+        int2 c = make_int2(0, 0);
+        if (cls) c = reinterpret_cast<const int2 *>(cls)[i];
+        row(a.x, c.x);
+        row(a.y, c.y);
     }
+    if ((B & 1) && blockIdx.x == 0 && threadIdx.x == 0) row(deg[B - 1], cls ? cls[B - 1] : 0);
+    __syncthreads();
     if (LDS) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * ncls * 256; i += kBlock) {
+        for (int i = threadIdx.x; i < 2 * ncls * 256; i += kStatBlock) {
             const int t = i / (ncls * 256), c = (i / 256) % ncls, d = i % 256;
             const unsigned int v = sh[t][c][d];
             if (v) atomicAdd(&w->hist[t][c][d], v);
         }
     }
-}
-
-__global__ void k_stats_scan(StatWork *w, int ncls) {      // pick the digit holding rank krem; extend the prefix
-    const int c = threadIdx.x % kMaxClasses, t = threadIdx.x / kMaxClasses;
-    if (c >= ncls || t >= 2) return;
-    long long k = w->krem[t][c];
-    unsigned int d = 0;
-    for (; d < 255; ++d) {
-        const unsigned int h = w->hist[t][c][d];
-        if (k < static_cast<long long>(h)) break;
-        k -= h;
+    if (FIRST) {
+        for (int i = threadIdx.x; i < ncls * 8; i += kStatBlock) {
+            const int c = i / 8, f = i % 8;
+            if (f == 3) {
+                unsigned long long m = 0;
+                for (int k = 0; k < kSlots; ++k) { const unsigned long long v = static_cast<unsigned long long>(__double_as_longlong(sacc[c][3][k])); m = v > m ? v : m; }
+                atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][3]), m);
+            } else {
+                double v = 0.0;
+                for (int k = 0; k < kSlots; ++k) v += sacc[c][f][k];
+                if (v != 0.0) atomicAdd(&w->acc[c][f], v);
+            }
+        }
     }
-    w->krem[t][c] = k;
-    w->prefix[t][c] = (w->prefix[t][c] << 8) | d;
-    for (int i = 0; i < 256; ++i) w->hist[t][c][i] = 0;
-}
-
-__global__ void k_stats_final(const StatWork *w, int ncls, double *__restrict__ stats) {
-    const int c = threadIdx.x;
-    if (c >= ncls) return;
-    const double n = w->acc[c][0], nan = w->acc[c][7], m = n - nan;
-    double *o = stats + c * kStatFields;
-    const double mean = w->acc[c][1] / m;
-    o[0] = n;
-    o[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000ll) : mean;
-    const double var = w->acc[c][2] / m - mean * mean;
-    o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
-    o[3] = nan > 0 ? o[1] : w->acc[c][3];
-    const double lo = __longlong_as_double(static_cast<long long>(w->prefix[0][c])), hi = __longlong_as_double(static_cast<long long>(w->prefix[1][c]));
-    o[4] = (nan > 0 || m <= 0) ? __longlong_as_double(0x7ff8000000000000ll) : 0.5 * (lo + hi);
-    o[5] = w->acc[c][4] / n; o[6] = w->acc[c][5] / n; o[7] = w->acc[c][6] / n;   // (x < t).sum() / len(x)
+    // The last workgroup to get here closes the pass.  Every wave drains its own atomics (they stay in vmcnt until the
+    // memory side has acknowledged them), the barrier collects the waves, then ONE lane publishes: a release fence by all
+    // 1024 threads of 512 workgroups (each a write-back of the XCD's L2) cost 75 us per pass.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(&w->tickets[pass], 1u) == gridDim.x - 1 ? 1 : 0;
+        if (is_last) __threadfence();
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int pair = wave; pair < 2 * ncls; pair += kStatBlock / 64) {      // a wave per (selection, class)
+        const int t = pair / ncls, c = pair % ncls;
+        long long k;
+        if (FIRST) {                                                    // middle ranks among the non-NaN rows of the class
+            const long long n = static_cast<long long>(coherent_f64(&w->acc[c][0]) - coherent_f64(&w->acc[c][7]));
+            k = n > 0 ? (t == 0 ? (n - 1) / 2 : n / 2) : 0;
+        } else {
+            k = w->krem[t][c];
+        }
+        unsigned int h[4];
+        unsigned int mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = coherent_u32(&w->hist[t][c][4 * lane + j]); mine += h[j]; }
+        unsigned int incl = mine;                                       // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        const long long before = static_cast<long long>(incl - mine);
+        // the digit holding rank k: the first bin whose cumulative count exceeds k (the last bin if none does)
+        const bool here = k >= before && k < before + static_cast<long long>(mine);
+        const unsigned long long vote = __ballot(here);
+        const int owner = vote ? __ffsll(static_cast<long long>(vote)) - 1 : 63;
+        if (lane == owner) {
+            long long kk = k - before;
+            unsigned int d = 0;
+            if (vote) { for (; d < 3; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; } }
+            else { d = 3; kk = k - before - (mine - h[3]); if (kk < 0) kk = 0; }
+            w->krem[t][c] = kk;
+            w->prefix[t][c] = (spre[t][c] << 8) | static_cast<unsigned long long>(4 * lane + d);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w->hist[t][c][4 * lane + j] = 0;     // ready for the next pass (next launch)
+    }
+    if (pass != kStatPasses - 1) return;
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncls; c += kStatBlock) {
+        const double n = coherent_f64(&w->acc[c][0]), nan = coherent_f64(&w->acc[c][7]), m = n - nan;
+        double *o = stats + c * kStatFields;
+        const double mean = coherent_f64(&w->acc[c][1]) / m;
+        o[0] = n;
+        o[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000ll) : mean;
+        const double var = coherent_f64(&w->acc[c][2]) / m - mean * mean;
+        o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
+        o[3] = nan > 0 ? o[1] : coherent_f64(&w->acc[c][3]);
+        const double lo = __longlong_as_double(static_cast<long long>(w->prefix[0][c])), hi = __longlong_as_double(static_cast<long long>(w->prefix[1][c]));
+        o[4] = (nan > 0 || m <= 0) ? __longlong_as_double(0x7ff8000000000000ll) : 0.5 * (lo + hi);
+        o[5] = coherent_f64(&w->acc[c][4]) / n; o[6] = coherent_f64(&w->acc[c][5]) / n; o[7] = coherent_f64(&w->acc[c][6]) / n;   // (x < t).sum() / len(x)
+    }
 }
 
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
@@ -1514,16 +1565,17 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     SO3_CHECK_ARGS(stats != nullptr && workspace != nullptr && (B == 0 || deg != nullptr), "so3_angle_stats: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     StatWork *w = static_cast<StatWork *>(workspace);
-    k_stats_init<<<1, 1024, 0, s>>>(w, ncls);
-    const unsigned grid = persistent_grid(B > 0 ? B : 1);
-    if (B > 0) k_stats_reduce<<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B);
-    k_stats_ranks<<<1, kMaxClasses, 0, s>>>(w, ncls);
-    for (int shift = 56; shift >= 0 && B > 0; shift -= 8) {
-        if (ncls <= kStatLdsClasses) k_stats_hist<true><<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
-        else k_stats_hist<false><<<grid, kBlock, 0, s>>>(deg, cls, ncls, w, B, shift);
-        k_stats_scan<<<1, 2 * kMaxClasses, 0, s>>>(w, ncls);
+    const hipError_t e = hipMemsetAsync(w, 0, sizeof(StatWork), s);
+    if (e != hipSuccess) return fail(static_cast<int>(e), "so3_angle_stats: memset");
+    const int64_t want = (B / 2 + kStatBlock - 1) / kStatBlock;
+    const int64_t cap = 2 * static_cast<int64_t>(device_cus());
+    const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));
+    for (int pass = 0; pass < kStatPasses; ++pass) {
+#define PASS(LD, FI) k_stats_pass<LD, FI><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, pass, stats)
+        if (ncls <= kStatLdsClasses) { if (pass == 0) PASS(true, true); else PASS(true, false); }
+        else { if (pass == 0) PASS(false, true); else PASS(false, false); }
+#undef PASS
     }
-    k_stats_final<<<1, kMaxClasses, 0, s>>>(w, ncls, stats);
     return check_launch("so3_angle_stats");
 }
 
