@@ -1002,7 +1002,11 @@ def test_offsets_past_four_gigabytes(rr, c_oracle):
         assert np.median(err) < 5e-7 and err.max() < 1e-3, (lo, err.max())
         assert np.array_equal(flip[lo:lo + 1000].cpu().numpy(), np.linalg.det(xs.reshape(-1, 3, 3).astype(np.float64)) < 0)
     worst, mismatches = 0.0, 0
-    for lo in range(0, n, 20_000_000):                      # element-wise (a 20M-batch bmm aborts inside rocBLAS)
+    # Orthogonality element-wise instead of torch.bmm(r^T, r): probed on this image (torch 2.10 + ROCm 7.0 rocBLAS), a batched
+    # 3x3 float32 bmm works up to a batch of 2^24 = 16 777 216 and at 20 000 000 the process dies with SIGABRT after
+    # "GPU core dump created" (a memory fault inside the library's batched-GEMM kernel; nothing of libso3proj is running).
+    # Callers of the reference's bmm-based metrics at this scale have to chunk the batch the same way.
+    for lo in range(0, n, 20_000_000):
         blk = r[lo:lo + 20_000_000]
         e = torch.zeros(blk.shape[0], device=DEV)
         for i in range(3):
