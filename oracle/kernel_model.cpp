@@ -59,6 +59,16 @@ void model_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B)
     for (int64_t b = 0; b < B; ++b) {
         float m[9], g[9], d[9];
         for (int i = 0; i < 9; ++i) { m[i] = M[9 * b + i]; g[i] = G[9 * b + i]; }
+        so3::project_backward_rows<float>(m, g, d);
+        for (int i = 0; i < 9; ++i) dM[9 * b + i] = d[i];
+    }
+}
+
+// the Jacobi frames' backward alone (what hard rows run)
+void model_project_bwd_jacobi_f32(const float *M, const float *G, float *dM, int64_t B) {
+    for (int64_t b = 0; b < B; ++b) {
+        float m[9], g[9], d[9];
+        for (int i = 0; i < 9; ++i) { m[i] = M[9 * b + i]; g[i] = G[9 * b + i]; }
         const auto f = so3::signed_svd<true, float>(m);
         so3::project_backward(f, g, d);
         for (int i = 0; i < 9; ++i) dM[9 * b + i] = d[i];

@@ -77,6 +77,14 @@ def project(m, packed=False, want_flip=False):
     return (r, flip.astype(bool)) if want_flip else r
 
 
+def project_bwd_jacobi(m, g):
+    """The backward through the Jacobi frames alone (hard rows of K2 / K3)."""
+    m, g = _c(m, np.float32), _c(g, np.float32)
+    d = np.empty_like(m)
+    lib().model_project_bwd_jacobi_f32(_p(m), _p(g), _p(d), ctypes.c_int64(m.shape[0]))
+    return d.reshape(-1, 3, 3)
+
+
 def project_bwd(m, g):
     m, g = _c(m, np.float32), _c(g, np.float32)
     d = np.empty_like(m)

@@ -628,7 +628,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
 // (float64 rows go straight to Jacobi: so3_project_fwd_f64 is not a benchmark path.)
-template <class T> __device__ __forceinline__ void project_rotation(const T (&m)[9], T (&r)[9]) {
+template <class T> __device__ __forceinline__ typename Tr<T>::mask project_rotation(const T (&m)[9], T (&r)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
     const typename R::mask hard = quat_rotation<T>(m, r);
@@ -646,10 +646,12 @@ template <class T> __device__ __forceinline__ void project_rotation(const T (&m)
             }
         }
     }
+    return hard;                       // which rows took the Jacobi path (their backward must, too)
 }
-template <> __device__ __forceinline__ void project_rotation<double>(const double (&m)[9], double (&r)[9]) {
+template <> __device__ __forceinline__ bool project_rotation<double>(const double (&m)[9], double (&r)[9]) {
     const auto f = signed_svd<false, double, 4, true, 6>(m);
     rotation_from(f, r);
+    return true;
 }
 
 // sign(det M) -> flip flag.  A float32 cofactor expansion decides whenever |det| clears its own rounding bound
@@ -691,6 +693,83 @@ __device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T 
     dm[0] = r0.x; dm[1] = r0.y; dm[2] = r0.z;
     dm[3] = r1.x; dm[4] = r1.y; dm[5] = r1.z;
     dm[6] = r2.x; dm[7] = r2.y; dm[8] = r2.z;
+}
+
+// =====================================================================================================================
+// Backward of the projection in terms of R alone (round 2): with S = R^T M (symmetric at the optimum, eigenvalues
+// s1, s2, s3') a perturbation dM turns R by R [w]x where  (tr(S) I - S) w = axial(R^T dM - dM^T R)  -- the matrix
+// A = tr(S) I - S has the eigenvalues s_i + s_j, the denominators of the reference's svd_backward chain.  Transposing,
+//     dL/dM = R [y]x ,   A y = axial(R^T G - G^T R) ,
+// which is U' B V^T of project_backward written without U', V or the singular values (B = [y]x in V's basis).
+// 18 + 18 packed instructions for the two products' needed entries, a symmetric 3x3 solve by cofactors (one v_rcp), 18
+// for R [y]x: the fast path's rotation is all it needs, so K2 / K3 no longer pay for an SVD on the rows 3a settles.
+// Valid where 3a's tests passed: they bound the smallest eigenvalue of A, 2 (s2 + s3'), from below.
+template <class T>
+__device__ __forceinline__ void backward_from_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], T (&dm)[9]) {
+    typedef Tr<T> R;
+    // S = R^T M, upper triangle: S_ij = sum_k r[3k+i] m[3k+j]
+    const T s00 = R::fma(r[6], m[6], R::fma(r[3], m[3], r[0] * m[0]));
+    const T s11 = R::fma(r[7], m[7], R::fma(r[4], m[4], r[1] * m[1]));
+    const T s22 = R::fma(r[8], m[8], R::fma(r[5], m[5], r[2] * m[2]));
+    const T s01 = R::fma(r[6], m[7], R::fma(r[3], m[4], r[0] * m[1]));
+    const T s02 = R::fma(r[6], m[8], R::fma(r[3], m[5], r[0] * m[2]));
+    const T s12 = R::fma(r[7], m[8], R::fma(r[4], m[5], r[1] * m[2]));
+    // A = tr(S) I - S
+    const T a00 = s11 + s22, a11 = s00 + s22, a22 = s00 + s11, a01 = -s01, a02 = -s02, a12 = -s12;
+    // b = axial(Z - Z^T), Z = R^T G:  b = (Z21 - Z12, Z02 - Z20, Z10 - Z01)   (0-based; Z_ij = sum_k r[3k+i] g[3k+j])
+    const T b0 = R::fma(r[8], g[7], R::fma(r[5], g[4], r[2] * g[1])) - R::fma(r[7], g[8], R::fma(r[4], g[5], r[1] * g[2]));
+    const T b1 = R::fma(r[6], g[8], R::fma(r[3], g[5], r[0] * g[2])) - R::fma(r[8], g[6], R::fma(r[5], g[3], r[2] * g[0]));
+    const T b2 = R::fma(r[7], g[6], R::fma(r[4], g[3], r[1] * g[0])) - R::fma(r[6], g[7], R::fma(r[3], g[4], r[0] * g[1]));
+    // y = A^-1 b by cofactors (A symmetric positive definite on settled rows)
+    const T c00 = R::fma(a11, a22, -(a12 * a12)), c01 = R::fma(a02, a12, -(a01 * a22)), c02 = R::fma(a01, a12, -(a02 * a11));
+    const T c11 = R::fma(a00, a22, -(a02 * a02)), c12 = R::fma(a01, a02, -(a00 * a12)), c22 = R::fma(a00, a11, -(a01 * a01));
+    const T det = R::fma(a02, c02, R::fma(a01, c01, a00 * c00));
+    const T rd = R::rcp(det);
+    const T y0 = R::fma(c02, b2, R::fma(c01, b1, c00 * b0)) * rd;
+    const T y1 = R::fma(c12, b2, R::fma(c11, b1, c01 * b0)) * rd;
+    const T y2 = R::fma(c22, b2, R::fma(c12, b1, c02 * b0)) * rd;
+    // dM = R [y]x :  column 0 = y2 r_col1 - y1 r_col2, column 1 = y0 r_col2 - y2 r_col0, column 2 = y1 r_col0 - y0 r_col1
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dm[3 * i + 0] = R::fma(y2, r[3 * i + 1], -(y1 * r[3 * i + 2]));
+        dm[3 * i + 1] = R::fma(y0, r[3 * i + 2], -(y2 * r[3 * i + 0]));
+        dm[3 * i + 2] = R::fma(y1, r[3 * i + 0], -(y0 * r[3 * i + 1]));
+    }
+}
+
+// dM for upstream G, given the rotation R = project_rotation(M) and the mask of rows that took the Jacobi path: settled rows
+// from the rotation, hard rows through the Jacobi frames (their denominators s_i + s_j may vanish: floored there).
+template <class T>
+__device__ __forceinline__ void backward_given_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], typename Tr<T>::mask hard, T (&dm)[9]) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    backward_from_rotation<T>(m, r, g, dm);
+    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+#pragma unroll
+        for (int i = 0; i < R::kLanes; ++i) {
+            if (R::lane_of(hard, i)) {
+                S mk[9], gk[9], dk[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { mk[j] = R::get(m[j], i); gk[j] = R::get(g[j], i); }
+                const auto f = signed_svd<true, S>(mk);
+                project_backward(f, gk, dk);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) R::set(dm[j], i, dk[j]);
+            }
+        }
+    }
+}
+template <>
+__device__ __forceinline__ void backward_given_rotation<double>(const double (&m)[9], const double (&)[9], const double (&g)[9], bool, double (&dm)[9]) {
+    const auto f = signed_svd<true, double, 4, true, 6>(m);
+    project_backward(f, g, dm);
+}
+
+// K2's arithmetic (autograd of K1): rotation, then its backward.
+template <class T> __device__ __forceinline__ void project_backward_rows(const T (&m)[9], const T (&g)[9], T (&dm)[9]) {
+    T r[9];
+    const typename Tr<T>::mask hard = project_rotation<T>(m, r);
+    backward_given_rotation<T>(m, r, g, hard, dm);
 }
 
 }  // namespace so3

@@ -416,8 +416,7 @@ struct OpProjectBwd : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &) const {
-        const auto f = signed_svd<true, T>(rows.a);
-        project_backward(f, rows.b, rows.o0);
+        project_backward_rows<T>(rows.a, rows.b, rows.o0);
     }
 };
 
@@ -435,8 +434,7 @@ struct OpFrobHead : OpBase {
         const T (&t)[9] = rows.b;
         T (&dm)[9] = rows.o0;
         T (&r)[9] = rows.o1;
-        const auto f = signed_svd<WANT_DM, T>(m);
-        rotation_from(f, r);
+        const typename R::mask hard = project_rotation<T>(m, r);
         T g[9];
         T n2 = R::splat(0.f);
 #pragma unroll
@@ -453,7 +451,7 @@ struct OpFrobHead : OpBase {
             const T gs = R::sel(R::gt(n2, R::splat(0.f)), inv * R::splat(inv_b), R::splat(0.f));   // zero difference -> zero gradient
 #pragma unroll
             for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
-            project_backward(f, g, dm);
+            backward_given_rotation<T>(m, r, g, hard, dm);
         }
     }
     __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
@@ -870,8 +868,7 @@ struct OpSe3UpdateBwd : OpBase {
 #pragma unroll
             for (int j = 0; j < 3; ++j)                       // dL/d(dR) = G_R R_k^T
                 gdr[3 * i + j] = R::fma(g[4 * i + 2], ti[4 * j + 2], R::fma(g[4 * i + 1], ti[4 * j + 1], g[4 * i] * ti[4 * j]));
-        const auto f = signed_svd<true, T>(m);
-        project_backward(f, gdr, dm);
+        project_backward_rows<T>(m, gdr, dm);
 #pragma unroll
         for (int i = 0; i < 9; ++i) d[i] = dm[i];
         const T zk = ti[11], iz = R::rcp(zk);

@@ -143,8 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_project_bwd(const void *__restrict__
     const bool active = static_cast<int>(threadIdx.x) < n;
     lane_get(tile_m, active, m);
     lane_get(tile_g, active, g);
-    const auto f = so3::signed_svd<true>(m);
-    so3::project_backward(f, g, dm);
+    so3::project_backward_rows<float>(m, g, dm);
     lane_put(tile_m, dm);
     __syncthreads();
     tile_out<BF16, VEC>(dM, first, n, tile_m);
@@ -184,8 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
         const bool active = static_cast<int>(threadIdx.x) < n;
         lane_get(tile_m, active, m);
         lane_get(tile_t, active, t);
-        const auto f = so3::signed_svd<WANT_DM>(m);
-        so3::rotation_from(f, r);
+        const bool hard = so3::project_rotation<float>(m, r);
         float n2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
         if (WANT_DM) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) g[i] *= gs;
-            so3::project_backward(f, g, dm);
+            so3::backward_given_rotation<float>(m, r, g, hard, dm);
             lane_put(tile_m, dm);
         }
         if (WANT_R) lane_put(tile_t, r);
@@ -237,8 +235,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
             t[i] = Rtrue[b * 9 + i];
         }
     }
-    const auto f = so3::signed_svd<WANT_DM>(m);
-    so3::rotation_from(f, r);
+    const bool hard = so3::project_rotation<float>(m, r);
     float n2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
     if (WANT_DM) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) g[i] *= gs;
-        so3::project_backward(f, g, dm);
+        so3::backward_given_rotation<float>(m, r, g, hard, dm);
     }
     if (active) {
 #pragma unroll
