@@ -485,6 +485,29 @@ struct OpFrobLoss : OpBase {
     __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
 };
 
+// acos in float64 to 1.4e-14 rad (the metric is compared at 1e-9 degrees): |c| <= 1/2: pi/2 - asin(c); otherwise through
+// asin(sqrt((1 - |c|)/2)).  asin(x) = x + x z g(z), z = x^2 <= 1/4, g a degree-9 polynomial (Chebyshev fit).  A third of the
+// device library's acos in instructions: the float64 work of K4 and of the fused K1+K4 is what holds their clocks down.
+__device__ __forceinline__ double acos_f64(double c) {
+    const double a = __builtin_fabs(c);
+    const bool small = a <= 0.5;
+    const double z = small ? c * c : (1.0 - a) * 0.5;
+    const double x = small ? c : __builtin_sqrt(z);
+    double g = 2.80174951579700952e-02;
+    g = __builtin_fma(g, z, -3.06358547004551354e-03);
+    g = __builtin_fma(g, z, 1.57334373966823808e-02);
+    g = __builtin_fma(g, z, 1.31733845957499804e-02);
+    g = __builtin_fma(g, z, 1.74436241846820592e-02);
+    g = __builtin_fma(g, z, 2.23658829849630453e-02);
+    g = __builtin_fma(g, z, 3.03821915977370988e-02);
+    g = __builtin_fma(g, z, 4.46428522253018087e-02);
+    g = __builtin_fma(g, z, 7.50000000378114595e-02);
+    g = __builtin_fma(g, z, 1.66666666666618946e-01);
+    const double r = __builtin_fma(x * z, g, x);           // asin(x)
+    const double big = c > 0.0 ? r + r : __builtin_fma(-2.0, r, 3.14159265358979323846);
+    return small ? 1.57079632679489661923 - r : big;       // NaN in -> NaN out (comparisons false, arithmetic propagates)
+}
+
 // K4: theta = acos(clamp((tr(R1^T R2) - 1)/2)) in float64 on float32 data (rotation_representation.py:230-242).
 template <bool WANT_DEG, bool WANT_SUM>
 struct OpAngle : OpBase {
@@ -506,7 +529,7 @@ struct OpAngle : OpBase {
             if (ctx.exists[k]) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);   // NaN compares false, as torch.any(...) does
             double c = fmin(fmax(c_raw, -1.0), 1.0);         // torch.clamp ...
             if (c_raw != c_raw) c = c_raw;                   // ... which keeps NaN (fmin/fmax drop it)
-            const double ang = acos(c) * unit_scale;
+            const double ang = acos_f64(c) * unit_scale;
             if (WANT_DEG) {
                 const u32x2 bits = __builtin_bit_cast(u32x2, ang);
                 __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc<8>(deg, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane * 8, 0, 0);
@@ -547,7 +570,7 @@ struct OpProjectAngle : OpBase {
             if (ctx.exists[k]) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
             double c = fmin(fmax(c_raw, -1.0), 1.0);
             if (c_raw != c_raw) c = c_raw;
-            const double ang = acos(c) * unit_scale;
+            const double ang = acos_f64(c) * unit_scale;
             if (WANT_DEG) {
                 const u32x2 bits = __builtin_bit_cast(u32x2, ang);
                 __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc<8>(deg, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane * 8, 0, 0);

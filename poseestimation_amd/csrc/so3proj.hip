@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict_
     const bool bad = active && (c_raw < -1.1 || c_raw > 1.1);  // NaN compares false, as torch.any(...) does
     double c = fmin(fmax(c_raw, -1.0), 1.0);                   // torch.clamp ...
     if (c_raw != c_raw) c = c_raw;                             // ... which keeps NaN (fmin/fmax drop it)
-    const double ang = acos(c) * unit;
+    const double ang = so3::acos_f64(c) * unit;
     if (range_flag != nullptr && __any(bad)) {
         if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
     }
