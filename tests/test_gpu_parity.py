@@ -165,6 +165,12 @@ def test_numerically_rank_deficient_input_still_gives_rotations(rr, dtype):
         "rank two": torch.cat((a[:, :2], a[:, :1] + a[:, 1:2]), 1),
         "rank two + 1e-7": torch.cat((a[:, :2], a[:, :1] + a[:, 1:2]), 1) + 1e-7 * torch.randn(n, 3, 3, device=DEV, generator=gen),
         "outer + 1e-7": torch.randn(n, 3, 1, device=DEV, generator=gen) @ torch.randn(n, 1, 3, device=DEV, generator=gen) + 1e-7 * a,
+        # what the quaternion fast path must hand to the Jacobi path: exact double roots at the top of K's spectrum (s2 = s3,
+        # det < 0: frequent with entries in -1..1), reflections (a triple root), scales outside its window
+        "entries in -1..1": torch.randint(-1, 2, (n, 3, 3), device=DEV, generator=gen).float(),
+        "reflections": rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen)) * torch.tensor([1.0, 1.0, -1.0], device=DEV),
+        "scaled 1e-5": 1e-5 * a,
+        "scaled 1e+5": 1e5 * a,
     }
     tol = 1e-5 if dtype == torch.float32 else 1e-12
     for name, m in families.items():
