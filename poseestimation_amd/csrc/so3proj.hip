@@ -1140,10 +1140,14 @@ void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), grid, block, 0, s, op, nunits, nullptr);
 }
 
-// Rows [0, 64*nunits) go to the engine when every pointer is 16-byte aligned; the rest to the tile kernels.
+// Rows [0, 64*nunits) go to the engine when every pointer is dword aligned (every float32 array is; a bfloat16 view that
+// starts at an odd row is not); the rest to the tile kernels.  The engine's 16-byte buffer loads and stores need dword
+// alignment only: a view that starts at row 1 of a tensor (36 B in: 4 mod 16) streams like an aligned one -- round 1
+// sent such views, e.g. the shards of an uneven split, to the one-row-per-thread kernels.
+inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 inline int64_t stream_units(int64_t B, std::initializer_list<const void *> ptrs) {
     for (const void *p : ptrs)
-        if (p != nullptr && !aligned16(p)) return 0;
+        if (p != nullptr && !aligned4(p)) return 0;
     return B / so3::kUnitRows;
 }
 
