@@ -470,6 +470,10 @@ constexpr float kQuatTau = 1e-3f;       // first pass
 constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
 constexpr int kQuatExtra = 2;           // how many further refinements a row may take
 constexpr float kQuatConv = 4e-4f;
+#ifndef SO3_QUAT_RESID
+#define SO3_QUAT_RESID 8e-7f
+#endif
+constexpr float kQuatResid = SO3_QUAT_RESID;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
 #ifndef SO3_QUAT_CURV
 #define SO3_QUAT_CURV 0.5f
 #endif
@@ -509,8 +513,10 @@ template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T>
     q[0] = R::sel(mab, a0, e0); q[1] = R::sel(mab, a1, e1); q[2] = R::sel(mab, a2, e2); q[3] = R::sel(mab, a3, e3);
 }
 
-// Rayleigh quotient q^T K q / q^T q.
-template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4]) {
+// Rayleigh quotient lambda = q^T K q / q^T q, and the residual |K q - lambda q|^2 next to lambda^2 |q|^2.  With eps the share
+// of the neighbouring eigenvector in q, the residual is eps g2 |q|, and eps g2 / (2 lambda) is the error of R in the very measure
+// it is judged by (|dR| gap / s1): the residual over lambda bounds that error whatever the gap is.
+template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4], T &res2, T &ref2) {
     typedef Tr<T> R;
     const T kq0 = R::fma(k.a03, q[3], R::fma(k.a02, q[2], R::fma(k.a01, q[1], k.a00 * q[0])));
     const T kq1 = R::fma(k.a13, q[3], R::fma(k.a12, q[2], R::fma(k.a11, q[1], k.a01 * q[0])));
@@ -518,7 +524,15 @@ template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const
     const T kq3 = R::fma(k.a33, q[3], R::fma(k.a23, q[2], R::fma(k.a13, q[1], k.a03 * q[0])));
     const T num = R::fma(q[3], kq3, R::fma(q[2], kq2, R::fma(q[1], kq1, q[0] * kq0)));
     const T den = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    return num * R::rcp(den);
+    const T lam = num * R::rcp(den);
+    const T r0 = R::fma(-lam, q[0], kq0), r1 = R::fma(-lam, q[1], kq1), r2 = R::fma(-lam, q[2], kq2), r3 = R::fma(-lam, q[3], kq3);
+    res2 = R::fma(r3, r3, R::fma(r2, r2, R::fma(r1, r1, r0 * r0)));
+    ref2 = (lam * lam) * den;
+    return lam;
+}
+template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4]) {
+    T a, b;
+    return rayleigh<T>(k, q, a, b);
 }
 
 // A row is settled when (1) the product of the gaps -- the trace of the adjugate at the refined lambda, which is P'(lambda)
@@ -589,11 +603,23 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
             lam = R::fma(-p, R::rcp(dp), lam);
         }
     }
-    // 5. eigenvector, Rayleigh quotient, eigenvector
+    // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
+    // 3e-4 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
+    // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
+    // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round in ten), and only
+    // the rows that failed take it.
     T q[4], trace;
     dominant_column<T>(k, lam, q, trace);
-    T lam2 = rayleigh<T>(k, q);
-    dominant_column<T>(k, lam2, q, trace);
+    T res2, ref2;
+    T lam2 = rayleigh<T>(k, q, res2, ref2);
+    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
+    if (wave_any(R::any(R::mnot(accurate)))) {
+        T q2[4], trace2;
+        dominant_column<T>(k, lam2, q2, trace2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = R::sel(accurate, q[i], q2[i]);
+        trace = R::sel(accurate, trace, trace2);
+    }
     // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
     typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
     // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on

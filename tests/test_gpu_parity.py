@@ -41,6 +41,16 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a)).to(DEV, dtype)
 
 
+def conditioned_err(x, r, r_ref):
+    """(|dR| per row, |dR| * gap / s1 per row) for input rows x: gap = s2 + s3 without flip, s2 - s3 with flip -- the measure in
+    which a rotation can be judged independently of how well its row determines it (float32 round-off is ~1e-7 there)."""
+    m = np.asarray(x, np.float64).reshape(-1, 3, 3)
+    s = np.linalg.svd(m, compute_uv=False)
+    gap = np.where(np.linalg.det(m) < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / np.maximum(s[:, 0], 1e-300)
+    err = np.abs(np.asarray(r, np.float64).reshape(len(m), -1) - np.asarray(r_ref, np.float64).reshape(len(m), -1)).max(1)
+    return err, err * gap
+
+
 def cond_scaled_err(r, r_ref, s, det):
     s = np.asarray(s, np.float64)
     gap = np.where(np.asarray(det) < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2])
@@ -290,8 +300,8 @@ def test_config2_one_million_rows(rr, c_oracle):
     assert sc[1].item() == n and abs(sc[0].item() / n - mean) < 1e-9
     # row by row against the float64 C oracle
     ref = c_oracle.project(x.numpy())
-    err = np.abs(rc - ref).reshape(n, -1).max(1)
-    assert np.median(err) < 2e-7 and np.quantile(err, 0.999) < 3e-6
+    err, scaled = conditioned_err(x.numpy(), rc, ref)
+    assert np.median(err) < 2e-7 and np.quantile(err, 0.99) < 2e-6 and scaled.max() < 2e-6       # 1.2e-7, 9e-7, 8e-7 measured
     deg_or, _ = c_oracle.angle_error(rc, t.cpu().numpy())           # K4 against the oracle on identical inputs
     assert np.abs(deg.cpu().numpy() - deg_or).max() < 1e-9
 
@@ -971,7 +981,8 @@ def test_reentrant_from_two_host_threads(rr, c_oracle):
     [t.join() for t in th]
     for i in range(2):
         ref = c_oracle.project(xs[i].cpu().numpy())
-        assert np.quantile(np.abs(outs[i].cpu().numpy() - ref), 0.999) < 3e-6
+        err, scaled = conditioned_err(xs[i].cpu().numpy(), outs[i].cpu().numpy(), ref)
+        assert np.median(err) < 2e-7 and scaled.max() < 2e-6
 
 
 def test_config5_shard_size_sixteen_million_rows(rr):
@@ -1040,7 +1051,8 @@ def test_engine_dtype_paths_at_size(rr, c_oracle):
     xb = x.bfloat16()
     ref = c_oracle.project(xb.float().cpu().numpy())
     r = rr.symmetric_orthogonalization(xb)
-    assert np.quantile(np.abs(r.cpu().numpy() - ref), 0.999) < 3e-6
+    err, scaled = conditioned_err(xb.float().cpu().numpy(), r.cpu().numpy(), ref)
+    assert np.median(err) < 2e-7 and scaled.max() < 2e-6
     g = torch.randn(n, 3, 3, device=DEV, generator=gen)
     xg = xb.clone().requires_grad_(True)
     rr.symmetric_orthogonalization(xg).backward(g)
@@ -1077,8 +1089,13 @@ def test_g8_se3_update_forward_backward(rr):
     out = dev(g["out"]).requires_grad_(True)
     tp = rr.calculate_T_pred(out, dev(g["t_init"]), DEV)
     assert tuple(tp.shape) == (200, 4, 4)
-    assert np.abs(tp.detach().cpu().numpy() - g["t_pred"]).max() < 1e-5                       # vs the reference (float32)
-    assert np.abs(tp.detach().cpu().numpy() - so.se3_update_np(g["out"], g["t_init"])).max() < 5e-6
+    # the rotation block inherits the head's conditioning (s1 / gap of the 3x3 in out[:, :9]): judge the error scaled by it
+    m9 = g["out"][:, :9].astype(np.float64).reshape(-1, 3, 3)
+    sv = np.linalg.svd(m9, compute_uv=False)
+    gap = np.where(np.linalg.det(m9) < 0, sv[:, 1] - sv[:, 2], sv[:, 1] + sv[:, 2]) / sv[:, 0]
+    e32 = np.abs(tp.detach().cpu().numpy() - g["t_pred"]).reshape(200, -1).max(1)             # vs the reference (float32)
+    e64 = np.abs(tp.detach().cpu().numpy() - so.se3_update_np(g["out"], g["t_init"])).reshape(200, -1).max(1)
+    assert (e32 * gap).max() < 1e-5 and (e64 * gap).max() < 5e-6 and np.median(e64) < 1e-6
     tp.backward(dev(g["g"]))
     ref = so.se3_update_backward_np(g["out"], g["t_init"], g["g"])
     rel = np.abs(out.grad.cpu().numpy() - ref).max(1) / (1e-3 + np.abs(ref).max(1))
