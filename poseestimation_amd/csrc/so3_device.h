@@ -451,9 +451,9 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 //   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2)  by Laguerre's iteration from
 //      the upper bound sqrt(3)|M|_F (all roots real: monotone from above, cubic), closed by one Newton step;
 //   3. q = the largest column of adj(lambda I - K) = (product of the three gaps) q q^T -- no division, no pivoting;
-//   4. one refinement: lambda <- Rayleigh quotient of q (error squared), q again from the adjugate;
+//   4. lambda <- Rayleigh quotient of q (error squared); q again from the adjugate only where the residual |Kq - lambda q| asks;
 //   5. R(q) -- orthogonal by construction.
-// About 320 packed + 100 plain VALU instructions and 26 transcendentals per PAIR of matrices, against 390 / 135 / 45 for
+// About 256 packed + 129 plain VALU instructions and 24 transcendentals per PAIR of matrices, against 394 / 130 / 45 for
 // the three Jacobi sweeps and the frames above (tools/proto/qpath2.py is the numpy float32 prototype: 1M Gaussian rows
 // median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
 //
@@ -464,7 +464,10 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 // (c) anything is not finite.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
 // time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
 #ifndef SO3_QUAT_LAGUERRE
-#define SO3_QUAT_LAGUERRE 4          // Laguerre iterations (then one Newton step)
+#define SO3_QUAT_LAGUERRE 4          // Laguerre iterations
+#endif
+#ifndef SO3_QUAT_NEWTON
+#define SO3_QUAT_NEWTON 1            // Newton steps after them
 #endif
 constexpr float kQuatTau = 1e-3f;       // first pass
 constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
@@ -590,7 +593,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // 4. lambda_max: Laguerre from above, then Newton
     T lam = R::sqrt(f * R::splat(S(3)));
 #pragma unroll
-    for (int it = 0; it < SO3_QUAT_LAGUERRE + 1; ++it) {
+    for (int it = 0; it < SO3_QUAT_LAGUERRE + SO3_QUAT_NEWTON; ++it) {
         const T l2 = lam * lam;
         const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
@@ -604,9 +607,9 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
         }
     }
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
-    // 3e-4 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
+    // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
     // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
-    // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round in ten), and only
+    // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round of 128 rows in five), and only
     // the rows that failed take it.
     T q[4], trace;
     dominant_column<T>(k, lam, q, trace);

@@ -3,7 +3,7 @@
 import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import poseestimation_amd as pa
 from poseestimation_amd import rotation_representation as rr
 from oracle import c_oracle

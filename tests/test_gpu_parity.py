@@ -1120,7 +1120,7 @@ def test_g8_se3_update_forward_backward(rr):
 
 def test_orthogonality_holds_for_ill_conditioned_input(rr):
     """s = (1, 10^-k2, +-10^-k3), k2 in [0,7]: R stays a rotation to 1e-5 however badly M is conditioned
-    (the final Gram-Schmidt steps, not the sweeps, guarantee it); see tools/illcond_check.py."""
+    (the final Gram-Schmidt steps, not the sweeps, guarantee it); see tests/manual/illcond_check.py."""
     from oracle import so3_oracle as so
     rng = np.random.default_rng(0)
     n = 200_000
