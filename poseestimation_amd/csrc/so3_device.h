@@ -600,7 +600,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
         if (it < SO3_QUAT_LAGUERRE) {
             const T ddp = R::fma(R::splat(S(12)), l2, twoc2);
             const T h = R::fma(R::splat(S(9)) * dp, dp, (p * ddp) * R::splat(S(-12)));     // (n-1)((n-1)P'^2 - n P P''), n = 4
-            const T den = dp + R::sqrt(R::max(h, R::splat(S(0))));
+            const T den = dp + R::sqrt(R::abs(h));      // h >= 0 up to round-off; |h| is a free source modifier
             lam = R::fma(p * R::splat(S(-4)), R::rcp(den), lam);
         } else {
             lam = R::fma(-p, R::rcp(dp), lam);

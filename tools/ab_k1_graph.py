@@ -24,7 +24,7 @@ for path in sys.argv[1:]:
                 assert lib.so3_project_fwd_f32(P(x[i % NB].data_ptr()), P(r[i % NB].data_ptr()), None, n, st) == 0
     graphs[path.split("/")[-1]] = (g, lib)
 torch.cuda.synchronize()
-for rnd in range(4):
+for rnd in range(int(__import__("os").environ.get("AB_ROUNDS", "4"))):
     line = []
     for name, (g, _) in graphs.items():
         with torch.cuda.stream(side):
