@@ -322,9 +322,9 @@ def main():
                 step(i)
         e1.record(stream)
     torch.cuda.synchronize()
-    if dist is not None:
+    wall = time.perf_counter() - t0           # this rank's K steps; the job's time is the MAX over ranks (below), the ranks
+    if dist is not None:                      # having started together -- the closing barrier's own latency is not a step
         dist.barrier()
-    wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
     if dist is not None:
         tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
