@@ -267,8 +267,9 @@ def main():
             # load before its clock is up (tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
             # fixed number of warm-up steps would time the ramp, not the kernel.  The timed graph is replayed once (upload,
             # first touch); then a SHORT graph of the same launches (<= 25 steps, so the ramp is sampled every ~0.4 ms) is
-            # replayed until its time has stopped falling: the mean of the last 8 replays no longer beats the mean of the 8
-            # before it by 0.5 %, after at least 25 ms and at most 60 ms of load.  (`sustained` below is the same graph after
+            # replayed until its time has stopped falling: the mean of the last 32 replays (10 ms) no longer beats the mean of
+            # the 32 before it by 0.3 %, after at least 50 ms and at most 120 ms of load (the ramp is a staircase: one device
+            # sat on a 16.2-us step at 25 ms and reached 14.9 us by 50 ms, tools/k1_ramp_fine.py).  (`sustained` below is the same graph after
             # 0.6 s: devices differ in whether that is faster -- clock still rising -- or slower -- power limit reached.)
             with torch.cuda.stream(side):
                 graph.replay()
@@ -281,25 +282,26 @@ def main():
                         step(i)
             torch.cuda.synchronize()
             pre = {"replays": 0, "ms": 0.0, "us_per_step_first": None, "us_per_step_last": None,
-                   "policy": "a %d-step graph replayed until the mean of the last 8 replays no longer beats the mean of the 8 before "
-                             "by 0.5 percent (25-60 ms of load)" % nshort}
+                   "policy": "a %d-step graph replayed until the mean of the last 32 replays no longer beats the mean of the 32 before "
+                             "by 0.3 percent (50-120 ms of load)" % nshort}
             t_pre = time.perf_counter()
             hist = []
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
             while True:
-                with torch.cuda.stream(side):              # a graph replays on the CURRENT stream
-                    a.record(side)
-                    warm.replay()
-                    b.record(side)
+                with torch.cuda.stream(side):              # a graph replays on the CURRENT stream; eight replays per host
+                    marks[0].record(side)                  # synchronisation keep the device loaded (one sync per replay left
+                    for j in range(8):                     # it idle a tenth of the time)
+                        warm.replay()
+                        marks[j + 1].record(side)
                 torch.cuda.synchronize()
-                hist.append(a.elapsed_time(b))
+                hist.extend(marks[j].elapsed_time(marks[j + 1]) for j in range(8))
                 spent = time.perf_counter() - t_pre
-                flat = len(hist) >= 16 and sum(hist[-8:]) >= 0.995 * sum(hist[-16:-8])
-                if (flat and spent >= 0.025) or spent >= 0.060:
+                flat = len(hist) >= 64 and sum(hist[-32:]) >= 0.997 * sum(hist[-64:-32])
+                if (flat and spent >= 0.050) or spent >= 0.120:
                     break
             pre["replays"] = len(hist)
             pre["us_per_step_first"] = hist[0] * 1e3 / nshort
-            pre["us_per_step_last"] = sum(hist[-8:]) / len(hist[-8:]) * 1e3 / nshort
+            pre["us_per_step_last"] = sum(hist[-32:]) / len(hist[-32:]) * 1e3 / nshort
             pre["ms"] = (time.perf_counter() - t_pre) * 1e3
         except Exception as exc:               # submission mode only: the same kernels are then launched eagerly
             print(f"[bench] hipGraph capture failed ({exc!r}); falling back to eager launches", file=sys.stderr)
