@@ -36,7 +36,6 @@ ROWS_DEFAULT = 1_000_000
 NBUF = 8
 BYTES_PER_PROJECTION = 72          # 36 B read + 36 B written
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-K1_KERNEL = "so3::k_rows<so3::OpProject<4,false,100,true>,2,3,256,false,false,1>"     # as rocprofv3 --kernel-trace names it
 
 
 def parse():
@@ -244,6 +243,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    step(0)
+    k1_kernel = lib.so3_last_kernel().decode()      # the instantiation the timed steps launch, as rocprofv3 --kernel-trace names it
     # The K timed steps are K kernel launches either way; by default they are captured once into a hipGraph
     # (the C ABI is enqueue-only, hence capturable) and replayed, so the 16-us kernels are not at the mercy
     # of Python's per-launch jitter.  --eager launches each step from the interpreter instead.
@@ -379,7 +380,7 @@ def main():
                        "submission": "eager launches" if args.eager else "one hipGraph of K kernel launches, replayed"},
             "mean_angle_error_deg": mean_angle,
             "mean_angle_error_delta_vs_ref_deg": delta,
-            "roofline": {"bound": "hbm", "kernel": K1_KERNEL, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": k1_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("stored profile profiles/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                             "this workload, FETCH_SIZE doubled per the gfx950 caveat); not measured in this run") if traffic is not None else None,

@@ -43,6 +43,11 @@ int so3_version(void);
 /* Thread-local description of the last non-zero return on this thread ("" if none). */
 const char *so3_last_error(void);
 
+/* Name of the streaming-engine kernel this thread launched last, as a profiler prints it
+ * ("so3::k_rows<so3::OpProject<4, false, 100, true>, 2, 3, 256, false, false, 1>"; "" if none yet): the runtime's name
+ * of the kernel behind the launch, demangled, so a bench line or a log names the instantiation that actually ran. */
+const char *so3_last_kernel(void);
+
 /* ---- K1: symmetric orthogonalization -------------------------------------------------------------
  * R_b = U diag(1,1,det(U V^T)) V^T for M_b = U S V^T.
  * Replaces rotation_representation.py:192-206 (view -> torch.svd -> transpose -> matmul -> det ->

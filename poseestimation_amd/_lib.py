@@ -18,6 +18,7 @@ _P, _I64, _I32, _INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c
 SYMBOLS = {
     "so3_version": (_INT, []),
     "so3_last_error": (ctypes.c_char_p, []),
+    "so3_last_kernel": (ctypes.c_char_p, []),
     "so3_project_fwd_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_project_fwd_bf16": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_project_bwd_f32": (_INT, [_P, _P, _P, _I64, _P]),

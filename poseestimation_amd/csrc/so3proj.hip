@@ -6,6 +6,9 @@
 // contiguous tile of 256 rows (9216 B), move it with coalesced accesses through LDS, and each lane picks its
 // nine floats out of LDS at a 9-dword stride (odd stride -> conflict-free ds_read_b32 / ds_write_b32).
 #include <hip/hip_runtime.h>
+#include <cxxabi.h>
+#include <stdlib.h>
+#include <string>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1129,9 +1132,34 @@ inline int device_cus() {
 
 // Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads.
 // DYN: one workgroup per CU (BLOCK must be 64 * 4 * WPS), rounds claimed from a ticket counter; PF: rounds in flight.
+// The name of a k_rows instantiation as a profiler prints it: the runtime's own (mangled) name of the kernel behind the host
+// stub, demangled, without the "void " in front and the parameter list behind.
+thread_local const char *g_last_kernel = "";
+template <class Op, int NPL, int WPS, int BLOCK, bool DYN, int PF>
+const char *rows_kernel_name(hipStream_t s) {
+    static const std::string name = [s] {
+        const char *mangled = hipKernelNameRefByPtr(reinterpret_cast<const void *>(&so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), s);
+        if (mangled == nullptr) return std::string("so3::k_rows<?>");
+        int status = 0;
+        char *d = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+        std::string full = (status == 0 && d != nullptr) ? d : mangled;
+        free(d);
+        if (full.rfind("void ", 0) == 0) full.erase(0, 5);
+        int depth = 0;                                         // cut at the '(' that opens the parameter list
+        for (size_t i = 0; i < full.size(); ++i) {
+            if (full[i] == '<') ++depth;
+            else if (full[i] == '>') --depth;
+            else if (full[i] == '(' && depth == 0) { full.erase(i); break; }
+        }
+        return full;
+    }();
+    return name.c_str();
+}
+
 template <int NPL, int WPS, int BLOCK, bool DYN = false, int PF = 1, class Op>
 void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     constexpr int kWaves = BLOCK / 64;
+    g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK, DYN, PF>(s);
     static_assert(!DYN || BLOCK == 64 * 4 * WPS, "a ticketed workgroup fills its CU");
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     const int64_t want = DYN ? rounds : (rounds + kWaves - 1) / kWaves;
@@ -1313,6 +1341,7 @@ extern "C" {
 
 int so3_version(void) { return SO3PROJ_VERSION; }
 const char *so3_last_error(void) { return g_err; }
+const char *so3_last_kernel(void) { return g_last_kernel; }
 
 int so3_project_fwd_f32(const float *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     return project_fwd<false>(M, R, flip, B, stream);

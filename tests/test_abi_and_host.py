@@ -61,6 +61,20 @@ def test_c_demo_runs_on_the_gpu(built_library, tmp_path):
         assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
 
 
+@pytest.mark.gpu
+def test_last_kernel_names_the_instantiation_that_ran(built_library):
+    """so3_last_kernel(): the streaming kernel's name as a profiler prints it, formed from the launch's template arguments."""
+    from poseestimation_amd import _lib, rotation_representation as rr
+    lib = _lib.load()
+    x = torch.randn(4096, 9, device="cuda:0")
+    rr.symmetric_orthogonalization(x)
+    assert lib.so3_last_kernel() == b"so3::k_rows<so3::OpProject<4, false, 100, true>, 2, 3, 256, false, false, 1>"
+    rr.symmetric_orthogonalization(x.bfloat16())
+    assert lib.so3_last_kernel().startswith(b"so3::k_rows<so3::OpProject<2, false,")
+    rr.angle_error(rr.symmetric_orthogonalization(x), rr.symmetric_orthogonalization(x.flip(0)))
+    assert lib.so3_last_kernel().startswith(b"so3::k_rows<so3::OpAngle<")
+
+
 def test_argument_validation_without_gpu(built_library):
     """Bad arguments are rejected on the host before any launch (no GPU needed)."""
     from poseestimation_amd import _lib
