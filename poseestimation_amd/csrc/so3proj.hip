@@ -1287,7 +1287,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     const int64_t nunits = stream_units(B, {M, Rtrue, R, dM});
     if (nunits > 0) {
 #define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
-                             op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<2, 2, 512>(op, nunits, s); } while (0)
+                             op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
         if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
@@ -1434,7 +1434,7 @@ int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, do
     const int64_t nunits = stream_units(B, {M, Rtrue, R, deg});
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
-                                 op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; launch_rows<2, 2, 512>(op, nunits, s); } while (0)
+                                 op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true); else if (deg) SLAUNCH(WR, true, false); else if (sum_count) SLAUNCH(WR, false, true); else SLAUNCH(WR, false, false); } while (0)
         if (R) PICKR(true); else PICKR(false);
 #undef PICKR
