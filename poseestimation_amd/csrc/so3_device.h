@@ -49,6 +49,7 @@ using std::min;
 inline float rsq(float x) { return 1.0f / std::sqrt(x); }
 inline float sqrt(float x) { return std::sqrt(x); }
 inline float rcp(float x) { return 1.0f / x; }
+inline float cos_rev(float x) { return std::cos(6.28318530717958647692f * x); }
 inline int frexp_exp(float x) { int e = 0; if (x != 0.0f && std::isfinite(x)) std::frexp(x, &e); return e; }
 inline int frexp_exp(double x) { int e = 0; if (x != 0.0 && std::isfinite(x)) std::frexp(x, &e); return e; }
 inline bool any_lane(bool p) { return p; }
@@ -56,6 +57,7 @@ inline bool any_lane(bool p) { return p; }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }       // v_rsq_f32, 1 ulp
 __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }     // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf(x); }   // v_cos_f32: cos(2 pi x), |x| <= 256
 __device__ __forceinline__ int frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }   // 0 for 0, inf and NaN
 __device__ __forceinline__ int frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
@@ -109,6 +111,8 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ float fma(float a, float b, float c) { return fmaf(a, b, c); }
     static __device__ __forceinline__ float abs(float a) { return fabsf(a); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ float cos_rev(float x) { return hw::cos_rev(x); }          // cos(2 pi x), hardware accuracy
     static __device__ __forceinline__ float copysign(float a, float b) { return copysignf(a, b); }
     static __device__ __forceinline__ float rsq(float x) { return hw::rsq(x); }
     static __device__ __forceinline__ float sqrt(float x) { return hw::sqrt(x); }
@@ -138,6 +142,8 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ f32x2 fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
     static __device__ __forceinline__ f32x2 abs(f32x2 a) { return __builtin_elementwise_abs(a); }
     static __device__ __forceinline__ f32x2 max(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+    static __device__ __forceinline__ f32x2 vmin(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+    static __device__ __forceinline__ f32x2 cos_rev(f32x2 x) { return f32x2{hw::cos_rev(x.x), hw::cos_rev(x.y)}; }
     static __device__ __forceinline__ f32x2 copysign(f32x2 a, f32x2 b) { return f32x2{copysignf(a.x, b.x), copysignf(a.y, b.y)}; }
     static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{hw::rsq(x.x), hw::rsq(x.y)}; }
     static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return f32x2{hw::sqrt(x.x), hw::sqrt(x.y)}; }
@@ -176,6 +182,8 @@ template <> struct Tr<double> {           // one matrix per lane in float64 (so3
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double abs(double a) { return __builtin_fabs(a); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double cos_rev(double x) { return ::cos(6.28318530717958647692 * x); }
     static __device__ __forceinline__ double copysign(double a, double b) { return __builtin_copysign(a, b); }
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }          // correctly rounded
     static __device__ __forceinline__ double rsq(double x) { return 1.0 / __builtin_sqrt(x); }
@@ -448,23 +456,28 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 // whose eigenvalues are s1+s2+s3', s1-s2-s3', -s1+s2-s3', -s1-s2+s3' (s3' = det-signed): the gap between the two largest,
 // 2(s2+s3'), is the conditioning of R itself.  Per matrix:
 //   1. (no prescale: the method is homogeneous in M; rows far from unit scale are hard);
-//   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2)  by Laguerre's iteration from
-//      the upper bound sqrt(3)|M|_F (all roots real: monotone from above, cubic), closed by one Newton step;
+//   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2):  started at s1 + s2 + s3' with the
+//      singular values from the closed-form roots of the cubic of M^T M (good to 5e-6 on the median row), then two Newton steps;
 //   3. q = the largest column of adj(lambda I - K) = (product of the three gaps) q q^T -- no division, no pivoting;
 //   4. lambda <- Rayleigh quotient of q (error squared); q again from the adjugate only where the residual |Kq - lambda q| asks;
 //   5. R(q) -- orthogonal by construction.
-// About 256 packed + 129 plain VALU instructions and 24 transcendentals per PAIR of matrices, against 394 / 130 / 45 for
+// About 230 packed + 130 plain VALU instructions and 30 transcendentals per PAIR of matrices, against 394 / 130 / 45 for
 // the three Jacobi sweeps and the frames above (tools/proto/qpath2.py is the numpy float32 prototype: 1M Gaussian rows
 // median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
 //
 // What the fast path cannot do it says so: a row is HARD when (a) the product of the three gaps, tr adj(lambda I - K), is
 // below kQuatTau lambda^3 (ill-conditioned, rank-deficient, ties: everything where the reference's answer is a matter of
 // LAPACK's ordering), or (b) the Rayleigh quotient moved lambda by more than kQuatConv times a lower bound of the gap
-// (Laguerre had not converged; the quotient is <= lambda_max <= the Laguerre iterate, so the move bounds BOTH errors), or
-// (c) anything is not finite.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
+// (the root finder had not converged: the move from the shift to the quotient bounds the error of both), or
+// (c) anything is not finite.  (b) is scaled by the larger of the two values: the first build's Laguerre iterate could only
+// be a little above the root, a Newton iterate thrown off near a critical point can be far above the whole spectrum, where
+// the adjugate is huge and looks healthy.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
 // time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
 #ifndef SO3_QUAT_LAGUERRE
 #define SO3_QUAT_LAGUERRE 4          // Laguerre iterations
+#endif
+#ifndef SO3_QUAT_TRIG
+#define SO3_QUAT_TRIG 1              // 1: closed-form start + two Newton steps; 0: Laguerre from the upper bound (the first build)
 #endif
 #ifndef SO3_QUAT_NEWTON
 #define SO3_QUAT_NEWTON 1            // Newton steps after them
@@ -516,9 +529,11 @@ template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T>
     q[0] = R::sel(mab, a0, e0); q[1] = R::sel(mab, a1, e1); q[2] = R::sel(mab, a2, e2); q[3] = R::sel(mab, a3, e3);
 }
 
-// Rayleigh quotient lambda = q^T K q / q^T q, and the residual |K q - lambda q|^2 next to lambda^2 |q|^2.  With eps the share
-// of the neighbouring eigenvector in q, the residual is eps g2 |q|, and eps g2 / (2 lambda) is the error of R in the very measure
-// it is judged by (|dR| gap / s1): the residual over lambda bounds that error whatever the gap is.
+// Rayleigh quotient lambda = q^T K q / q^T q, and the squared residual |K q - lambda q|^2 / |q|^2 next to lambda^2.  With eps the
+// share of the neighbouring eigenvector in q, the residual is eps g2 |q|, and eps g2 / (2 lambda) is the error of R in the very
+// measure it is judged by (|dR| gap / s1): the residual over lambda bounds that error whatever the gap is.  (Divided by |q|^2
+// before it is compared: q is a column of the adjugate, |q|^2 ~ lambda^6, and lambda^2 |q|^2 leaves the float32 range for
+// entries above 2e4 -- where an infinite reference would call every row accurate.)
 template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4], T &res2, T &ref2) {
     typedef Tr<T> R;
     const T kq0 = R::fma(k.a03, q[3], R::fma(k.a02, q[2], R::fma(k.a01, q[1], k.a00 * q[0])));
@@ -527,10 +542,11 @@ template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const
     const T kq3 = R::fma(k.a33, q[3], R::fma(k.a23, q[2], R::fma(k.a13, q[1], k.a03 * q[0])));
     const T num = R::fma(q[3], kq3, R::fma(q[2], kq2, R::fma(q[1], kq1, q[0] * kq0)));
     const T den = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    const T lam = num * R::rcp(den);
+    const T inv = R::rcp(den);
+    const T lam = num * inv;
     const T r0 = R::fma(-lam, q[0], kq0), r1 = R::fma(-lam, q[1], kq1), r2 = R::fma(-lam, q[2], kq2), r3 = R::fma(-lam, q[3], kq3);
-    res2 = R::fma(r3, r3, R::fma(r2, r2, R::fma(r1, r1, r0 * r0)));
-    ref2 = (lam * lam) * den;
+    res2 = R::fma(r3, r3, R::fma(r2, r2, R::fma(r1, r1, r0 * r0))) * inv;
+    ref2 = lam * lam;
     return lam;
 }
 template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4]) {
@@ -554,7 +570,9 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
     typedef typename R::scalar S;
     const T l2 = lam_after * lam_after;
     const typename R::mask separated = R::gt(trace, (l2 * lam_after) * tau);
-    const typename R::mask converged = R::le(R::abs(lam_before - lam_after) * (l2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
+    // the scale of (2) is the LARGER of the two: a shift far above the spectrum has a huge, healthy-looking adjugate
+    const T lmax2 = R::max(l2, lam_before * lam_before);
+    const typename R::mask converged = R::le(R::abs(lam_before - lam_after) * (lmax2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
     const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
     return separated & converged & topmost;
 }
@@ -590,7 +608,47 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     cf = R::fma(g12, g12, cf); cf = R::fma(g20, g20, cf); cf = R::fma(g21, g21, cf); cf = R::fma(g22, g22, cf);
     const T c2 = f * R::splat(S(-2)), c1 = det * R::splat(S(-8)), c0 = R::fma(f, f, cf * R::splat(S(-4)));
     const T twoc2 = c2 + c2;
-    // 4. lambda_max: Laguerre from above, then Newton
+    // 4. lambda_max = s1 + s2 + s3'.  Start: the squared singular values are the roots of  mu^3 - f mu^2 + cf mu - det^2,
+    // in closed form  mu_k = f/3 + 2 sqrt(p) cos(theta/3 + 2 pi k/3),  p = (f^2 - 3 cf)/9,  cos(theta) = q / p^(3/2),
+    // q = (2 f^3 - 9 f cf + 27 det^2)/54 -- with a four-term acos (7e-5), the hardware cosine and mu2 from the trace this
+    // lands within 5e-6 of lambda_max on the median Gaussian row (p99 3e-4, worst 8e-3: small singular values come out
+    // of a cancellation, but they weigh little in the sum).  Two Newton steps on the quartic finish it; the start is
+    // raised by 1e-3 so that they come from above.  (Laguerre from the bound sqrt(3)|M|_F needed four steps and a Newton
+    // step for the same roots: 68 packed instructions and 20 transcendentals against 40 and 26.)
+#if SO3_QUAT_TRIG
+    T lam;
+    {
+        // in units of f (mu / f in [0, 1]): no power of the entries beyond f^2 is formed
+        const T inv_f = R::rcp(f);
+        const T di = det * inv_f;
+        const T cfn = (cf * inv_f) * inv_f, dn = (di * di) * inv_f;                               // cf / f^2,  det^2 / f^3
+        const T p = R::max(R::fma(cfn, R::splat(S(-1.0 / 3.0)), R::splat(S(1.0 / 9.0))), R::splat(S(1e-12)));
+        const T q = R::fma(dn, R::splat(S(0.5)), R::fma(cfn, R::splat(S(-1.0 / 6.0)), R::splat(S(1.0 / 27.0))));
+        const T x = R::max(R::vmin(q * R::rsq((p * p) * p), R::splat(S(1))), R::splat(S(-1)));
+        const T ax = R::abs(x);
+        T poly = R::fma(ax, R::splat(S(-0.0187293)), R::splat(S(0.0742610)));
+        poly = R::fma(poly, ax, R::splat(S(-0.2121144)));
+        poly = R::fma(poly, ax, R::splat(S(1.5707288)));
+        const T acos_abs = R::sqrt(R::splat(S(1)) - ax) * poly;                                 // acos(|x|), radians
+        // theta / 3 in revolutions: acos(x) = pi - acos(|x|) for x < 0
+        const T third_rev = R::splat(S(1.0 / (6.0 * 3.14159265358979323846)));
+        const T th = R::sel(R::ge(x, R::splat(S(0))), acos_abs * third_rev, R::fma(acos_abs, -third_rev, R::splat(S(1.0 / 6.0))));
+        const T two_sp = R::sqrt(p) * R::splat(S(2)), third = R::splat(S(1.0 / 3.0));
+        const T mu1 = R::fma(two_sp, R::cos_rev(th), third);
+        const T mu3 = R::fma(two_sp, R::cos_rev(th + third), third);
+        const T mu2 = (R::splat(S(1)) - mu1) - mu3;
+        const T s3 = R::copysign(R::sqrt(R::abs(mu3)), det);
+        lam = ((R::sqrt(R::abs(mu1)) + R::sqrt(R::abs(mu2))) + s3) * (R::sqrt(f) * R::splat(S(1.001)));
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const T l2 = lam * lam;
+        const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
+        const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
+        lam = R::fma(-p, R::rcp(dp), lam);
+    }
+#else
+    // Laguerre from above, then Newton
     T lam = R::sqrt(f * R::splat(S(3)));
 #pragma unroll
     for (int it = 0; it < SO3_QUAT_LAGUERRE + SO3_QUAT_NEWTON; ++it) {
@@ -606,6 +664,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
             lam = R::fma(-p, R::rcp(dp), lam);
         }
     }
+#endif
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
     // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
     // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
@@ -616,28 +675,30 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     T res2, ref2;
     T lam2 = rayleigh<T>(k, q, res2, ref2);
     const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
+    T shift = lam;                               // the shift the current q was computed at
     if (wave_any(R::any(R::mnot(accurate)))) {
         T q2[4], trace2;
         dominant_column<T>(k, lam2, q2, trace2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = R::sel(accurate, q[i], q2[i]);
         trace = R::sel(accurate, trace, trace2);
+        shift = R::sel(accurate, lam, lam2);
     }
     // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
     typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
     // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
     // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
-    // Laguerre iteration was still on its way and rows with a gap down to ~3e-4 of lambda.  What is left (rank-deficient,
-    // ties, gaps at round-off) is hard.
+    // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
+    // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
 #pragma unroll 1
     for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(settled))); ++extra) {
         T q3[4], trace3;
         const T lam3 = rayleigh<T>(k, q);
         dominant_column<T>(k, lam3, q3, trace3);
-        const typename R::mask settled3 = quat_settled<T>(lam2, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+        const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = R::sel(settled, q[i], q3[i]);
-        lam2 = R::sel(settled, lam2, lam3);
+        shift = R::sel(settled, shift, lam3);
         settled = settled | settled3;
     }
     // 7. R(q), q = (w, x, y, z) unnormalised
