@@ -81,6 +81,10 @@ def test_model_on_adversarial_families(km, dtype):
         ok = gap > 1e-6
         if ok.any():
             assert (np.abs(r - ref).reshape(n, -1).max(1) * gap)[ok].max() < tol_cond, name
+            if dtype == "f32" and name == "scaled 3e+04":
+                # entries of 3e4 are inside the fast path's window, but lambda^2 |q|^2 ~ lambda^8 is not inside float32: the residual
+                # test once compared against an infinite reference there and kept every first eigenvector, converged or not
+                assert (np.abs(r - ref).reshape(n, -1).max(1) * gap)[ok].max() < 2e-6, name
         # optimality (defined even where R is not unique): tr(R^T M) = s1 + s2 +- s3
         best = s[:, 0] + s[:, 1] + np.where(np.linalg.det(m32.astype(np.float64)) < 0, -s[:, 2], s[:, 2])
         got = (r * m32.astype(np.float64)).sum((1, 2))
