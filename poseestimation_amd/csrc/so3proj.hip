@@ -352,6 +352,64 @@ __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict_
     }
 }
 
+// Batches of up to kSmallBatch rows (the per-batch metric of a training loop, 3D-Pose/main.py:60-62: B = 512) are
+// launch-latency-bound, and the accumulators' initialisation was a launch of its own.  One workgroup, one row per thread:
+// the kernel writes (sum, count) and the range flag with plain stores -- one launch, no atomics.  PROJECT: the first
+// operand is the head's input M and the angle is taken of its projection (the fused evaluation step).
+template <bool PROJECT, bool WANT_R, bool WANT_DEG>
+__global__ __launch_bounds__(kSmallBatch) void k_angle_small(const float *__restrict__ A, const float *__restrict__ Bm,
+                                                             float *__restrict__ R, double *__restrict__ deg,
+                                                             double *__restrict__ sum_count, int32_t *__restrict__ range_flag,
+                                                             double unit, int B) {
+    __shared__ double red[kSmallBatch / 64];
+    __shared__ int red_bad[kSmallBatch / 64];
+    const int b = threadIdx.x;
+    const bool active = b < B;
+    float a[9], t[9], r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        a[i] = (i & 3) == 0 ? 1.f : 0.f;              // idle lanes: identity
+        t[i] = a[i];
+    }
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            a[i] = A[b * 9 + i];
+            t[i] = Bm[b * 9 + i];
+        }
+    }
+    if (PROJECT) {
+        so3::project_rotation<float>(a, r);
+        if (WANT_R && active) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[b * 9 + i] = r[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) r[i] = a[i];
+    }
+    double tr = 0.0;                                   // the arithmetic of OpAngle / k_angle_error, operation for operation
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(r[i]), static_cast<double>(t[i]), tr);
+    const double c_raw = (tr - 1.0) * 0.5;
+    const bool bad = active && (c_raw < -1.1 || c_raw > 1.1);
+    double c = fmin(fmax(c_raw, -1.0), 1.0);
+    if (c_raw != c_raw) c = c_raw;
+    const double ang = so3::acos_f64(c) * unit;
+    if (WANT_DEG && active) deg[b] = ang;
+    const double v = wave_sum(active ? ang : 0.0);
+    const bool any_bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; red_bad[threadIdx.x >> 6] = any_bad ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        int flag = 0;
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) { total += red[w]; flag |= red_bad[w]; }
+        if (sum_count) { sum_count[0] = total; sum_count[1] = static_cast<double>(B); }
+        if (range_flag) *range_flag = flag;
+    }
+}
+
 __global__ void k_angle_init(double *sum_count, int32_t *range_flag, double count) {
     if (sum_count) { sum_count[0] = 0.0; sum_count[1] = count; }
     if (range_flag) *range_flag = 0;
@@ -1394,11 +1452,18 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
                     int radians, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
+    if (B > 0 && B <= kSmallBatch && (sum_count || range_flag)) {       // one workgroup: the accumulators need no launch of their own
+        SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
+        const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
+        if (deg) hipLaunchKernelGGL((k_angle_small<false, false, true>), grid, block, 0, s, R1, R2, nullptr, deg, sum_count, range_flag, unit, static_cast<int>(B));
+        else hipLaunchKernelGGL((k_angle_small<false, false, false>), grid, block, 0, s, R1, R2, nullptr, deg, sum_count, range_flag, unit, static_cast<int>(B));
+        return check_launch("so3_angle_error");
+    }
     // one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
     if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_angle_error");
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
-    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
     const int64_t nunits = stream_units(B, {R1, R2, deg});
     if (nunits > 0) {
         // 1024-thread workgroups: one same-address float64 atomic per workgroup costs ~9 ns at the end of the kernel;
@@ -1427,10 +1492,18 @@ int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, do
                                 int radians, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_angle_error_f32: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
+    if (B > 0 && B <= kSmallBatch && (sum_count || range_flag)) {       // one workgroup, one launch
+        SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_project_angle_error_f32: null pointer");
+        const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
+#define SMALL(WR, WD) hipLaunchKernelGGL((k_angle_small<true, WR, WD>), grid, block, 0, s, M, Rtrue, R, deg, sum_count, range_flag, unit, static_cast<int>(B))
+        if (R && deg) SMALL(true, true); else if (R) SMALL(true, false); else if (deg) SMALL(false, true); else SMALL(false, false);
+#undef SMALL
+        return check_launch("so3_project_angle_error_f32");
+    }
     if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_project_angle_error_f32");
     SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_project_angle_error_f32: null pointer");
-    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
     const int64_t nunits = stream_units(B, {M, Rtrue, R, deg});
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \

@@ -1235,3 +1235,33 @@ def test_comparison_experiment_trains_identically(rr, pa, key):
         first = loss_ref.item() if first is None else first
         last = loss_ref.item()
     assert last < first                                       # and it does train
+
+
+# ------------------------------------------------------------------------------------------------
+# launch-bound batches of the metric (B <= 1024): one launch, the kernel writes (sum, count) and the flag itself
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b", [1, 63, 64, 65, 512, 1000, 1024, 1025])
+def test_small_batch_metric_is_one_launch_with_the_same_angles(rr, b):
+    gen = torch.Generator(device=DEV).manual_seed(700 + b)
+    big = 4096                                                  # the same rows inside a batch that takes the streaming path
+    x = torch.randn(big, 9, device=DEV, generator=gen)
+    t = rr.symmetric_orthogonalization(torch.randn(big, 9, device=DEV, generator=gen))
+    r = rr.symmetric_orthogonalization(x)
+    ref_deg = rr.angle_error(r, t)
+    deg = rr.angle_error(r[:b], t[:b])
+    assert torch.equal(deg, ref_deg[:b])                        # per-row angles: the same operations in the same order
+    sc = rr.angle_error_sum_count(r[:b], t[:b])
+    assert sc[1].item() == b and abs(sc[0].item() - ref_deg[:b].sum().item()) < 1e-9 * max(b, 1)
+    fused = rr.head_angle_error(x[:b], t[:b])
+    assert (fused - ref_deg[:b]).abs().max().item() < 1e-9
+    fsc = rr.head_angle_error(x[:b], t[:b], reduce="sum_count")
+    assert fsc[1].item() == b and abs(fsc[0].item() - ref_deg[:b].sum().item()) < 1e-8 * max(b, 1)
+    d2, r2 = rr.head_angle_error(x[:b], t[:b], return_rotation=True)
+    assert torch.equal(r2, r[:b]) and (d2 - ref_deg[:b]).abs().max().item() < 1e-9
+    with pytest.raises(ValueError, match="angle out of range"):
+        rr.angle_error(r[:b], 3.0 * r[:b])                      # tr = 9, cosine 4: out of range whatever the rows are
+    with pytest.raises(ValueError, match="angle out of range"):
+        rr.head_angle_error(x[:b], 3.0 * r[:b], reduce="mean")
+    bad = t[:b].clone()
+    bad[b // 2] *= float("nan")                                 # NaN is not "out of range" (torch.any of a false comparison)
+    assert torch.isnan(rr.angle_error(r[:b], bad)[b // 2])
