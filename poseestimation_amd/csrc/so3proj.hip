@@ -315,6 +315,38 @@ __global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ 
     if (threadIdx.x == 0) atomicAdd(loss_sum, total);
 }
 
+// K3' for a launch-bound batch (B <= kSmallBatch): one workgroup, one row per thread, loss_sum written with a plain
+// store -- no zero-fill before the kernel.  Row arithmetic as in k_frob_loss / OpFrobLoss.
+template <bool WANT_GRAD>
+__global__ __launch_bounds__(kSmallBatch) void k_frob_loss_small(const float *__restrict__ Rpred, const float *__restrict__ Rtrue,
+                                                                 float *__restrict__ dRpred, double *__restrict__ loss_sum,
+                                                                 int B, float inv_b) {
+    __shared__ double red[kSmallBatch / 64];
+    const int b = threadIdx.x;
+    const bool active = b < B;
+    float g[9];
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        g[i] = active ? Rpred[b * 9 + i] - Rtrue[b * 9 + i] : 0.f;
+        n2 = fmaf(g[i], g[i], n2);
+    }
+    const float nrm = n2 * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-37f));
+    if (WANT_GRAD && active) {
+        const float gs = (n2 > 0.f) ? inv_b * __builtin_amdgcn_rsqf(n2) : 0.f;     // zero difference -> zero gradient
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dRpred[b * 9 + i] = g[i] * gs;
+    }
+    const double v = wave_sum(active ? static_cast<double>(nrm) : 0.0);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
+        *loss_sum = total;
+    }
+}
+
 // ---- K4 -------------------------------------------------------------------------------------------
 template <bool VEC, bool WANT_DEG, bool WANT_SUM>
 __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict__ R1, const float *__restrict__ R2,
@@ -1424,6 +1456,14 @@ int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, dou
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f32: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f32: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (B > 0 && B <= kSmallBatch) {                     // one workgroup, one launch: the kernel writes loss_sum itself
+        SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
+        const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
+        const float inv = 1.0f / static_cast<float>(B);
+        if (dRpred) hipLaunchKernelGGL((k_frob_loss_small<true>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, static_cast<int>(B), inv);
+        else hipLaunchKernelGGL((k_frob_loss_small<false>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, static_cast<int>(B), inv);
+        return check_launch("so3_frob_loss_f32");
+    }
     hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
     if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
     if (B == 0) return 0;

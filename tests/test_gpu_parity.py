@@ -1265,3 +1265,23 @@ def test_small_batch_metric_is_one_launch_with_the_same_angles(rr, b):
     bad = t[:b].clone()
     bad[b // 2] *= float("nan")                                 # NaN is not "out of range" (torch.any of a false comparison)
     assert torch.isnan(rr.angle_error(r[:b], bad)[b // 2])
+
+
+@pytest.mark.parametrize("b", [1, 64, 65, 512, 1024, 1025])
+def test_small_batch_stand_alone_loss_is_one_launch_with_the_same_rows(rr, b):
+    gen = torch.Generator(device=DEV).manual_seed(900 + b)
+    big = 4096
+    p_all = rr.symmetric_orthogonalization(torch.randn(big, 9, device=DEV, generator=gen))
+    t_all = rr.symmetric_orthogonalization(torch.randn(big, 9, device=DEV, generator=gen))
+    pb = p_all.detach().clone().requires_grad_(True)
+    rr.loss_frobenius(pb, t_all).backward()                    # streaming path: per-row gradients scaled by 1 / big
+    ps = p_all[:b].detach().clone().requires_grad_(True)
+    loss = rr.loss_frobenius(ps, t_all[:b])
+    loss.backward()
+    ref = torch.linalg.matrix_norm((t_all[:b] - p_all[:b]).double()).mean().item()
+    assert abs(loss.item() - ref) < 2e-6 * max(ref, 1.0)
+    assert torch.allclose(ps.grad * b, pb.grad[:b] * big, rtol=2e-6, atol=1e-7)   # same row arithmetic, another 1/B
+    same = p_all[:b].detach().clone().requires_grad_(True)     # zero difference: zero loss, zero gradient, no NaN
+    z = rr.loss_frobenius(same, p_all[:b].detach())
+    z.backward()
+    assert z.item() == 0.0 and float(same.grad.abs().max()) == 0.0

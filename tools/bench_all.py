@@ -113,6 +113,8 @@ def main():
     x4 = torch.randn(b, 9, device=dev).bfloat16(); r4 = torch.empty(b, 9, device=dev); d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
     t4 = rr.symmetric_orthogonalization(torch.randn(b, 9, device=dev))
     timeit("K3 so3_frob_fwd_bwd_bf16 (B=512)", lambda i: lib.so3_frob_fwd_bwd_bf16(p(x4), p(t4), p(r4), p(d4), p(ls), b, st), b * (18 + 36 + 36 + 18), iters=300)
+    g4 = torch.empty(b, 9, device=dev)
+    timeit("K3' so3_frob_loss_f32 (B=512, loss + dRpred: one launch)", lambda i: lib.so3_frob_loss_f32(p(r4), p(t4), p(g4), p(ls), b, st), b * 108, iters=300)
     x4f = x4.float(); sc4 = torch.empty(2, dtype=torch.float64, device=dev); fl4 = torch.zeros(1, dtype=torch.int32, device=dev)
     timeit("K4 so3_angle_error (B=512, sum,count + flag: one launch)", lambda i: lib.so3_angle_error(p(r4), p(t4), None, p(sc4), p(fl4), 0, b, st), b * 72, iters=300)
     timeit("K1+K4 so3_project_angle_error_f32 (B=512, sum,count + flag)", lambda i: lib.so3_project_angle_error_f32(p(x4f), p(t4), None, None, p(sc4), p(fl4), 0, b, st), b * 72, iters=300)
