@@ -925,7 +925,8 @@ def test_iterative_step_head_update_loss_backward(rr):
 # ------------------------------------------------------------------------------------------------
 # next row f3: per-class evaluation statistics (3D-Pose/test_per_class.py:174-216)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,ncls", [(1, 1), (2, 1), (1000, 1), (1001, 3), (250_000, 10), (1_000_000, 10)])
+@pytest.mark.parametrize("n,ncls", [(1, 1), (2, 1), (1000, 1), (1001, 3), (250_000, 10), (1_000_000, 10),
+                                    (100_001, 16), (100_001, 17), (300_000, 40), (300_000, 64)])   # > 16 classes: the 128-KB histograms
 def test_angle_error_statistics_match_numpy(rr, n, ncls):
     from oracle import so3_oracle as so
     rng = np.random.default_rng(n + ncls)
