@@ -545,7 +545,9 @@ template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const
     const T inv = R::rcp(den);
     const T lam = num * inv;
     const T r0 = R::fma(-lam, q[0], kq0), r1 = R::fma(-lam, q[1], kq1), r2 = R::fma(-lam, q[2], kq2), r3 = R::fma(-lam, q[3], kq3);
-    res2 = R::fma(r3, r3, R::fma(r2, r2, R::fma(r1, r1, r0 * r0))) * inv;
+    // (r inv) r, not (r r) inv: a converged row's residual is ~1e-6 lambda |q| ~ 1e-6 lambda^4, whose square underflows for entries
+    // below 1e-4 -- and a zero residual called every such row accurate
+    res2 = R::fma(r3 * inv, r3, R::fma(r2 * inv, r2, R::fma(r1 * inv, r1, (r0 * inv) * r0)));
     ref2 = lam * lam;
     return lam;
 }

@@ -219,3 +219,19 @@ def test_model_property_any_finite_float32_matrix_gives_the_optimal_rotation(km)
             assert (best - (r * mm).sum()) / s[0] < 5e-6
 
     prop()
+
+
+@pytest.mark.parametrize("scale", [2e-5, 5e-5, 1e-4, 1.0, 3e4, 8e4])
+def test_fast_path_accuracy_does_not_depend_on_the_scale_inside_its_window(km, scale):
+    """The fast path takes rows with |M|_F^2 in [2^-28, 2^36] as they come.  Its residual test once squared a residual that
+    underflows for entries below 1e-4 (zero: every row 'accurate') and compared against lambda^2 |q|^2, which overflows above
+    2e4 (infinite: the same) -- rows that needed the second eigenvector kept the first, 3e-6 to 8e-6 instead of 9e-7."""
+    rng = np.random.default_rng(5)
+    m = (rng.standard_normal((200_000, 9)) * scale).astype(np.float32)
+    r, hard = km.project_quat(m)
+    ref, s, d = so.symmetric_orthogonalization_np(m, return_parts=True)
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0]
+    err = np.abs(np.asarray(r, np.float64).reshape(-1, 9) - ref.reshape(-1, 9)).max(1) * gap
+    ok = ~hard.astype(bool) & (gap > 1e-6)
+    assert ok.mean() > 0.3                                       # the window's edges send more rows to the Jacobi path
+    assert err[ok].max() < 1.2e-6
