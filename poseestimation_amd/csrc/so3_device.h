@@ -473,15 +473,6 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 // be a little above the root, a Newton iterate thrown off near a critical point can be far above the whole spectrum, where
 // the adjugate is huge and looks healthy.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
 // time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
-#ifndef SO3_QUAT_LAGUERRE
-#define SO3_QUAT_LAGUERRE 4          // Laguerre iterations
-#endif
-#ifndef SO3_QUAT_TRIG
-#define SO3_QUAT_TRIG 1              // 1: closed-form start + two Newton steps; 0: Laguerre from the upper bound (the first build)
-#endif
-#ifndef SO3_QUAT_NEWTON
-#define SO3_QUAT_NEWTON 1            // Newton steps after them
-#endif
 constexpr float kQuatTau = 1e-3f;       // first pass
 constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
 constexpr int kQuatExtra = 2;           // how many further refinements a row may take
@@ -617,7 +608,6 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // of a cancellation, but they weigh little in the sum).  Two Newton steps on the quartic finish it; the start is
     // raised by 1e-3 so that they come from above.  (Laguerre from the bound sqrt(3)|M|_F needed four steps and a Newton
     // step for the same roots: 68 packed instructions and 20 transcendentals against 40 and 26.)
-#if SO3_QUAT_TRIG
     T lam;
     {
         // in units of f (mu / f in [0, 1]): no power of the entries beyond f^2 is formed
@@ -649,24 +639,6 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
         lam = R::fma(-p, R::rcp(dp), lam);
     }
-#else
-    // Laguerre from above, then Newton
-    T lam = R::sqrt(f * R::splat(S(3)));
-#pragma unroll
-    for (int it = 0; it < SO3_QUAT_LAGUERRE + SO3_QUAT_NEWTON; ++it) {
-        const T l2 = lam * lam;
-        const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
-        const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
-        if (it < SO3_QUAT_LAGUERRE) {
-            const T ddp = R::fma(R::splat(S(12)), l2, twoc2);
-            const T h = R::fma(R::splat(S(9)) * dp, dp, (p * ddp) * R::splat(S(-12)));     // (n-1)((n-1)P'^2 - n P P''), n = 4
-            const T den = dp + R::sqrt(R::abs(h));      // h >= 0 up to round-off; |h| is a free source modifier
-            lam = R::fma(p * R::splat(S(-4)), R::rcp(den), lam);
-        } else {
-            lam = R::fma(-p, R::rcp(dp), lam);
-        }
-    }
-#endif
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
     // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
     // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
