@@ -312,11 +312,12 @@ def main():
             st = ctypes.c_void_p(stream.cuda_stream)
             torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with torch.cuda.stream(stream):
+    with torch.cuda.stream(stream):           # a graph replays on the CURRENT stream: entered before the clock starts
+        e0.record(stream); e1.record(stream)  # (torch creates an event's handle at its first record: not inside the region either)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         e0.record(stream)
         if graph is not None:
             graph.replay()
@@ -324,10 +325,10 @@ def main():
             for i in range(args.steps):
                 step(i)
         e1.record(stream)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0           # this rank's K steps; the job's time is the MAX over ranks (below), the ranks
-    if dist is not None:                      # having started together -- the closing barrier's own latency is not a step
-        dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0       # this rank's K steps; the job's time is the MAX over ranks (below), the ranks
+        if dist is not None:                  # having started together -- the closing barrier's own latency is not a step
+            dist.barrier()
     ev_ms = e0.elapsed_time(e1)
     if dist is not None:
         tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
