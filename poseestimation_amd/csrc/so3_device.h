@@ -64,17 +64,11 @@ __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballo
 #endif
 }  // namespace hw
 
-#ifndef SO3_REUSE_NORMS
-#define SO3_REUSE_NORMS 0   // 1 breaks orthogonality for s2/s1 < 1e-2 (tools/illcond_check.py): kept off
-#endif
-#ifndef SO3_SWEEPS
-#define SO3_SWEEPS 3
-#endif
 // Sweep schedule: kSweeps fixed cyclic sweeps, then -- if any matrix held by the wave still has a relative
 // off-orthogonality of its (0,1) pair above kResidualTol (a wave-uniform branch) -- one more rotation of that pair,
 // kept by the matrices that failed.  On Gaussian input 99.93 % of the rows are below 1e-5 after three sweeps
 // (tools/proto_jacobi.py), so about one wave round in eight takes the branch.
-constexpr int kSweeps = SO3_SWEEPS;
+constexpr int kSweeps = 3;
 constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|^2 |a_1|^2)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
 constexpr float kTinyNorm2 = 1e-30f;
@@ -353,23 +347,14 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     const V3<T> mr0 = mk<T>(m[0], m[1], m[2]), mr1 = mk<T>(m[3], m[4], m[5]), mr2 = mk<T>(m[6], m[7], m[8]);
     V3<T> t1 = axpy<T>(u1.z, mr2, axpy<T>(u1.y, mr1, scale<T>(mr0, u1.x)));     // M^T u1 = s1 v1
     V3<T> t2 = axpy<T>(u2.z, mr2, axpy<T>(u2.y, mr1, scale<T>(mr0, u2.x)));     // M^T u2 = s2 v2
-#if SO3_REUSE_NORMS
-    // |M^T u1| = s1 = |x| and |GS(M^T u2)| = s2 = |w| up to the SQUARE of the sweep residual (u1 = x/|x| exactly;
-    // a residual eps tilts it by eps towards u2, which changes |M^T u1|^2 by eps^2 s2^2): reuse 1/|x| and 1/|w|
-    // instead of two more dot products and rsq per matrix.
-    T nt1 = nx;
-    V3<T> v1 = scale<T>(t1, inx);
-    V3<T> r2 = axpy<T>(-dot(v1, t2), v1, t2);
-    T nr2 = nw;
-    V3<T> v2 = scale<T>(r2, inw);
-#else
+    // (|M^T u1| = |x| and |GS(M^T u2)| = |w| up to the square of the sweep residual, but reusing 1/|x| and 1/|w| here breaks
+    // orthogonality for s2/s1 < 1e-2: the norms are recomputed.)
     T nt1 = dot(t1, t1);
     V3<T> v1 = scale<T>(t1, R::rsq(nt1));
     const T pt = dot(v1, t2);
     V3<T> r2 = axpy<T>(-pt, v1, t2);
     T nr2 = dot(r2, r2);
     V3<T> v2 = scale<T>(r2, R::rsq(nr2));
-#endif
 
     // Rank <= 1 (or all-zero) input: the frame is not unique; pick one deterministically.  Numerically rank one
     // counts too: when the second singular value sits at round-off (s2 <~ eps s1; an outer product, a matrix of small
@@ -380,9 +365,6 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     // (`<=` comparisons are false for NaN, so NaN input flows through the fast path to NaN output.)
     const T tiny = R::splat(K::tiny);
     const T lost = R::splat(S(1e-2));
-#if SO3_REUSE_NORMS
-    const T pt = R::splat(S(0));
-#endif
     const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, R::fma(lost * qy, qy, tiny)) | R::le(nt1, tiny)
                                         | R::le(nr2, R::fma(lost * pt, pt, tiny));
     if (__builtin_expect(R::any(degenerate), 0)) {
@@ -477,14 +459,8 @@ constexpr float kQuatTau = 1e-3f;       // first pass
 constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
 constexpr int kQuatExtra = 2;           // how many further refinements a row may take
 constexpr float kQuatConv = 4e-4f;
-#ifndef SO3_QUAT_RESID
-#define SO3_QUAT_RESID 8e-7f
-#endif
-constexpr float kQuatResid = SO3_QUAT_RESID;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
-#ifndef SO3_QUAT_CURV
-#define SO3_QUAT_CURV 0.5f
-#endif
-constexpr float kQuatCurv = SO3_QUAT_CURV;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
+constexpr float kQuatResid = 8e-7f;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
+constexpr float kQuatCurv = 0.5f;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
 
 template <class T> struct Sym4 {        // symmetric 4x4, upper triangle
     T a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
@@ -664,16 +640,23 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
     // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
     // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
+    // A row whose gap product sits at the adjugate's own round-off (an eighth of the second pass's threshold) cannot be settled
+    // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
+    // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
+    // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
+    const typename R::mask hopeless = R::mnot(R::gt(trace, ((lam2 * lam2) * lam2) * R::splat(S(0.125f * kQuatTau2))));
+    typename R::mask frozen = settled | hopeless;
 #pragma unroll 1
-    for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(settled))); ++extra) {
+    for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
         T q3[4], trace3;
         const T lam3 = rayleigh<T>(k, q);
         dominant_column<T>(k, lam3, q3, trace3);
         const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = R::sel(settled, q[i], q3[i]);
-        shift = R::sel(settled, shift, lam3);
-        settled = settled | settled3;
+        for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
+        shift = R::sel(frozen, shift, lam3);
+        settled = settled | (settled3 & R::mnot(frozen));
+        frozen = settled | hopeless;
     }
     // 7. R(q), q = (w, x, y, z) unnormalised
     const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
@@ -691,26 +674,34 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
 }
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
+// When any row held by the wave is hard (a wave-uniform branch), the Jacobi path runs on EVERYTHING the wave holds -- for the
+// packed engine that is the packed instantiation, both halves of every lane at once -- and only the hard rows keep its result.
+// (Round 2 redid hard rows one lane-half at a time inside a divergent branch: fast path + two scalar SVDs per lane, and a batch
+// with 1 % near-reflections took 1.9 x the time of a Gaussian one.)  signed_svd<., float> and signed_svd<., f32x2> execute the
+// same IEEE operations per matrix, so a row's bits do not depend on which instantiation, or which wave-mates, it met.
+// WANT_BWD: the frames come with their singular values, for the hard rows' backward (project_backward).
 // (float64 rows go straight to Jacobi: so3_project_fwd_f64 is not a benchmark path.)
-template <class T> __device__ __forceinline__ typename Tr<T>::mask project_rotation(const T (&m)[9], T (&r)[9]) {
+template <class T> struct HardRows {
+    typename Tr<T>::mask hard;       // which rows took the Jacobi path (their backward must, too)
+    bool any;                        // wave-uniform: does `frames` hold anything
+    SignedSvd<T> frames;
+};
+template <bool WANT_BWD, class T> __device__ __forceinline__ void project_rotation_frames(const T (&m)[9], T (&r)[9], HardRows<T> &h) {
     typedef Tr<T> R;
-    typedef typename R::scalar S;
-    const typename R::mask hard = quat_rotation<T>(m, r);
-    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+    h.hard = quat_rotation<T>(m, r);
+    h.any = wave_any(R::any(h.hard));
+    if (__builtin_expect(h.any, 0)) {
+        h.frames = signed_svd<WANT_BWD, T>(m);
+        T rj[9];
+        rotation_from(h.frames, rj);
 #pragma unroll
-        for (int i = 0; i < R::kLanes; ++i) {
-            if (R::lane_of(hard, i)) {
-                S mk[9], rk[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) mk[j] = R::get(m[j], i);
-                const auto f = signed_svd<false, S>(mk);
-                rotation_from(f, rk);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) R::set(r[j], i, rk[j]);
-            }
-        }
+        for (int j = 0; j < 9; ++j) r[j] = R::sel(h.hard, rj[j], r[j]);
     }
-    return hard;                       // which rows took the Jacobi path (their backward must, too)
+}
+template <class T> __device__ __forceinline__ typename Tr<T>::mask project_rotation(const T (&m)[9], T (&r)[9]) {
+    HardRows<T> h;
+    project_rotation_frames<false, T>(m, r, h);
+    return h.hard;
 }
 template <> __device__ __forceinline__ bool project_rotation<double>(const double (&m)[9], double (&r)[9]) {
     const auto f = signed_svd<false, double, 4, true, 6>(m);
@@ -771,13 +762,19 @@ __device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T 
 template <class T>
 __device__ __forceinline__ void backward_from_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], T (&dm)[9]) {
     typedef Tr<T> R;
-    // S = R^T M, upper triangle: S_ij = sum_k r[3k+i] m[3k+j]
+    // S = R^T M, S_ij = sum_k r[3k+i] m[3k+j], SYMMETRISED: off-diagonal entries are the mean of both triangles.  R carries a
+    // round-off rotation delta ~ eps s1 / gap about its ill-conditioned axis, which makes the computed S = (I - [delta]x) S_exact
+    // non-symmetric; one triangle alone then shifts A's smallest eigenvalue (s2 + s3') at FIRST order in delta -- a relative
+    // error eps (s1 / gap)^2 in y -- while the symmetric part shifts it at second order only and leaves eps s1 / gap, the
+    // conditioning of the gradient itself (round 2 used the upper triangle: 10-300 x the Jacobi frames' error on
+    // s = (1, e, -e'), e ~ 1e-3).
     const T s00 = R::fma(r[6], m[6], R::fma(r[3], m[3], r[0] * m[0]));
     const T s11 = R::fma(r[7], m[7], R::fma(r[4], m[4], r[1] * m[1]));
     const T s22 = R::fma(r[8], m[8], R::fma(r[5], m[5], r[2] * m[2]));
-    const T s01 = R::fma(r[6], m[7], R::fma(r[3], m[4], r[0] * m[1]));
-    const T s02 = R::fma(r[6], m[8], R::fma(r[3], m[5], r[0] * m[2]));
-    const T s12 = R::fma(r[7], m[8], R::fma(r[4], m[5], r[1] * m[2]));
+    const T half = R::splat(typename R::scalar(0.5));
+    const T s01 = (R::fma(r[6], m[7], R::fma(r[3], m[4], r[0] * m[1])) + R::fma(r[7], m[6], R::fma(r[4], m[3], r[1] * m[0]))) * half;
+    const T s02 = (R::fma(r[6], m[8], R::fma(r[3], m[5], r[0] * m[2])) + R::fma(r[8], m[6], R::fma(r[5], m[3], r[2] * m[0]))) * half;
+    const T s12 = (R::fma(r[7], m[8], R::fma(r[4], m[5], r[1] * m[2])) + R::fma(r[8], m[7], R::fma(r[5], m[4], r[2] * m[1]))) * half;
     // A = tr(S) I - S
     const T a00 = s11 + s22, a11 = s00 + s22, a22 = s00 + s11, a01 = -s01, a02 = -s02, a12 = -s12;
     // b = axial(Z - Z^T), Z = R^T G:  b = (Z21 - Z12, Z02 - Z20, Z10 - Z01)   (0-based; Z_ij = sum_k r[3k+i] g[3k+j])
@@ -801,39 +798,30 @@ __device__ __forceinline__ void backward_from_rotation(const T (&m)[9], const T 
     }
 }
 
-// dM for upstream G, given the rotation R = project_rotation(M) and the mask of rows that took the Jacobi path: settled rows
-// from the rotation, hard rows through the Jacobi frames (their denominators s_i + s_j may vanish: floored there).
+// dM for upstream G, given the rotation R and the hard rows' frames from project_rotation_frames<true>: settled rows from the
+// rotation, hard rows through the Jacobi frames (their denominators s_i + s_j may vanish: floored there).
 template <class T>
-__device__ __forceinline__ void backward_given_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], typename Tr<T>::mask hard, T (&dm)[9]) {
+__device__ __forceinline__ void backward_given_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], const HardRows<T> &h, T (&dm)[9]) {
     typedef Tr<T> R;
-    typedef typename R::scalar S;
     backward_from_rotation<T>(m, r, g, dm);
-    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+    if (__builtin_expect(h.any, 0)) {
+        T dj[9];
+        project_backward(h.frames, g, dj);
 #pragma unroll
-        for (int i = 0; i < R::kLanes; ++i) {
-            if (R::lane_of(hard, i)) {
-                S mk[9], gk[9], dk[9];
-#pragma unroll
-                for (int j = 0; j < 9; ++j) { mk[j] = R::get(m[j], i); gk[j] = R::get(g[j], i); }
-                const auto f = signed_svd<true, S>(mk);
-                project_backward(f, gk, dk);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) R::set(dm[j], i, dk[j]);
-            }
-        }
+        for (int j = 0; j < 9; ++j) dm[j] = R::sel(h.hard, dj[j], dm[j]);
     }
-}
-template <>
-__device__ __forceinline__ void backward_given_rotation<double>(const double (&m)[9], const double (&)[9], const double (&g)[9], bool, double (&dm)[9]) {
-    const auto f = signed_svd<true, double, 4, true, 6>(m);
-    project_backward(f, g, dm);
 }
 
 // K2's arithmetic (autograd of K1): rotation, then its backward.
 template <class T> __device__ __forceinline__ void project_backward_rows(const T (&m)[9], const T (&g)[9], T (&dm)[9]) {
     T r[9];
-    const typename Tr<T>::mask hard = project_rotation<T>(m, r);
-    backward_given_rotation<T>(m, r, g, hard, dm);
+    HardRows<T> h;
+    project_rotation_frames<true, T>(m, r, h);
+    backward_given_rotation<T>(m, r, g, h, dm);
+}
+template <> __device__ __forceinline__ void project_backward_rows<double>(const double (&m)[9], const double (&g)[9], double (&dm)[9]) {
+    const auto f = signed_svd<true, double, 4, true, 6>(m);
+    project_backward(f, g, dm);
 }
 
 }  // namespace so3

@@ -3,20 +3,21 @@
 //
 // The batch is cut into UNITS of 64 rows (64 x 9 elements: 2304 B for f32, 1152 B for bf16).  Persistent
 // waves, no workgroup barrier on the data path: in one ROUND a wave takes NPL consecutive units (lane l
-// owns row l of each) from up to two input arrays, computes, and writes up to two output arrays; wave w takes
-// rounds w, w+W, w+2W, ...  A unit travels
-//     HBM --buffer_load_dwordx4 nt--> VGPR --ds_write_b128--> LDS --ds_read_b32/u16 (stride 9)--> lane
-// and back the same way.  Design points (measurements in DESIGN.md):
+// owns row l of each) from up to three input arrays, computes, and writes up to two output arrays; wave w takes
+// rounds w, w+W, w+2W, ...  A round's units travel as one block
+//     HBM --buffer_load_dwordx4 nt--> VGPR --ds_write_b128--> LDS --ds_read_b32 (stride 9)--> lane
+//     HBM --buffer_load_dwordx4 nt lds---------------------> LDS   (DMA build: float32 inputs, no VGPR staging)
+// and back  lane --ds_write_b32--> LDS --ds_read_b128--> VGPR --buffer_store_dwordx4 nt--> HBM.
+// Design points (measurements in DESIGN.md):
 //   * NPL = 2 packs two independent matrices into the halves of v_pk_* operands (so3_device.h): a Jacobi
 //     sweep is a dependent chain and dependent scalar VALU issues at about half rate.
-//   * The NEXT round's loads are issued before the current round's arithmetic and land in LDS at the END of
-//     the loop body: they are older than the round's stores, so the wait is vmcnt(#stores), never a drain.
-//   * Unit I/O is raw buffer instructions with a PER-UNIT descriptor (num_records = unit bytes, or 0 for a
-//     unit that does not exist / a prefetch past the end): partial float4 slots, odd tails and the dangling
-//     prefetch are dropped by the hardware range check instead of exec-masked branches, which keeps the
-//     compiler's vmcnt bookkeeping exact and costs no traffic.
-//   * LDS is private to a wave (a slot per unit and array, padded so every lane can touch float4 #lane+128);
-//     DS operations of one wave complete in issue order, so no s_barrier is needed.
+//   * The NEXT round's loads are in flight during the current round's arithmetic and are waited for BEHIND the
+//     round's stores: they are older than the stores, so the wait is vmcnt(#stores), never a drain.
+//   * Unit I/O is raw buffer instructions with a per-round descriptor (num_records = the bytes that exist, 0 for
+//     a prefetch past the end): partial float4 slots, odd tails and the dangling prefetch are dropped by the
+//     hardware range check instead of exec-masked branches, which keeps the compiler's vmcnt bookkeeping exact
+//     and costs no traffic.
+//   * LDS is private to a wave; DS operations of one wave complete in issue order, so no s_barrier is needed.
 //   * Every streamed access is non-temporal: each byte is touched once.
 //   * Reductions (loss, sum of angles) stay in a per-lane float64 register until the wave retires; one atomic
 //     per WORKGROUP then publishes them (same-address float64 atomics cost ~12 ns each).
@@ -38,10 +39,17 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 constexpr int kUnitRows = 64;
 constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data format
-#ifndef SO3_STREAM_CPOL
-#define SO3_STREAM_CPOL 2                        // cache policy of the streamed loads/stores: 2 = nt (non-temporal)
+// Cache policy of the streamed accesses (each byte is touched once): aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1.
+// A plain 36 MB -> 36 MB copy: 14.8 us with the default policy, 13.1 us nt (tools/ubench/copy_ceiling.hip).
+#ifndef SO3_LOAD_CPOL
+#define SO3_LOAD_CPOL 2
 #endif
-constexpr int kStreamCpol = SO3_STREAM_CPOL;     // a plain 36 MB -> 36 MB copy: 14.8 us default policy, 13.1 us nt
+#ifndef SO3_STORE_CPOL
+#define SO3_STORE_CPOL 2
+#endif
+constexpr int kLoadCpol = SO3_LOAD_CPOL, kStoreCpol = SO3_STORE_CPOL;
+constexpr int kStreamNt = 2;                     // the cloud kernels' once-read points
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -67,6 +75,8 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
     static constexpr int kBytes = G * kUnitBytes;                // the round's block
     static constexpr int kVec4 = kBytes / 16;
     static constexpr int kLoads = (kVec4 + 63) / 64;             // float4 per lane (the last one partial)
+    static constexpr int kTailLanes = kVec4 - 64 * (kLoads - 1); // lanes of the last load that carry data
+    static constexpr int kImageBytes = G * kUnitRows * N * 4;    // the float32 image of the block, without padding
     // The LDS image is ALWAYS float32 (bfloat16 is converted once per block on its way in or out): lanes then read their
     // rows with ds_read_b32 at a 9-dword stride, conflict-free, whatever the storage type.  (Sub-dword reads of a bf16
     // image at an 18-byte stride made K1 with bf16 input slower than with float32 input while moving half the bytes.)
@@ -83,12 +93,24 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
     static __device__ __forceinline__ void fetch(f32x4 (&v)[kLoads], rsrc_t rs, int lane) {
 #pragma unroll
         for (int j = 0; j < kLoads; ++j)
-            v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * j) * 16, 0, kStreamCpol));
+            v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * j) * 16, 0, kLoadCpol));
     }
     static __device__ __forceinline__ void store(rsrc_t rs, const f32x4 (&v)[kLoads], int lane) {
 #pragma unroll
         for (int j = 0; j < kLoads; ++j)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStreamCpol);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStoreCpol);
+    }
+    // LDS-DMA: the block straight from HBM into the wave's image (float32: the image is the storage format), 1 KiB per
+    // wave-instruction, lane l's 16 bytes at image + 1024 j + 16 l; the lanes of the last load that lie beyond the block are
+    // masked (they would land in the neighbouring image).  `img` is wave-uniform (M0).
+    // MASK = false: the image is padded to whole loads instead (the lanes beyond the block are dropped by the range check and
+    // write zeros into the padding) -- no exec-masked branch, which keeps the waitcnt pass's count of pending operations exact.
+    template <bool MASK> static __device__ __forceinline__ void fetch_lds(char *img, rsrc_t rs, int lane) {
+        static_assert(EB == 4, "LDS-DMA needs the storage format to be the image format");
+#pragma unroll
+        for (int j = 0; j < kLoads; ++j)
+            if (!MASK || j + 1 < kLoads || kTailLanes == 64 || lane < kTailLanes)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(img + j * 1024), 16, lane * 16, j * 1024, 0, kLoadCpol);
     }
     // registers (storage type, 16 B per lane and load) -> float32 image in LDS
     static __device__ __forceinline__ void to_lds(char *slot, const f32x4 (&v)[kLoads], int lane) {
@@ -107,10 +129,12 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
         }
     }
     // float32 image in LDS -> registers in the storage type
-    static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
+    // (MASK: the image is not padded to whole loads -- lanes beyond the block keep zeros and are cut off by the store's descriptor)
+    template <bool MASK = false> static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
         const f32x4 *t4 = reinterpret_cast<const f32x4 *>(slot);
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) {
+            if (MASK && j + 1 == kLoads && kTailLanes != 64 && lane >= kTailLanes) { v[j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
             if constexpr (EB == 4) {
                 v[j] = t4[lane + 64 * j];
             } else {
@@ -136,7 +160,7 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
     }
 };
 template <int N, int G> struct UnitIO<0, N, G> {
-    static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0;
+    static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0, kImageBytes = 0;
 };
 
 // Per-row side outputs (flip flags, angles): one element per row, contiguous across the lanes of a unit.
@@ -173,89 +197,71 @@ template <int NPL> struct RowCtx {
 //   template <class T, int NPL> void compute(Rows<T, Op> &rows, RowCtx<NPL> &)      reads rows.a/b/c, writes rows.o0/o1
 //   void finish(double block_total, bool any_flag)      -- called by thread 0 of each workgroup at the end
 //   kReduce: whether acc/flag are used.
-// WPS = resident waves per SIMD the register budget is sized for (the host launches 256 * WPS * 256 / BLOCK
-// workgroups).  STAMP (diagnostic builds only): per wave {s_memrealtime entry, exit, s_memtime entry,
-// cycles | XCC << 28 | HW_ID << 32, cycles waiting for prefetched units | rounds done << 48, cycles until the first unit arrived}.
-//
-// Which wave takes which round.  DYN = false: wave w of the grid takes rounds w, w + W, w + 2W, ... (static).
-// DYN = true: ONE workgroup per CU (BLOCK = 64 * 4 * WPS fills it), workgroup b owns rounds b, b + G, b + 2G, ...
-// (G = gridDim.x) and its waves CLAIM them one at a time from a ticket counter in LDS.  Why: 1M rows are 7.6 rounds
-// per SIMD, and with the static deal the dispatcher happens to put the waves that hold one round more than the others
-// on the same CUs -- in-kernel stamps showed SIMDs with 9 rounds next to SIMDs with 6, and the 9s set the kernel's time.
-// With tickets a SIMD that is ahead simply takes the next round: 7 or 8 per SIMD wherever the workgroups land.
-// PF = rounds in flight in registers per wave (see the loop).
-template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false, bool DYN = false, int PF = 1>
+// WPS = resident waves per SIMD the register budget is sized for (the host launches CUs * 4 * WPS * 64 / BLOCK
+// workgroups); wave w of the grid takes rounds w, w + W, w + 2W, ... (static deal: tickets, two rounds in flight and
+// s_setprio were measured in round 2 and bought nothing).
+// DMA = the round's input blocks go straight into LDS (buffer_load_dwordx4 ... lds), no VGPR staging and no ds_write_b128:
+//   two LDS images per wave, the next round's loads are issued into the idle one as soon as the current round's rows
+//   are in registers.  float32 inputs only (the LDS image IS the storage format).
+// STAMP (diagnostic builds only, instantiated by tools/ubench/k1_anatomy.hip from its own translation unit): per wave
+//   {s_memrealtime entry, exit, s_memtime entry, cycles | XCC << 28 | HW_ID << 32, rounds done << 48, 0} and the
+//   begin / end of the arithmetic of the wave's first four rounds.
+template <class Op> struct EngineIO {
+    template <int NPL> struct For {
+        typedef UnitIO<Op::kIn0, Op::kIn0N, NPL> I0;
+        typedef UnitIO<Op::kIn1, Op::kIn1N, NPL> I1;
+        typedef UnitIO<Op::kIn2, Op::kIn2N, NPL> I2;
+        typedef UnitIO<Op::kOut0, Op::kOut0N, NPL> O0;
+        typedef UnitIO<Op::kOut1, Op::kOut1N, NPL> O1;
+    };
+};
+
+template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false, bool DMA = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
-    typedef UnitIO<Op::kIn0, Op::kIn0N, NPL> I0;
-    typedef UnitIO<Op::kIn1, Op::kIn1N, NPL> I1;
-    typedef UnitIO<Op::kIn2, Op::kIn2N, NPL> I2;
-    typedef UnitIO<Op::kOut0, Op::kOut0N, NPL> O0;
-    typedef UnitIO<Op::kOut1, Op::kOut1N, NPL> O1;
+    typedef typename EngineIO<Op>::template For<NPL> IO;
+    typedef typename IO::I0 I0;
+    typedef typename IO::I1 I1;
+    typedef typename IO::I2 I2;
+    typedef typename IO::O0 O0;
+    typedef typename IO::O1 O1;
+    static_assert(!DMA || ((Op::kIn0 == 4) && (Op::kIn1 == 0 || Op::kIn1 == 4) && (Op::kIn2 == 0 || Op::kIn2 == 4)),
+                  "LDS-DMA lands the storage format in LDS: float32 inputs only");
     constexpr int kWaves = BLOCK / 64;
     // LDS slot of a wave: the images of the round's input blocks side by side; outputs are staged over them once the
-    // rows are in registers
-    constexpr int kInBytes = I0::kSlotBytes + I1::kSlotBytes + I2::kSlotBytes;
-    constexpr int kOutBytes = O0::kSlotBytes + O1::kSlotBytes;
+    // rows are in registers.  Images are padded to whole 1-KiB loads; only when the two images per wave of the DMA build would
+    // not fit the CU's 160 KiB are they cut to the exact block size and the partial last load lane-masked (kExact).
+    constexpr int kPadIn = I0::kSlotBytes + I1::kSlotBytes + I2::kSlotBytes, kPadOut = O0::kSlotBytes + O1::kSlotBytes;
+    constexpr bool kExact = DMA && 2 * (kPadIn > kPadOut ? kPadIn : kPadOut) * 4 * WPS + 1024 > 160 * 1024;
+    constexpr int kIn0B = kExact ? I0::kBytes : I0::kSlotBytes, kIn1B = kExact ? I1::kBytes : I1::kSlotBytes, kIn2B = kExact ? I2::kBytes : I2::kSlotBytes;
+    constexpr int kOut0B = kExact ? O0::kImageBytes : O0::kSlotBytes, kOut1B = kExact ? O1::kImageBytes : O1::kSlotBytes;
+    constexpr int kInBytes = kIn0B + kIn1B + kIn2B;
+    constexpr int kOutBytes = kOut0B + kOut1B;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
-    __shared__ __attribute__((aligned(16))) char lds[kWaves][kSlot];
-    __shared__ double red[kWaves];
-    __shared__ int red_flag[kWaves];
-    __shared__ unsigned next_ticket;
+    // Two arrays, not one of twice the size: distinct LDS objects carry distinct alias scopes down to the waitcnt pass, so a
+    // ds access to one image waits only for the LDS-DMA loads that target THAT image (and never for the other one's, in flight).
+    __shared__ __attribute__((aligned(16))) char lds_a[kWaves][kSlot];
+    __shared__ __attribute__((aligned(16))) char lds_b[kWaves][DMA ? kSlot : 16];
+    __shared__ double red[Op::kReduce ? kWaves : 1];
+    __shared__ int red_flag[Op::kReduce ? kWaves : 1];
 
-    unsigned long long t_real0 = 0, t_mem0 = 0, stall_cycles = 0, first_wait = 0, rounds_done = 0;
+    unsigned long long t_real0 = 0, t_mem0 = 0, rounds_done = 0;
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
-    char *slot = lds[wave_in_block];
     const int64_t nrounds = (nunits + NPL - 1) / NPL;
-    // static: round t, then t + stride.  dynamic: ticket k of this workgroup is round blockIdx + k * gridDim.
-    const int64_t stride = DYN ? static_cast<int64_t>(gridDim.x) : static_cast<int64_t>(gridDim.x) * kWaves;
-    int64_t t = DYN ? static_cast<int64_t>(blockIdx.x) + wave_in_block * stride : static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kWaves;
     const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
-    if (DYN) {
-        if (threadIdx.x == 0) next_ticket = kWaves;         // tickets 0 .. kWaves-1 are the waves' first rounds
-        __syncthreads();
-    }
+    int64_t t = wave_id;
     RowCtx<NPL> ctx;
     ctx.lane = lane;
     ctx.acc = 0.0;
     ctx.flag = false;
     if (t < nrounds) {
-        // PF rounds are in flight in registers behind the round that sits in LDS.  One round ahead (PF = 1) leaves the
-        // memory pipe short of requests whenever the wave's arithmetic outlasts a load's latency: with K1's arithmetic the
-        // kernel took the copy's time PLUS 0.4 of the arithmetic's.  Two rounds ahead cost 6 * NPL more VGPRs per input.
-        struct Flight {
-            f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
-        };
-        Flight buf[PF];
-        int64_t held[PF];                                   // the round each buffer holds (>= nrounds: none, empty loads)
-        int64_t cursor = t;
-        auto next_round = [&]() -> int64_t {
-            if (DYN) {
-                unsigned k = 0;
-                if (lane == 0) k = __hip_atomic_fetch_add(&next_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                return static_cast<int64_t>(blockIdx.x) + static_cast<int64_t>(__builtin_amdgcn_readfirstlane(k)) * stride;
-            }
-            cursor += stride;
-            return cursor;
-        };
         auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
             const int64_t left = nunits - tr * NPL;
             return tr < nrounds ? static_cast<int>(left < NPL ? left : NPL) : 0;
-        };
-        auto issue = [&](Flight &b, int64_t tr) {           // past the last round the descriptors are empty: the loads
-            const int cnt = units_of(tr);                   // return 0 and cost no traffic
-            const int64_t u = cnt > 0 ? tr * NPL : 0;
-            I0::fetch(b.in0, I0::rsrc(op.in0, u, cnt), lane);
-            if constexpr (Op::kIn1 != 0) I1::fetch(b.in1, I1::rsrc(op.in1, u, cnt), lane);
-            if constexpr (Op::kIn2 != 0) I2::fetch(b.in2, I2::rsrc(op.in2, u, cnt), lane);
-        };
-        auto land = [&](const Flight &b) {                  // registers -> the wave's LDS slot (float32 images)
-            I0::to_lds(slot, b.in0, lane);
-            if constexpr (Op::kIn1 != 0) I1::to_lds(slot + I0::kSlotBytes, b.in1, lane);
-            if constexpr (Op::kIn2 != 0) I2::to_lds(slot + I0::kSlotBytes + I1::kSlotBytes, b.in2, lane);
         };
         // STAMP builds: wall-clock (100 MHz) begin / end of the arithmetic of the wave's first four rounds
         auto phase = [&](int ph) {
@@ -267,68 +273,106 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        // the first round travels through the last buffer, the next PF - 1 through the others; buffer 0 is then the oldest
-        issue(buf[PF - 1], t);
+        // the lanes' rows of round t out of the wave's image `img`
+        auto take_rows = [&](const char *img, Rows<T, Op> &rows) {
 #pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) { held[i] = next_round(); issue(buf[i], held[i]); }
-        if (STAMP) { __builtin_amdgcn_s_waitcnt(0); first_wait = __builtin_amdgcn_s_memtime() - t_mem0; }
-        land(buf[PF - 1]);
-        held[PF - 1] = next_round();
-        issue(buf[PF - 1], held[PF - 1]);
-        bool done = false;
-        while (!done) {
-#pragma unroll
-            for (int p = 0; p < PF; ++p) {                  // buffer p holds the round after the one in LDS
-                wave_lds_fence();
-                Rows<T, Op> rows;
+            for (int k = 0; k < NPL; ++k) {
+                ctx.unit[k] = t * NPL + k;
+                ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail,
+                const int u = ctx.exists[k] ? k : 0;    // whose lanes work on the round's first unit instead (results dropped)
+                I0::read_row(img, u, lane, k, rows.a);
+                if constexpr (Op::kIn1 != 0) I1::read_row(img + kIn0B, u, lane, k, rows.b);
+                if constexpr (Op::kIn2 != 0) I2::read_row(img + kIn0B + kIn1B, u, lane, k, rows.c);
+            }
+        };
+        // the round's results: rows -> image (over the consumed inputs) -> float4 per lane -> HBM
+        auto put_rows = [&](char *img, const Rows<T, Op> &rows) {
+            if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
-                    ctx.unit[k] = t * NPL + k;
-                    ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail,
-                    const int u = ctx.exists[k] ? k : 0;    // whose lanes work on the round's first unit instead (results dropped)
-                    I0::read_row(slot, u, lane, k, rows.a);
-                    if constexpr (Op::kIn1 != 0) I1::read_row(slot + I0::kSlotBytes, u, lane, k, rows.b);
-                    if constexpr (Op::kIn2 != 0) I2::read_row(slot + I0::kSlotBytes + I1::kSlotBytes, u, lane, k, rows.c);
+                    if constexpr (Op::kOut0 != 0) O0::write_row(img, k, lane, k, rows.o0);
+                    if constexpr (Op::kOut1 != 0) O1::write_row(img + kOut0B, k, lane, k, rows.o1);
                 }
                 wave_lds_fence();
+                f32x4 v0[O0::kLoads], v1[O1::kLoads];
+                if constexpr (Op::kOut0 != 0) O0::template from_lds<kExact>(v0, img, lane);
+                if constexpr (Op::kOut1 != 0) O1::template from_lds<kExact>(v1, img + kOut0B, lane);
+                wave_lds_fence();
+                const int cnt = units_of(t);            // an odd tail's phantom unit is cut off by the descriptor
+                if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, t * NPL, cnt), v0, lane);
+                if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, t * NPL, cnt), v1, lane);
+            }
+        };
+        if constexpr (DMA) {
+            char *img_a = lds_a[wave_in_block], *img_b = lds_b[wave_in_block];
+            auto issue = [&](char *img, int64_t tr) {       // past the last round the descriptors are empty: no traffic
+                const int cnt = units_of(tr);
+                const int64_t u = cnt > 0 ? tr * NPL : 0;
+                I0::template fetch_lds<kExact>(img, I0::rsrc(op.in0, u, cnt), lane);
+                if constexpr (Op::kIn1 != 0) I1::template fetch_lds<kExact>(img + kIn0B, I1::rsrc(op.in1, u, cnt), lane);
+                if constexpr (Op::kIn2 != 0) I2::template fetch_lds<kExact>(img + kIn0B + kIn1B, I2::rsrc(op.in2, u, cnt), lane);
+            };
+            // One round: the rows of round t (out of `cur`) are in registers; the next round's loads go into `nxt`, the results
+            // are staged over `cur`, and the next round's rows are taken at the END -- behind this round's stores, so the wait
+            // for nxt's loads is vmcnt(#stores), never a drain (and the same count on every path into the loop: taken at the top
+            // of the body instead, the first round's vmcnt(0) merges into the loop header).  False after the wave's last round.
+            auto round = [&](char *cur, char *nxt, Rows<T, Op> &rows) -> bool {
+                const int64_t tn = t + stride;
+                issue(nxt, tn);
                 phase(3);
-#ifdef SO3_SETPRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
                 op.template compute<T, NPL>(rows, ctx);
-#ifdef SO3_SETPRIO
-                __builtin_amdgcn_s_setprio(SO3_SETPRIO);     // experiment: the wave's memory phase outranks its mates' arithmetic
-#endif
                 phase(4);
                 if (STAMP) ++rounds_done;
-                if constexpr (Op::kOut0 != 0 || Op::kOut1 != 0) {
-#pragma unroll
-                    for (int k = 0; k < NPL; ++k) {
-                        if constexpr (Op::kOut0 != 0) O0::write_row(slot, k, lane, k, rows.o0);
-                        if constexpr (Op::kOut1 != 0) O1::write_row(slot + O0::kSlotBytes, k, lane, k, rows.o1);
-                    }
-                    wave_lds_fence();
-                    f32x4 v0[O0::kLoads], v1[O1::kLoads];
-                    if constexpr (Op::kOut0 != 0) O0::from_lds(v0, slot, lane);
-                    if constexpr (Op::kOut1 != 0) O1::from_lds(v1, slot + O0::kSlotBytes, lane);
-                    wave_lds_fence();
-                    const int cnt = units_of(t);            // an odd tail's phantom unit is cut off by the descriptor
-                    if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, t * NPL, cnt), v0, lane);
-                    if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, t * NPL, cnt), v1, lane);
-                }
-                if (held[p] >= nrounds) { done = true; break; }
-                // The oldest buffer lands in LDS here, at the END of the body: its loads are older than this round's
-                // stores (and than the younger buffers' loads), so the wait is vmcnt(#younger), never a drain.
-                unsigned long long w0 = 0;
-                if (STAMP) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    w0 = __builtin_amdgcn_s_memtime();
-                }
-                land(buf[p]);
-                if (STAMP) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); stall_cycles += __builtin_amdgcn_s_memtime() - w0; }
-                t = held[p];
-                held[p] = next_round();
-                issue(buf[p], held[p]);
+                put_rows(cur, rows);
+                if (tn >= nrounds) return false;
+                t = tn;
+                wave_lds_fence();
+                take_rows(nxt, rows);
+                wave_lds_fence();
+                return true;
+            };
+            issue(img_a, t);
+            Rows<T, Op> rows;
+            take_rows(img_a, rows);                         // (the waitcnt pass holds these reads until the image's DMA has landed)
+            wave_lds_fence();
+            while (round(img_a, img_b, rows) && round(img_b, img_a, rows)) {}
+        } else {
+            char *slot = lds_a[wave_in_block];
+            // One round is in flight in registers behind the round that sits in LDS.
+            f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
+            auto issue = [&](int64_t tr) {                  // past the last round the descriptors are empty: the loads
+                const int cnt = units_of(tr);               // return 0 and cost no traffic
+                const int64_t u = cnt > 0 ? tr * NPL : 0;
+                I0::fetch(in0, I0::rsrc(op.in0, u, cnt), lane);
+                if constexpr (Op::kIn1 != 0) I1::fetch(in1, I1::rsrc(op.in1, u, cnt), lane);
+                if constexpr (Op::kIn2 != 0) I2::fetch(in2, I2::rsrc(op.in2, u, cnt), lane);
+            };
+            auto land = [&]() {                             // registers -> the wave's LDS slot (float32 images)
+                I0::to_lds(slot, in0, lane);
+                if constexpr (Op::kIn1 != 0) I1::to_lds(slot + kIn0B, in1, lane);
+                if constexpr (Op::kIn2 != 0) I2::to_lds(slot + kIn0B + kIn1B, in2, lane);
+            };
+            issue(t);
+            land();
+            int64_t held = t + stride;                      // the round the registers hold (>= nrounds: none, empty loads)
+            issue(held);
+            while (true) {
+                wave_lds_fence();
+                Rows<T, Op> rows;
+                take_rows(slot, rows);
+                wave_lds_fence();
+                phase(3);
+                op.template compute<T, NPL>(rows, ctx);
+                phase(4);
+                if (STAMP) ++rounds_done;
+                put_rows(slot, rows);
+                if (held >= nrounds) break;
+                // The prefetched round lands in LDS here, at the END of the body: its loads are older than this round's
+                // stores, so the wait is vmcnt(#stores), never a drain.
+                land();
+                t = held;
+                held += stride;
+                issue(held);
             }
         }
     }
@@ -347,7 +391,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             op.finish(total, f != 0);
         }
     }
-    if (STAMP && (DYN || wave_id < nrounds)) {
+    if (STAMP && wave_id < nrounds) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
             stamps[6 * wave_id + 0] = t_real0;
@@ -358,8 +402,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
             stamps[6 * wave_id + 3] = ((__builtin_amdgcn_s_memtime() - t_mem0) & 0xFFFFFFFull)
                                       | (static_cast<unsigned long long>(xcc & 0xF) << 28) | (static_cast<unsigned long long>(hw) << 32);
-            stamps[6 * wave_id + 4] = stall_cycles | (rounds_done << 48);
-            stamps[6 * wave_id + 5] = first_wait;
+            stamps[6 * wave_id + 4] = rounds_done << 48;
+            stamps[6 * wave_id + 5] = 0;
         }
     }
 }
@@ -377,10 +421,9 @@ struct OpBase {
 };
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
-// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206).  SWEEPS = kFastPath (the product): quaternion
-// fast path + Jacobi for hard rows (project_rotation); SWEEPS >= 0: Jacobi only, SWEEPS < 0: copy (both diagnostic).
-constexpr int kFastPath = 100;
-template <int IN_BYTES, bool FLIP, int SWEEPS = kFastPath, bool ADAPT = true>
+// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path, the Jacobi path for
+// the rows it declares hard (project_rotation).
+template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     uint8_t *flip = nullptr;
@@ -388,15 +431,7 @@ struct OpProject : OpBase {
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
         const T (&m)[9] = rows.a;
         T (&r)[9] = rows.o0;
-        if constexpr (SWEEPS < 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) r[i] = m[i];
-        } else if constexpr (SWEEPS == kFastPath) {
-            project_rotation<T>(m, r);
-        } else {
-            const auto f = signed_svd<false, T, SWEEPS, ADAPT>(m);
-            rotation_from(f, r);
-        }
+        project_rotation<T>(m, r);
         if (FLIP) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
@@ -434,7 +469,9 @@ struct OpFrobHead : OpBase {
         const T (&t)[9] = rows.b;
         T (&dm)[9] = rows.o0;
         T (&r)[9] = rows.o1;
-        const typename R::mask hard = project_rotation<T>(m, r);
+        HardRows<T> hard;
+        if constexpr (WANT_DM) project_rotation_frames<true, T>(m, r, hard);
+        else project_rotation_frames<false, T>(m, r, hard);
         T g[9];
         T n2 = R::splat(0.f);
 #pragma unroll

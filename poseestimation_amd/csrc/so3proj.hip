@@ -186,7 +186,8 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
         const bool active = static_cast<int>(threadIdx.x) < n;
         lane_get(tile_m, active, m);
         lane_get(tile_t, active, t);
-        const bool hard = so3::project_rotation<float>(m, r);
+        so3::HardRows<float> hard;
+        so3::project_rotation_frames<WANT_DM, float>(m, r, hard);
         float n2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
             t[i] = Rtrue[b * 9 + i];
         }
     }
-    const bool hard = so3::project_rotation<float>(m, r);
+    so3::HardRows<float> hard;
+    so3::project_rotation_frames<WANT_DM, float>(m, r, hard);
     float n2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -529,8 +531,8 @@ __global__ __launch_bounds__(kBlock) void k_kabsch(const float *__restrict__ P, 
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
                 const int off = (i0 + 64 * u + lane) * 12;
-                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, off, 0, so3::kStreamCpol);
-                qq[u] = __builtin_amdgcn_raw_buffer_load_b96(rq, off, 0, so3::kStreamCpol);
+                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, off, 0, so3::kStreamNt);
+                qq[u] = __builtin_amdgcn_raw_buffer_load_b96(rq, off, 0, so3::kStreamNt);
             }
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
             u32x3 pp[kKabschUnroll];
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u)
-                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+                pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamNt);
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
                 const int pt = i0 + 64 * u + lane;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(kBlock) void k_rotate_clouds(const float *__restric
         for (int i0 = 0; i0 < N; i0 += 64 * kCloudUnroll) {
             u32x3 pp[kCloudUnroll];
 #pragma unroll
-            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+            for (int u = 0; u < kCloudUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamNt);
 #pragma unroll
             for (int u = 0; u < kCloudUnroll; ++u) {
                 const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
@@ -714,11 +716,11 @@ __global__ __launch_bounds__(kBlock) void k_rotate_clouds(const float *__restric
                 const float qz = fmaf(r6, px, fmaf(r7, py, r8 * pz));
                 const int i = i0 + 64 * u + lane;
                 if (TRANSPOSED) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qx), rx, i * 4, 0, so3::kStreamCpol);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qy), ry, i * 4, 0, so3::kStreamCpol);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qz), rz, i * 4, 0, so3::kStreamCpol);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qx), rx, i * 4, 0, so3::kStreamNt);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qy), ry, i * 4, 0, so3::kStreamNt);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(qz), rz, i * 4, 0, so3::kStreamNt);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro, i * 12, 0, so3::kStreamCpol);
+                    __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro, i * 12, 0, so3::kStreamNt);
                 }
             }
         }
@@ -756,7 +758,7 @@ __global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict
         u32x3 pp[kU];
         for (int i0 = 0; i0 < N; i0 += 64 * kU) {
 #pragma unroll
-            for (int u = 0; u < kU; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, HOLD > 0 ? so3::kStreamCpol : 0);
+            for (int u = 0; u < kU; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, HOLD > 0 ? so3::kStreamNt : 0);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 const bool in = i0 + 64 * u + lane < N;
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(kBlock) void k_pc_normalize(const float *__restrict
                 const float qx = (__uint_as_float(pp[u].x) - c[0]) * inv, qy = (__uint_as_float(pp[u].y) - c[1]) * inv,
                             qz = (__uint_as_float(pp[u].z) - c[2]) * inv;
                 __builtin_amdgcn_raw_buffer_store_b96(u32x3{__float_as_uint(qx), __float_as_uint(qy), __float_as_uint(qz)}, ro,
-                                                      (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+                                                      (i0 + 64 * u + lane) * 12, 0, so3::kStreamNt);
             }
         }
     }
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void k_add_l1(const float *__restrict__ Tgt
         for (int i0 = 0; i0 < N; i0 += 64 * kAddUnroll) {
             u32x3 pp[kAddUnroll];
 #pragma unroll
-            for (int u = 0; u < kAddUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamCpol);
+            for (int u = 0; u < kAddUnroll; ++u) pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamNt);
 #pragma unroll
             for (int u = 0; u < kAddUnroll; ++u) {
                 const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
@@ -1223,15 +1225,15 @@ inline int device_cus() {
     return cus[dev];
 }
 
-// Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads.
-// DYN: one workgroup per CU (BLOCK must be 64 * 4 * WPS), rounds claimed from a ticket counter; PF: rounds in flight.
+// Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads;
+// DMA: inputs straight into LDS (float32 inputs only).
 // The name of a k_rows instantiation as a profiler prints it: the runtime's own (mangled) name of the kernel behind the host
 // stub, demangled, without the "void " in front and the parameter list behind.
 thread_local const char *g_last_kernel = "";
-template <class Op, int NPL, int WPS, int BLOCK, bool DYN, int PF>
+template <class Op, int NPL, int WPS, int BLOCK, bool DMA>
 const char *rows_kernel_name(hipStream_t s) {
     static const std::string name = [s] {
-        const char *mangled = hipKernelNameRefByPtr(reinterpret_cast<const void *>(&so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), s);
+        const char *mangled = hipKernelNameRefByPtr(reinterpret_cast<const void *>(&so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), s);
         if (mangled == nullptr) return std::string("so3::k_rows<?>");
         int status = 0;
         char *d = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
@@ -1249,16 +1251,15 @@ const char *rows_kernel_name(hipStream_t s) {
     return name.c_str();
 }
 
-template <int NPL, int WPS, int BLOCK, bool DYN = false, int PF = 1, class Op>
+template <int NPL, int WPS, int BLOCK, bool DMA = false, class Op>
 void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     constexpr int kWaves = BLOCK / 64;
-    g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK, DYN, PF>(s);
-    static_assert(!DYN || BLOCK == 64 * 4 * WPS, "a ticketed workgroup fills its CU");
+    g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK, DMA>(s);
     const int64_t rounds = (nunits + NPL - 1) / NPL;
-    const int64_t want = DYN ? rounds : (rounds + kWaves - 1) / kWaves;
-    const int64_t cap = DYN ? device_cus() : static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;   // CUs x 4 SIMDs x WPS wave slots
+    const int64_t want = (rounds + kWaves - 1) / kWaves;
+    const int64_t cap = static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;   // CUs x 4 SIMDs x WPS wave slots
     const dim3 grid(static_cast<unsigned>(want < cap ? want : cap)), block(BLOCK);
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), grid, block, 0, s, op, nunits, nullptr);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), grid, block, 0, s, op, nunits, nullptr);
 }
 
 // Rows [0, 64*nunits) go to the engine when every pointer is dword aligned (every float32 array is; a bfloat16 view that
@@ -1294,15 +1295,10 @@ inline const void *advance_bytes(const void *p, int64_t bytes) { return p ? stat
 inline void *advance_bytes(void *p, int64_t bytes) { return p ? static_cast<char *>(p) + bytes : nullptr; }
 
 // ---- K1 --------------------------------------------------------------------------------------------
-#ifndef SO3_K1_DYN
-#define SO3_K1_DYN 0
+#ifndef SO3_K1_DMA
+#define SO3_K1_DMA 0
 #endif
-#ifndef SO3_K1_PF
-#define SO3_K1_PF 1
-#endif
-constexpr bool K1_DYN = SO3_K1_DYN != 0;
-constexpr int K1_PF = SO3_K1_PF;
-constexpr int K1_BLOCK = K1_DYN ? 768 : 256;
+constexpr bool K1_DMA = SO3_K1_DMA != 0;
 template <bool BF16>
 int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
@@ -1312,8 +1308,9 @@ int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream)
     constexpr int EB = BF16 ? 2 : 4;
     const int64_t nunits = stream_units(B, {M, R});
     if (nunits > 0) {
-        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, K1_BLOCK, K1_DYN, K1_PF>(op, nunits, s); }
-        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, K1_BLOCK, K1_DYN, K1_PF>(op, nunits, s); }
+        constexpr bool kDma = K1_DMA && !BF16;
+        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256, kDma>(op, nunits, s); }
+        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256, kDma>(op, nunits, s); }
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {

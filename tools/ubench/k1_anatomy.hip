@@ -1,6 +1,6 @@
 // k1_anatomy: stand-alone timing / in-kernel-stamp tool for the streaming K1 kernel.
-// Instantiates the SAME kernel template the library ships (csrc/so3_rows.h) in several
-// geometries, times each with hipEvents over rotating buffers, and (STAMP build of the same
+// Instantiates the SAME kernel template the library ships (csrc/so3_rows.h) -- K1 and a copy through the engine,
+// register-staged and LDS-DMA -- times each with hipEvents over rotating buffers, and (STAMP build of the same
 // template) reports per-wave lifetimes and the shader clock from s_memtime / s_memrealtime.
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -o k1_anatomy k1_anatomy.hip
 #include <hip/hip_runtime.h>
@@ -27,73 +27,76 @@ __global__ void fill(float *p, int64_t n, unsigned seed) {
     }
 }
 
-// MODE 0: persistent waves, static deal (round-1 geometry).  MODE 1: one workgroup per CU, rounds claimed from an LDS
-// ticket counter (DYN).  MODE 2: not persistent -- one round per wave, the hardware dispatcher balances.
-template <int NPL, int WPS, int SWEEPS, bool ADAPT, int BLOCK = 256, int MODE = 0, int PF = 1>
-void run(float **in, float **out, unsigned long long *stamps_d) {
-    constexpr bool DYN = MODE == 1;
+// The engine moving bytes with no arithmetic: what the data path alone costs (this tool's own operation -- the product
+// headers carry no copy mode).
+struct OpCopy : so3::OpBase {
+    static constexpr int kIn0 = 4, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(so3::Rows<T, OpCopy> &rows, so3::RowCtx<NPL> &) const {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rows.o0[i] = rows.a[i];
+    }
+};
+
+template <class Op, int NPL, int WPS, bool DMA, int BLOCK = 256>
+void run(const char *what, float **in, float **out, unsigned long long *stamps_d) {
     const int64_t nunits = ROWS / 64;
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     constexpr int kW = BLOCK / 64;
     const int64_t want = (rounds + kW - 1) / kW;
-    const unsigned blocks = MODE == 2 ? (unsigned)want : (unsigned)std::min<int64_t>(DYN ? rounds : want, 256LL * 4 * WPS / kW);
+    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    typedef so3::OpProject<4, false, SWEEPS, ADAPT> Op;
     auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
     const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
     CHECK(hipMemset(stamps_d, 0, 8 * 46 * 8192));
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true, DYN, PF>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
-    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, MODE == 1 ? (int64_t)blocks * kW : rounds);
-    std::vector<unsigned long long> st6(6 * nw); std::vector<unsigned long long> st(4 * nw);
+    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, rounds);
+    std::vector<unsigned long long> st6(6 * nw);
     CHECK(hipMemcpy(st6.data(), stamps_d, st6.size() * 8, hipMemcpyDeviceToHost));
     std::vector<unsigned long long> rs(40 * nw);
     CHECK(hipMemcpy(rs.data(), stamps_d + 6 * (int64_t)blocks * kW, rs.size() * 8, hipMemcpyDeviceToHost));
-    double stall = 0, fw = 0;
-    for (int64_t w = 0; w < nw; ++w) { for (int j = 0; j < 4; ++j) st[4 * w + j] = st6[6 * w + j]; stall += (double)(st6[6 * w + 4] & 0xFFFFFFFFFFFFull); fw += (double)st6[6 * w + 5]; }
-    printf("   [stamped] mean cycles per wave waiting for prefetched units: %.0f ; first unit arrived after %.0f cycles\n", stall / nw, fw / nw);
     unsigned long long r0 = ~0ull, r1 = 0; double life = 0, clk = 0; std::vector<double> starts;
     for (int64_t w = 0; w < nw; ++w) {
-        r0 = std::min(r0, st[4 * w]); r1 = std::max(r1, st[4 * w + 1]);
-        life += (double)(st[4 * w + 1] - st[4 * w]);
-        clk += (double)(st[4 * w + 3] & 0xFFFFFFFull) / (double)(st[4 * w + 1] - st[4 * w]);
+        r0 = std::min(r0, st6[6 * w]); r1 = std::max(r1, st6[6 * w + 1]);
+        life += (double)(st6[6 * w + 1] - st6[6 * w]);
+        clk += (double)(st6[6 * w + 3] & 0xFFFFFFFull) / (double)(st6[6 * w + 1] - st6[6 * w]);
     }
-    for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st[4 * w] - r0) * 0.01);
+    for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st6[6 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
-    {   // per-wave dump for offline analysis: wave, rounds, start_us, end_us, cycles, hw_id, xcc
-        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_pf%d_m%d_b%d_npl%d_wps%d_s%d%s.csv", PF, MODE, BLOCK, NPL, WPS, SWEEPS, ADAPT ? "a" : "");
+    {   // per-wave dump for offline analysis (tools/wave_csv.py, tools/phase_csv.py)
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_dma%d_npl%d_wps%d.csv", what, DMA ? 1 : 0, NPL, WPS);
         FILE *fh = fopen(name, "w");
         if (fh) {
             fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc,first_wait_cyc,phases\n");
-            const int64_t nwv = (int64_t)blocks * kW;
             for (int64_t w = 0; w < nw; ++w) {
-                const int64_t nr = (int64_t)(st6[6 * w + 4] >> 48); (void)nwv;
-                fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu,%llu", (long long)w, (long long)nr, (double)(st[4 * w] - r0) * 0.01,
-                        (double)(st[4 * w + 1] - r0) * 0.01, st[4 * w + 3] & 0xFFFFFFFull, st[4 * w + 3] >> 32, (st[4 * w + 3] >> 28) & 0xF, st6[6 * w + 5]);
+                const int64_t nr = (int64_t)(st6[6 * w + 4] >> 48);
+                fprintf(fh, "%lld,%lld,%.2f,%.2f,%llu,%llu,%llu,%llu", (long long)w, (long long)nr, (double)(st6[6 * w] - r0) * 0.01,
+                        (double)(st6[6 * w + 1] - r0) * 0.01, st6[6 * w + 3] & 0xFFFFFFFull, st6[6 * w + 3] >> 32, (st6[6 * w + 3] >> 28) & 0xF, st6[6 * w + 5]);
                 for (int j = 0; j < 40; ++j) fprintf(fh, "%s%.2f", j ? " " : ",", rs[40 * w + j] ? (double)(rs[40 * w + j] - r0) * 0.01 : -1.0);
                 fprintf(fh, "\n");
             }
             fclose(fh);
         }
     }
-    printf("pf=%d mode=%d NPL=%d WPS=%d sweeps=%d%s block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("%-8s dma=%d NPL=%d WPS=%d block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           PF, MODE, NPL, WPS, SWEEPS, ADAPT ? "+adaptive" : "", BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           what, DMA ? 1 : 0, NPL, WPS, BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
+    fflush(stdout);
 }
 
 int main(int argc, char **argv) {
-    const bool quick = argc > 1 && argv[1][0] == 'q';      // "quick": the shipped geometry only (A/B builds of the header)
     float *in[NBUF], *out[NBUF];
     for (int i = 0; i < NBUF; ++i) {
         CHECK(hipMalloc(&in[i], ROWS * 9 * 4)); CHECK(hipMalloc(&out[i], ROWS * 9 * 4));
@@ -101,14 +104,17 @@ int main(int argc, char **argv) {
     }
     unsigned long long *stamps; CHECK(hipMalloc(&stamps, 8 * 46 * 8192));
     CHECK(hipDeviceSynchronize());
-    if (quick) {
-        g_launches = 1000;
-        for (int rep = 0; rep < 4; ++rep) {
-            run<2, 3, 100, true, 256, 0, 1>(in, out, stamps);
-            run<2, 3, 100, true, 768, 1, 1>(in, out, stamps);
-        }
-        run<2, 3, -1, false, 256, 0, 1>(in, out, stamps);
-        return 0;
+    g_launches = argc > 1 ? atoi(argv[1]) : 1000;
+    typedef so3::OpProject<4, false> K1;
+    for (int rep = 0; rep < 3; ++rep) {
+        run<K1, 2, 3, false>("k1", in, out, stamps);
+        run<K1, 2, 3, true>("k1", in, out, stamps);
+        run<OpCopy, 2, 3, false>("copy", in, out, stamps);
+        run<OpCopy, 2, 3, true>("copy", in, out, stamps);
     }
+    run<K1, 2, 4, true>("k1", in, out, stamps);
+    run<OpCopy, 2, 4, true>("copy", in, out, stamps);
+    run<OpCopy, 1, 4, true>("copy", in, out, stamps);
+    run<OpCopy, 1, 8, true>("copy", in, out, stamps);
     return 0;
 }

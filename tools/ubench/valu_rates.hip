@@ -16,8 +16,10 @@ template <int MODE, int ACC>
 __global__ __launch_bounds__(256) void bench(float *out, unsigned long long *clk, float a, float b) {
     float x[ACC];
     float2v y[ACC];
+    double z[ACC];
 #pragma unroll
-    for (int i = 0; i < ACC; ++i) { x[i] = threadIdx.x * 1e-3f + i; y[i] = float2v{x[i], x[i] + 0.5f}; }
+    for (int i = 0; i < ACC; ++i) { x[i] = threadIdx.x * 1e-3f + i; y[i] = float2v{x[i], x[i] + 0.5f}; z[i] = x[i]; }
+    const double ad = a, bd = b;
     const float2v a2 = {a, a * 1.0001f}, b2 = {b, b * 0.9999f};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITERS; ++it) {
@@ -28,12 +30,16 @@ __global__ __launch_bounds__(256) void bench(float *out, unsigned long long *clk
             if (MODE == 2) x[i] = __builtin_amdgcn_rsqf(x[i]) + 1.5f;                 // v_rsq_f32 + v_add
             if (MODE == 3) x[i] = fmaf(x[i], x[i], b);                                // v_fma_f32, all-VGPR operands
             if (MODE == 4) x[i] = (x[i] > a) ? x[i] * b : x[i] + a;                   // cmp + cndmask + mul + add
+            if (MODE == 5) z[i] = __builtin_fma(z[i], ad, bd);                        // v_fma_f64
+            if (MODE == 6) { x[i] = x[i] + a; z[i] = z[i] + static_cast<double>(x[i]); }   // v_add_f32 + v_cvt_f64_f32 + v_add_f64
+            if (MODE == 7) { x[i] = x[i] + a; z[i] = z[i] + ad; }                     // v_add_f32 + v_add_f64
+            if (MODE == 8) z[i] = z[i] * ad;                                          // v_mul_f64
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
 #pragma unroll
-    for (int i = 0; i < ACC; ++i) s += x[i] + y[i].x + y[i].y;
+    for (int i = 0; i < ACC; ++i) s += x[i] + y[i].x + y[i].y + static_cast<float>(z[i]);
     if (s == 12345.678f) out[0] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = t1 - t0;
 }
@@ -61,6 +67,13 @@ void run(const char *name, int ops_per_inner, float *d, unsigned long long *clk,
 int main() {
     float *d; CHECK(hipMalloc(&d, 4));
     unsigned long long *clk; CHECK(hipMalloc(&clk, 8));
+    for (int bpc : {2, 4}) {
+        run<5, 1>("v_fma_f64", 1, d, clk, bpc);
+        run<5, 8>("v_fma_f64", 1, d, clk, bpc);
+        run<8, 8>("v_mul_f64", 1, d, clk, bpc);
+        run<6, 8>("add_f32+cvt_f64_f32+add_f64", 3, d, clk, bpc);
+        run<7, 8>("add_f32+add_f64", 2, d, clk, bpc);
+    }
     for (int bpc : {1, 2, 4, 8}) {
         run<0, 1>("v_fma_f32", 1, d, clk, bpc);
         run<0, 2>("v_fma_f32", 1, d, clk, bpc);
