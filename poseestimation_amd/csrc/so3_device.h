@@ -281,11 +281,28 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
 
     // 2. one-sided Jacobi on the columns
     V3<T> a0 = mk<T>(m[0], m[3], m[6]), a1 = mk<T>(m[1], m[4], m[7]), a2 = mk<T>(m[2], m[5], m[8]);
+    rotate(a0, a1);
+    rotate(a0, a2);
+    rotate(a1, a2);
+    // 2a. A matrix whose columns were orthogonal to begin with -- reflections and near-reflections, permutations, diagonal
+    // matrices: what the fast path hands over in bulk when it is given such a batch -- is done after ONE sweep: all three
+    // pairs are tested, a row that passes keeps these columns whatever its wave-mates need (per row, as everywhere), and
+    // the remaining sweeps are skipped when no row of the wave needs them (wave-uniform).
+    if (SWEEPS > 1) {
+        const T e0 = dot(a0, a0), e1 = dot(a1, a1), e2 = dot(a2, a2);
+        const T h01 = dot(a0, a1), h02 = dot(a0, a2), h12 = dot(a1, a2);
+        const T t2 = R::splat(K::tol2);
+        const typename R::mask early = R::le(h01 * h01, e0 * e1 * t2) & R::le(h02 * h02, e0 * e2 * t2) & R::le(h12 * h12, e1 * e2 * t2);
+        if (wave_any(R::any(R::mnot(early)))) {
+            const V3<T> f0 = a0, f1 = a1, f2 = a2;
 #pragma unroll
-    for (int sweep = 0; sweep < SWEEPS; ++sweep) {
-        rotate(a0, a1);
-        rotate(a0, a2);
-        rotate(a1, a2);
+            for (int sweep = 1; sweep < SWEEPS; ++sweep) {
+                rotate(a0, a1);
+                rotate(a0, a2);
+                rotate(a1, a2);
+            }
+            a0 = sel<T>(early, f0, a0); a1 = sel<T>(early, f1, a1); a2 = sel<T>(early, f2, a2);
+        }
     }
 
     // 2b. convergence test.  A cyclic sweep ends with rotation (1,2), which leaves gamma_12 = 0 and
@@ -437,7 +454,7 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 //         [  .             .              .          -m00-m11+m22    ]
 // whose eigenvalues are s1+s2+s3', s1-s2-s3', -s1+s2-s3', -s1-s2+s3' (s3' = det-signed): the gap between the two largest,
 // 2(s2+s3'), is the conditioning of R itself.  Per matrix:
-//   1. (no prescale: the method is homogeneous in M; rows far from unit scale are hard);
+//   1. (the method is homogeneous in M: only rows far from unit scale are prescaled, by a power of two, in a rare branch);
 //   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2):  started at s1 + s2 + s3' with the
 //      singular values from the closed-form roots of the cubic of M^T M (good to 5e-6 on the median row), then two Newton steps;
 //   3. q = the largest column of adj(lambda I - K) = (product of the three gaps) q q^T -- no division, no pivoting;
@@ -460,6 +477,7 @@ constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
 constexpr int kQuatExtra = 2;           // how many further refinements a row may take
 constexpr float kQuatConv = 4e-4f;
 constexpr float kQuatResid = 8e-7f;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
+constexpr float kQuatWindowLo = 3.7252903e-9f, kQuatWindowHi = 17179869184.0f;   // 2^-28 <= |M|_F^2 <= 2^34 (see quat_rotation, step 1)
 constexpr float kQuatCurv = 0.5f;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
 
 template <class T> struct Sym4 {        // symmetric 4x4, upper triangle
@@ -550,13 +568,35 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
 template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
-    // 1. no prescale: every step below is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the
-    // tests compare like with like), so the fast path works on the matrix as it comes as long as |M|_F^2 stays within
-    // [2^-28, 2^36] (third powers of it -- sixth powers of the entries -- stay finite, normal and a few orders clear of
-    // the underflow threshold: entries between 2e-5 and 8e4).  Rows outside that window are declared hard at the end:
-    // the Jacobi path brings its own power-of-two prescale.  (Prescaling here cost 9 packed and 16 plain instructions per
-    // pair of matrices for inputs -- network outputs -- that are O(1) anyway.)
-    const T (&m)[9] = m_in;
+    // 1. scale.  Every step below is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the tests
+    // compare like with like), so the fast path works on the matrix as it comes as long as |M|_F^2 stays within
+    // [2^-28, 2^34] (the Rayleigh quotient's numerator lambda |q|^2 ~ 64 lambda^7 must stay finite -- rows between 2^34.4 and
+    // 2^36, inside round 2's window, came out hard -- and sixth powers of the entries a few orders clear of the underflow
+    // threshold: entries between 2e-5 and 4e4).  Network outputs are O(1): no unconditional prescale (it cost
+    // 9 packed and 16 plain instructions per pair of matrices).
+    T m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = m_in[i];
+    T f = m[0] * m[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
+    // Rows outside the window get an exact power-of-two prescale (largest |entry| -> [0.5, 1); R does not depend on the scale)
+    // under a wave-uniform branch; rows inside it are multiplied by 1 -- their bits do not change.  Zero, infinite and NaN
+    // rows stay outside the window and are declared hard at the end.
+    {
+        const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
+        if (__builtin_expect(wave_any(R::any(R::mnot(inside))), 0)) {
+            T mx = R::max(R::max(R::abs(m[0]), R::abs(m[1])), R::abs(m[2]));
+            mx = R::max(mx, R::max(R::max(R::abs(m[3]), R::abs(m[4])), R::abs(m[5])));
+            mx = R::max(mx, R::max(R::max(R::abs(m[6]), R::abs(m[7])), R::abs(m[8])));
+            const T sc = R::sel(inside, R::splat(S(1)), R::ldexp(R::splat(S(1)), R::neg_frexp_exp(mx)));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) m[i] = m[i] * sc;
+            f = m[0] * m[0];
+#pragma unroll
+            for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
+        }
+    }
     // 2. K (order w, x, y, z)
     const T tr = (m[0] + m[4]) + m[8];
     const T two = R::splat(S(2));
@@ -565,9 +605,6 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     k.a01 = m[7] - m[5]; k.a02 = m[2] - m[6]; k.a03 = m[3] - m[1];
     k.a12 = m[1] + m[3]; k.a13 = m[2] + m[6]; k.a23 = m[5] + m[7];
     // 3. the characteristic quartic  l^4 + c2 l^2 + c1 l + c0
-    T f = m[0] * m[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
     const T g00 = R::fma(m[4], m[8], -(m[5] * m[7])), g01 = R::fma(m[5], m[6], -(m[3] * m[8])), g02 = R::fma(m[3], m[7], -(m[4] * m[6]));
     const T g10 = R::fma(m[2], m[7], -(m[1] * m[8])), g11 = R::fma(m[0], m[8], -(m[2] * m[6])), g12 = R::fma(m[1], m[6], -(m[0] * m[7]));
     const T g20 = R::fma(m[1], m[5], -(m[2] * m[4])), g21 = R::fma(m[2], m[3], -(m[0] * m[5])), g22 = R::fma(m[0], m[4], -(m[1] * m[3]));
@@ -640,11 +677,14 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
     // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
     // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
-    // A row whose gap product sits at the adjugate's own round-off (an eighth of the second pass's threshold) cannot be settled
+    // A row whose gap product does not reach half the second pass's threshold, or whose curvature P'' does not reach half of
+    // criterion (4)'s bar (a near-reflection: refining lambda does not move either by a factor of two), cannot be settled
     // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
     // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
     // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
-    const typename R::mask hopeless = R::mnot(R::gt(trace, ((lam2 * lam2) * lam2) * R::splat(S(0.125f * kQuatTau2))));
+    const T l22 = lam2 * lam2;
+    const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
+                                              & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
     typename R::mask frozen = settled | hopeless;
 #pragma unroll 1
     for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
@@ -669,7 +709,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
     r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    const typename R::mask in_window = R::ge(f, R::splat(S(3.7252903e-9))) & R::le(f, R::splat(S(68719476736.0)));   // 2^-28 <= |M|_F^2 <= 2^36
+    const typename R::mask in_window = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
     return R::mnot(settled & finite & in_window);
 }
 

@@ -42,7 +42,7 @@ def test_bench_json_contract(mode):
     assert d["ms_per_step_events"] <= d["ms_per_step"] and abs(r["avg_launch_us"] - d["ms_per_step_events"] * 1e3) < 1e-6
     assert r["traffic"] is None or "stored profile" in r["traffic_source"]
     # the kernel is named by the library from the launch's own template arguments, not by a literal in bench.py
-    assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false,") and r["kernel"].endswith(">")
+    assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false>,") and r["kernel"].endswith(">")
     if mode == "graph":
         assert d["pre_timing"]["replays"] >= 1 and d["pre_timing"]["ms"] <= 200.0
 
