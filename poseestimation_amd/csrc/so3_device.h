@@ -565,7 +565,13 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
-template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9]) {
+// `prescale` (optional): the exact power of two a row outside the scale window was multiplied by (1 elsewhere) -- the backward
+// from the rotation works on the same prescaled matrix.
+template <class T> struct Prescale {
+    T factor;
+    bool any;          // wave-uniform: some row of the wave has factor != 1
+};
+template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9], Prescale<T> *prescale = nullptr) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
     // 1. scale.  Every step below is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the tests
@@ -585,11 +591,14 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // rows stay outside the window and are declared hard at the end.
     {
         const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
-        if (__builtin_expect(wave_any(R::any(R::mnot(inside))), 0)) {
+        const bool any_outside = wave_any(R::any(R::mnot(inside)));
+        if (prescale != nullptr) { prescale->factor = R::splat(S(1)); prescale->any = any_outside; }
+        if (__builtin_expect(any_outside, 0)) {
             T mx = R::max(R::max(R::abs(m[0]), R::abs(m[1])), R::abs(m[2]));
             mx = R::max(mx, R::max(R::max(R::abs(m[3]), R::abs(m[4])), R::abs(m[5])));
             mx = R::max(mx, R::max(R::max(R::abs(m[6]), R::abs(m[7])), R::abs(m[8])));
             const T sc = R::sel(inside, R::splat(S(1)), R::ldexp(R::splat(S(1)), R::neg_frexp_exp(mx)));
+            if (prescale != nullptr) prescale->factor = sc;
 #pragma unroll
             for (int i = 0; i < 9; ++i) m[i] = m[i] * sc;
             f = m[0] * m[0];
@@ -725,10 +734,11 @@ template <class T> struct HardRows {
     typename Tr<T>::mask hard;       // which rows took the Jacobi path (their backward must, too)
     bool any;                        // wave-uniform: does `frames` hold anything
     SignedSvd<T> frames;
+    Prescale<T> prescale;            // of the rows the fast path settled (WANT_BWD only)
 };
 template <bool WANT_BWD, class T> __device__ __forceinline__ void project_rotation_frames(const T (&m)[9], T (&r)[9], HardRows<T> &h) {
     typedef Tr<T> R;
-    h.hard = quat_rotation<T>(m, r);
+    h.hard = quat_rotation<T>(m, r, WANT_BWD ? &h.prescale : nullptr);
     h.any = wave_any(R::any(h.hard));
     if (__builtin_expect(h.any, 0)) {
         h.frames = signed_svd<WANT_BWD, T>(m);
@@ -843,7 +853,18 @@ __device__ __forceinline__ void backward_from_rotation(const T (&m)[9], const T 
 template <class T>
 __device__ __forceinline__ void backward_given_rotation(const T (&m)[9], const T (&r)[9], const T (&g)[9], const HardRows<T> &h, T (&dm)[9]) {
     typedef Tr<T> R;
-    backward_from_rotation<T>(m, r, g, dm);
+    if (__builtin_expect(h.prescale.any, 0)) {
+        // rows outside the fast path's scale window: S = R^T M, its cofactors and determinant are formed from the prescaled
+        // matrix (third powers of the entries), and dM(c M) = dM(M) / c
+        T ms[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) ms[j] = m[j] * h.prescale.factor;
+        backward_from_rotation<T>(ms, r, g, dm);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) dm[j] = dm[j] * h.prescale.factor;
+    } else {
+        backward_from_rotation<T>(m, r, g, dm);
+    }
     if (__builtin_expect(h.any, 0)) {
         T dj[9];
         project_backward(h.frames, g, dj);

@@ -161,6 +161,18 @@ def test_model_backward_against_the_closed_form(km):
     # rank-deficient rows: floored denominators, finite gradients
     low = (rng.standard_normal((1000, 3, 1)) @ rng.standard_normal((1000, 1, 3))).astype(np.float32)
     assert np.isfinite(km.project_bwd(low, g[:1000])).all()
+    # rows outside the fast path's scale window: the rotation comes from the prescaled matrix, and so must the gradient
+    # (S = R^T M, its cofactors and determinant would leave the float32 range): dM(c M) = dM(M) / c, exactly for powers of two
+    base = km.project_bwd(x[:4096], g[:4096])
+    for scale in (2.0 ** 40, 2.0 ** -40, 1e18, 1e-18):
+        xs = (scale * x[:4096]).astype(np.float32)
+        d = km.project_bwd(xs, g[:4096])
+        assert np.isfinite(d).all(), scale
+        refs = so.projection_backward_np(xs, g[:4096])
+        rel = np.abs(d - refs).reshape(4096, -1).max(1) / np.abs(refs).reshape(4096, -1).max(1)
+        assert np.median(rel) < 5e-7 and rel.max() < 1e-3, scale
+        if np.log2(scale) == round(np.log2(scale)):
+            assert np.array_equal(d * np.float32(scale), base), scale
 
 
 def test_model_backward_on_ill_conditioned_settled_rows_is_as_good_as_float32_autograd(km):
