@@ -122,6 +122,31 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
 int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
                                 int32_t *range_flag, int radians, int64_t B, void *stream);
 
+/* ---- the same reductions with a caller-owned WORKSPACE and the mean written by the kernel ---------------------------
+ * K3, K3', K4 and K1+K4 reduce over the batch (loss_sum, sum_count, range_flag).  The entry points above zero those
+ * accumulators with a memset / 1-thread launch in front of the kernel and add to them with one atomic per workgroup.
+ * With a workspace every workgroup parks its partial in a slot of its own, and the last one to finish (a ticket) sums the
+ * slots in a fixed order and writes the results with plain stores: one launch less per call (1.5-2 us of a 15-30 us call at
+ * 1M rows), and the same input gives the same bits whatever order the workgroups retire in.
+ *   workspace  so3_reduce_workspace_bytes() bytes of device memory owned by the caller, ZERO-FILLED ONCE before its first
+ *              use (every call leaves it zeroed), used by ONE stream at a time.  NULL selects the behaviour of the entry
+ *              points above.  (Batches of <= 1024 rows run as one workgroup and never touch it; input that cannot take the
+ *              streaming engine -- e.g. a bfloat16 view starting at an odd row -- falls back to the memset + atomics path.)
+ *   loss_mean  out optional 1 float: (float)(loss_sum / B) -- what loss_frobenius returns (3D-Pose/loss.py:11), so the host
+ *              side needs no launch of its own to turn the float64 sum into the float32 mean.
+ * Everything else as in so3_frob_fwd_bwd_* / so3_frob_loss_f32 / so3_angle_error / so3_project_angle_error_f32. */
+size_t so3_reduce_workspace_bytes(void);
+int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
+                            void *workspace, int64_t B, void *stream);
+int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean,
+                             void *workspace, int64_t B, void *stream);
+int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean,
+                         void *workspace, int64_t B, void *stream);
+int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                       void *workspace, int64_t B, void *stream);
+int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                   int32_t *range_flag, int radians, void *workspace, int64_t B, void *stream);
+
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
  * point_cloud/main.py:43-57). */

@@ -31,6 +31,12 @@ SYMBOLS = {
     "so3_angle_error": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_project_angle_error_f32": (_INT, [_P, _P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
+    "so3_reduce_workspace_bytes": (ctypes.c_size_t, []),
+    "so3_frob_fwd_bwd_ws_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "so3_frob_fwd_bwd_ws_bf16": (_INT, [_P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "so3_frob_loss_ws_f32": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "so3_angle_error_ws": (_INT, [_P, _P, _P, _P, _P, _INT, _P, _I64, _P]),
+    "so3_project_angle_error_ws_f32": (_INT, [_P, _P, _P, _P, _P, _P, _INT, _P, _I64, _P]),
     "so3_se3_update_f32": (_INT, [_P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),
     "so3_se3_update_bwd_f32": (_INT, [_P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I64, _P]),
     "so3_ortho6d_fwd_f32": (_INT, [_P, _P, _I64, _P]),

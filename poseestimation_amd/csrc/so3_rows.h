@@ -169,6 +169,69 @@ template <int BYTES> __device__ __forceinline__ rsrc_t row_rsrc(void *base, int6
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, exists ? kUnitRows * BYTES : 0, kRsrcFlags);
 }
 
+// ---- reductions without a zero-fill launch and without atomics on the result ----------------------------------
+// A caller-owned WORKSPACE (so3_reduce_workspace_bytes(), zero-filled once, used by one stream at a time): every workgroup adds
+// its partial to its own slot (the slot holds 0, so the slot becomes the partial exactly; float64 atomics execute at the
+// memory side, coherent across the XCDs), takes a ticket, and the workgroup that draws the last ticket sums the slots in a
+// fixed order, writes the result and leaves slots, flag and ticket zeroed for the next call.  Against round 2 (a memset or
+// 1-thread init launch in front of the kernel, one same-address atomic per workgroup behind it) that is one launch less per
+// call, and the sum no longer depends on the order in which workgroups retire: the same input gives the same bits.
+constexpr int kMaxPartials = 4094;
+struct ReduceWs {
+    unsigned int ticket;
+    int flag;
+    unsigned int pad[2];
+    double part[kMaxPartials];
+};
+static_assert(sizeof(ReduceWs) == 32768, "so3_reduce_workspace_bytes()");
+
+__device__ __forceinline__ double coherent_f64(const double *p) {         // other workgroups' atomics, read past the L2 of this XCD
+    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Called by ALL threads of a workgroup at the end of the kernel; wg_total / wg_flag are thread 0's.  `expected` = how many
+// workgroups take tickets in this launch (0: publish only -- a remainder kernel whose partials the following launch collects),
+// `npart` = slots to sum.  write_result(total, any_flag) runs on thread 0 of the last workgroup.
+template <int BLOCK, class F>
+__device__ __forceinline__ void ticket_finish(ReduceWs *ws, unsigned slot, unsigned expected, unsigned npart, double wg_total, bool wg_flag,
+                                              F &&write_result) {
+    __shared__ int is_last;
+    __shared__ double fin[BLOCK / 64];
+    if (threadIdx.x == 0) {
+        atomicAdd(&ws->part[slot], wg_total);
+        if (wg_flag) atomicOr(&ws->flag, 1);
+        int last = 0;
+        if (expected != 0) {
+            // the partial is acknowledged by the memory side (it leaves vmcnt) before the ticket is drawn
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __threadfence();
+            last = atomicAdd(&ws->ticket, 1u) == expected - 1 ? 1 : 0;
+            if (last) __threadfence();
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    double v = 0.0;
+    for (unsigned i = threadIdx.x; i < npart; i += BLOCK) {            // thread t sums slots t, t + BLOCK, ...: a fixed order
+        v += coherent_f64(&ws->part[i]);
+        __hip_atomic_store(&ws->part[i], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) fin[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) total += fin[w];
+        const int flag = __hip_atomic_load(&ws->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        write_result(total, flag != 0);
+        __hip_atomic_store(&ws->flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 #endif  // !SO3_HOST_MODEL
 
 template <int NPL> struct LaneT;
@@ -383,12 +446,17 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         const bool any_flag = __any(ctx.flag);
         if (lane == 0) { red[wave_in_block] = v; red_flag[wave_in_block] = any_flag ? 1 : 0; }
         __syncthreads();
+        double total = 0.0;
+        int f = 0;
         if (threadIdx.x == 0) {
-            double total = 0.0;
-            int f = 0;
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) { total += red[w]; f |= red_flag[w]; }
-            op.finish(total, f != 0);
+        }
+        if (op.ws == nullptr) {                             // no workspace: atomics onto accumulators the host initialised
+            if (threadIdx.x == 0) op.finish(total, f != 0);
+        } else {
+            ticket_finish<BLOCK>(op.ws, op.ws_slot0 + blockIdx.x, gridDim.x, op.ws_slot0 + gridDim.x, total, f != 0,
+                                 [&](double t, bool any) { op.finish_total(t, any); });
         }
     }
     if (STAMP && wave_id < nrounds) {
@@ -417,7 +485,12 @@ struct OpBase {
     const void *in0 = nullptr, *in1 = nullptr, *in2 = nullptr;
     void *out0 = nullptr, *out1 = nullptr;
     static constexpr bool kReduce = false;
+#ifndef SO3_HOST_MODEL
+    ReduceWs *ws = nullptr;        // reduction workspace (nullptr: atomics onto host-initialised accumulators)
+    unsigned ws_slot0 = 0;         // slots below this one were filled by the remainder kernel launched before the engine
+#endif
     __device__ __forceinline__ void finish(double, bool) const {}
+    __device__ __forceinline__ void finish_total(double, bool) const {}
 };
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
@@ -491,7 +564,13 @@ struct OpFrobHead : OpBase {
             backward_given_rotation<T>(m, r, g, hard, dm);
         }
     }
+    float *loss_mean = nullptr;
+    double inv_b_f64 = 0.0;
     __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
+    __device__ __forceinline__ void finish_total(double total, bool) const {
+        *loss_sum = total;
+        if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * inv_b_f64);
+    }
 };
 
 // K3': stand-alone Frobenius loss (3D-Pose/loss.py:7-11).  out0 = d(mean loss)/dRpred (optional).
@@ -519,7 +598,13 @@ struct OpFrobLoss : OpBase {
 #pragma unroll
         for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
     }
+    float *loss_mean = nullptr;
+    double inv_b_f64 = 0.0;
     __device__ __forceinline__ void finish(double total, bool) const { atomicAdd(loss_sum, total); }
+    __device__ __forceinline__ void finish_total(double total, bool) const {
+        *loss_sum = total;
+        if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * inv_b_f64);
+    }
 };
 
 // acos in float64 to 1.4e-14 rad (the metric is compared at 1e-9 degrees): |c| <= 1/2: pi/2 - asin(c); otherwise through
@@ -574,9 +659,14 @@ struct OpAngle : OpBase {
             if (WANT_SUM && ctx.exists[k]) ctx.acc += ang;
         }
     }
+    double count = 0.0;
     __device__ __forceinline__ void finish(double total, bool any_flag) const {
         if (WANT_SUM) atomicAdd(sum_count, total);
         if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
+    }
+    __device__ __forceinline__ void finish_total(double total, bool any_flag) const {
+        if (WANT_SUM) { sum_count[0] = total; sum_count[1] = count; }
+        if (range_flag != nullptr) *range_flag = any_flag ? 1 : 0;
     }
 };
 
@@ -615,9 +705,14 @@ struct OpProjectAngle : OpBase {
             if (WANT_SUM && ctx.exists[k]) ctx.acc += ang;
         }
     }
+    double count = 0.0;
     __device__ __forceinline__ void finish(double total, bool any_flag) const {
         if (WANT_SUM) atomicAdd(sum_count, total);
         if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
+    }
+    __device__ __forceinline__ void finish_total(double total, bool any_flag) const {
+        if (WANT_SUM) { sum_count[0] = total; sum_count[1] = count; }
+        if (range_flag != nullptr) *range_flag = any_flag ? 1 : 0;
     }
 };
 

@@ -166,11 +166,18 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /* >= 4 do
     return scratch[0] + scratch[1] + scratch[2] + scratch[3];
 }
 
+// A remainder kernel's share of a workspace reduction (so3_rows.h): its workgroups fill slots [0, gridDim.x) and take no
+// ticket; the engine launch that follows on the stream sums them with its own.
+__device__ __forceinline__ void publish_partial(so3::ReduceWs *ws, double total, bool flag) {
+    atomicAdd(&ws->part[blockIdx.x], total);
+    if (flag) atomicOr(&ws->flag, 1);
+}
+
 // ---- K3 -------------------------------------------------------------------------------------------
 template <bool BF16, bool VEC, bool WANT_R, bool WANT_DM>
 __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict__ M, const float *__restrict__ Rtrue,
                                                          float *__restrict__ R, void *__restrict__ dM,
-                                                         double *__restrict__ loss_sum, int64_t B, float inv_b) {
+                                                         double *__restrict__ loss_sum, int64_t B, float inv_b, so3::ReduceWs *ws) {
     __shared__ __attribute__((aligned(16))) float tile_m[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
     __shared__ double red[4];
@@ -212,7 +219,10 @@ __global__ __launch_bounds__(kBlock) void k_frob_fwd_bwd(const void *__restrict_
     // one float64 atomic per workgroup: same-address atomics cost ~12 ns each (one per 256-row tile made this
     // kernel atomic-bound: 59 us per 1M rows)
     const double total = block_sum(acc, red);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+    if (threadIdx.x == 0) {
+        if (ws != nullptr) publish_partial(ws, total, false);
+        else atomicAdd(loss_sum, total);
+    }
 }
 
 // K3 for a batch that fits ONE workgroup (config #4: B = 512): one row per thread, rows read and written straight from
@@ -222,7 +232,7 @@ constexpr int kSmallBatch = 1024;
 template <bool BF16, bool WANT_R, bool WANT_DM>
 __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restrict__ M, const float *__restrict__ Rtrue,
                                                             float *__restrict__ R, void *__restrict__ dM,
-                                                            double *__restrict__ loss_sum, int B, float inv_b) {
+                                                            double *__restrict__ loss_sum, float *__restrict__ loss_mean, int B, float inv_b) {
     __shared__ double red[kSmallBatch / 64];
     const int b = threadIdx.x;
     const bool active = b < B;
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
         double total = 0.0;
         for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
         *loss_sum = total;
+        if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * (1.0 / static_cast<double>(B)));   // float64 sum / B, rounded once
     }
 }
 
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
 template <bool VEC, bool WANT_GRAD>
 __global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ Rpred, const float *__restrict__ Rtrue,
                                                       float *__restrict__ dRpred, double *__restrict__ loss_sum,
-                                                      int64_t B, float inv_b) {
+                                                      int64_t B, float inv_b, so3::ReduceWs *ws) {
     __shared__ __attribute__((aligned(16))) float tile_p[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_t[kTileFloats];
     __shared__ double red[4];
@@ -314,7 +325,10 @@ __global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ 
         }
     }
     const double total = block_sum(acc, red);          // one atomic per workgroup
-    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+    if (threadIdx.x == 0) {
+        if (ws != nullptr) publish_partial(ws, total, false);
+        else atomicAdd(loss_sum, total);
+    }
 }
 
 // K3' for a launch-bound batch (B <= kSmallBatch): one workgroup, one row per thread, loss_sum written with a plain
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_frob_loss(const float *__restrict__ 
 template <bool WANT_GRAD>
 __global__ __launch_bounds__(kSmallBatch) void k_frob_loss_small(const float *__restrict__ Rpred, const float *__restrict__ Rtrue,
                                                                  float *__restrict__ dRpred, double *__restrict__ loss_sum,
-                                                                 int B, float inv_b) {
+                                                                 float *__restrict__ loss_mean, int B, float inv_b) {
     __shared__ double red[kSmallBatch / 64];
     const int b = threadIdx.x;
     const bool active = b < B;
@@ -346,14 +360,21 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_loss_small(const float *__
         double total = 0.0;
         for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
         *loss_sum = total;
+        if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * (1.0 / static_cast<double>(B)));
     }
+}
+
+// float32 mean from the float64 sum once the kernels before it on the stream are done (batches too large for one workgroup,
+// no workspace: the atomics' total is only complete at the end of the launch)
+__global__ void k_mean_from_sum(const double *__restrict__ loss_sum, float *__restrict__ loss_mean, double inv_b) {
+    *loss_mean = static_cast<float>(*loss_sum * inv_b);
 }
 
 // ---- K4 -------------------------------------------------------------------------------------------
 template <bool VEC, bool WANT_DEG, bool WANT_SUM>
 __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict__ R1, const float *__restrict__ R2,
                                                         double *__restrict__ out, double *__restrict__ sum_count,
-                                                        int32_t *__restrict__ range_flag, double unit, int64_t B) {
+                                                        int32_t *__restrict__ range_flag, double unit, int64_t B, so3::ReduceWs *ws) {
     __shared__ __attribute__((aligned(16))) float tile_a[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_b[kTileFloats];
     __shared__ double red[4];
@@ -374,14 +395,16 @@ __global__ __launch_bounds__(kBlock) void k_angle_error(const float *__restrict_
     double c = fmin(fmax(c_raw, -1.0), 1.0);                   // torch.clamp ...
     if (c_raw != c_raw) c = c_raw;                             // ... which keeps NaN (fmin/fmax drop it)
     const double ang = so3::acos_f64(c) * unit;
-    if (range_flag != nullptr && __any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
+    if (__any(bad) && (threadIdx.x & 63) == 0) {
+        if (ws != nullptr) atomicOr(&ws->flag, 1);
+        else if (range_flag != nullptr) atomicOr(range_flag, 1);
     }
     if (WANT_DEG && active) out[first + threadIdx.x] = ang;
     if (WANT_SUM) {
         const double total = block_sum(active ? ang : 0.0, red);
         if (threadIdx.x == 0) {
-            atomicAdd(sum_count, total);       // the row count is written once by k_set_count
+            if (ws != nullptr) publish_partial(ws, total, false);
+            else atomicAdd(sum_count, total);  // the row count is written once by k_angle_init
         }
     }
 }
@@ -1055,9 +1078,7 @@ struct StatWork {                                  // layout of the caller's wor
 __device__ __forceinline__ unsigned int coherent_u32(const unsigned int *p) {     // other workgroups' atomics, read past L1
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double coherent_f64(const double *p) {
-    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+using so3::coherent_f64;
 
 // LDS: workgroup-private histograms first (early passes put almost every row into one or two digits -- the
 // exponent bytes -- and a million same-address global atomics would serialise), then one flush per bin.
@@ -1354,34 +1375,42 @@ int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream
 }
 
 // ---- K3 --------------------------------------------------------------------------------------------
+// How a reduction over a large batch is finished.  With a workspace (and whole units on the engine): the remainder kernel,
+// if any, runs FIRST and fills slots [0, tile_wgs); the engine launch then takes tickets and its last workgroup writes the
+// result.  Without: the accumulators are zeroed by a memset / init launch and every workgroup adds to them atomically.
+inline bool use_workspace(void *workspace, int64_t nunits, unsigned tile_wgs) {
+    return workspace != nullptr && nunits > 0 && tile_wgs <= 1024u;        // + at most 1024 engine workgroups <= kMaxPartials
+}
+
 template <bool BF16>
-int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
+int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_fwd_bwd: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (B > 0 && B <= kSmallBatch) {                    // one workgroup, one launch: the kernel writes loss_sum itself
+    if (B > 0 && B <= kSmallBatch) {                    // one workgroup, one launch: the kernel writes loss_sum (and the mean) itself
         SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
         const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
         const float inv = 1.0f / static_cast<float>(B);
-#define SMALL(WR, WD) hipLaunchKernelGGL((k_frob_small<BF16, WR, WD>), grid, block, 0, s, M, Rtrue, R, dM, loss_sum, static_cast<int>(B), inv)
+#define SMALL(WR, WD) hipLaunchKernelGGL((k_frob_small<BF16, WR, WD>), grid, block, 0, s, M, Rtrue, R, dM, loss_sum, loss_mean, static_cast<int>(B), inv)
         if (R && dM) SMALL(true, true); else if (R) SMALL(true, false); else if (dM) SMALL(false, true); else SMALL(false, false);
 #undef SMALL
         return check_launch("so3_frob_fwd_bwd");
     }
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-    if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
-    if (B == 0) return 0;
-    SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
     constexpr int EB = BF16 ? 2 : 4;
-    const float inv_b = 1.0f / static_cast<float>(B);
-    const int64_t nunits = stream_units(B, {M, Rtrue, R, dM});
-    if (nunits > 0) {
-#define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
-                             op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
-        if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
-#undef SLAUNCH
-    }
+    const int64_t nunits = B > 0 ? stream_units(B, {M, Rtrue, R, dM}) : 0;
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    const unsigned tile_wgs = rest > 0 ? persistent_grid(rest) : 0u;
+    so3::ReduceWs *ws = use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
+    if (ws == nullptr) {
+        hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+        if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
+    }
+    if (B == 0) {
+        if (loss_mean != nullptr) { hipError_t e = hipMemsetAsync(loss_mean, 0, sizeof(float), s); if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset"); }
+        return 0;
+    }
+    SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
+    const float inv_b = 1.0f / static_cast<float>(B);
     if (rest > 0) {
         const void *Mt = advance_bytes(M, done * 9 * EB);
         const float *Tt = Rtrue + done * 9;
@@ -1389,13 +1418,21 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
         void *dt = advance_bytes(dM, done * 9 * EB);
         bool vec = aligned16(Tt) && (Rt == nullptr || aligned16(Rt));
         if (!BF16) vec = vec && aligned16(Mt) && (dt == nullptr || aligned16(dt));
-        const dim3 grid(persistent_grid(rest)), block(kBlock);
-#define LAUNCH(VE, WR, WD) hipLaunchKernelGGL((k_frob_fwd_bwd<BF16, VE, WR, WD>), grid, block, 0, s, Mt, Tt, Rt, dt, loss_sum, rest, inv_b)
+        const dim3 grid(tile_wgs), block(kBlock);
+#define LAUNCH(VE, WR, WD) hipLaunchKernelGGL((k_frob_fwd_bwd<BF16, VE, WR, WD>), grid, block, 0, s, Mt, Tt, Rt, dt, loss_sum, rest, inv_b, ws)
 #define PICK(VE) do { if (R && dM) LAUNCH(VE, true, true); else if (R) LAUNCH(VE, true, false); else if (dM) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
         if (vec) PICK(true); else PICK(false);
 #undef PICK
 #undef LAUNCH
     }
+    if (nunits > 0) {
+#define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
+                             op.loss_sum = loss_sum; op.inv_b = inv_b; op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); \
+                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+        if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
+#undef SLAUNCH
+    }
+    if (ws == nullptr && loss_mean != nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(loss_sum, loss_mean, 1.0 / static_cast<double>(B));
     return check_launch("so3_frob_fwd_bwd");
 }
 
@@ -1446,50 +1483,78 @@ int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, voi
     return project_bwd<true>(M, G, dM, B, stream);
 }
 int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
-    return frob<false>(M, Rtrue, R, dM, loss_sum, B, stream);
+    return frob<false>(M, Rtrue, R, dM, loss_sum, nullptr, nullptr, B, stream);
 }
 int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
-    return frob<true>(M, Rtrue, R, dM, loss_sum, B, stream);
+    return frob<true>(M, Rtrue, R, dM, loss_sum, nullptr, nullptr, B, stream);
+}
+size_t so3_reduce_workspace_bytes(void) { return sizeof(so3::ReduceWs); }
+int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean, void *workspace,
+                            int64_t B, void *stream) {
+    return frob<false>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, B, stream);
+}
+int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace,
+                             int64_t B, void *stream) {
+    return frob<true>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, B, stream);
 }
 
-int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
+static int frob_loss(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace, int64_t B,
+                     void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f32: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f32: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (B > 0 && B <= kSmallBatch) {                     // one workgroup, one launch: the kernel writes loss_sum itself
+    if (B > 0 && B <= kSmallBatch) {                     // one workgroup, one launch: the kernel writes loss_sum (and the mean) itself
         SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
         const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
         const float inv = 1.0f / static_cast<float>(B);
-        if (dRpred) hipLaunchKernelGGL((k_frob_loss_small<true>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, static_cast<int>(B), inv);
-        else hipLaunchKernelGGL((k_frob_loss_small<false>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, static_cast<int>(B), inv);
+        if (dRpred) hipLaunchKernelGGL((k_frob_loss_small<true>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, static_cast<int>(B), inv);
+        else hipLaunchKernelGGL((k_frob_loss_small<false>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, static_cast<int>(B), inv);
         return check_launch("so3_frob_loss_f32");
     }
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-    if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
-    if (B == 0) return 0;
+    const int64_t nunits = B > 0 ? stream_units(B, {Rpred, Rtrue, dRpred}) : 0;
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    const unsigned tile_wgs = rest > 0 ? persistent_grid(rest) : 0u;
+    so3::ReduceWs *ws = use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
+    if (ws == nullptr) {
+        hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+        if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
+    }
+    if (B == 0) {
+        if (loss_mean != nullptr) { hipError_t e = hipMemsetAsync(loss_mean, 0, sizeof(float), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset"); }
+        return 0;
+    }
     SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f32: null pointer");
     const float inv_b = 1.0f / static_cast<float>(B);
-    const int64_t nunits = stream_units(B, {Rpred, Rtrue, dRpred});
-    if (nunits > 0) {
-        if (dRpred) { so3::OpFrobLoss<true> op; op.in0 = Rpred; op.in1 = Rtrue; op.out0 = dRpred; op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<1, 4, 1024>(op, nunits, s); }
-        else { so3::OpFrobLoss<false> op; op.in0 = Rpred; op.in1 = Rtrue; op.loss_sum = loss_sum; op.inv_b = inv_b; launch_rows<1, 4, 1024>(op, nunits, s); }
-    }
-    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
         const float *Pt = Rpred + done * 9, *Tt = Rtrue + done * 9;
         float *gt = advance(dRpred, done * 9);
         const bool vec = aligned16(Pt) && aligned16(Tt) && (gt == nullptr || aligned16(gt));
-        const dim3 grid(persistent_grid(rest)), block(kBlock);
-#define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Pt, Tt, gt, loss_sum, rest, inv_b)
+        const dim3 grid(tile_wgs), block(kBlock);
+#define LAUNCH(VE, WG) hipLaunchKernelGGL((k_frob_loss<VE, WG>), grid, block, 0, s, Pt, Tt, gt, loss_sum, rest, inv_b, ws)
         if (vec) { if (dRpred) LAUNCH(true, true); else LAUNCH(true, false); }
         else { if (dRpred) LAUNCH(false, true); else LAUNCH(false, false); }
 #undef LAUNCH
     }
+    if (nunits > 0) {
+#define SLAUNCH(WG) do { so3::OpFrobLoss<WG> op; op.in0 = Rpred; op.in1 = Rtrue; op.out0 = dRpred; op.loss_sum = loss_sum; op.inv_b = inv_b; \
+                         op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); op.ws = ws; op.ws_slot0 = tile_wgs; \
+                         launch_rows<1, 4, 1024>(op, nunits, s); } while (0)
+        if (dRpred) SLAUNCH(true); else SLAUNCH(false);
+#undef SLAUNCH
+    }
+    if (ws == nullptr && loss_mean != nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(loss_sum, loss_mean, 1.0 / static_cast<double>(B));
     return check_launch("so3_frob_loss_f32");
 }
+int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
+    return frob_loss(Rpred, Rtrue, dRpred, loss_sum, nullptr, nullptr, B, stream);
+}
+int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace,
+                         int64_t B, void *stream) {
+    return frob_loss(Rpred, Rtrue, dRpred, loss_sum, loss_mean, workspace, B, stream);
+}
 
-int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
-                    int radians, int64_t B, void *stream) {
+static int angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
+                       int radians, void *workspace, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
@@ -1500,36 +1565,45 @@ int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_c
         else hipLaunchKernelGGL((k_angle_small<false, false, false>), grid, block, 0, s, R1, R2, nullptr, deg, sum_count, range_flag, unit, static_cast<int>(B));
         return check_launch("so3_angle_error");
     }
-    // one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
-    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    const int64_t nunits = B > 0 ? stream_units(B, {R1, R2, deg}) : 0;
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    const unsigned tile_wgs = rest > 0 ? grid_for(rest) : 0u;
+    so3::ReduceWs *ws = (sum_count || range_flag) && use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
+    // without a workspace one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
+    if (ws == nullptr && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_angle_error");
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
-    const int64_t nunits = stream_units(B, {R1, R2, deg});
-    if (nunits > 0) {
-        // 1024-thread workgroups: one same-address float64 atomic per workgroup costs ~9 ns at the end of the kernel;
-        // 768 workgroups of 512 made the fused-sum variant 20.5 us per 1M rows, 256 of 1024 make it 15.8 us.
-#define SLAUNCH(WD, WS) do { so3::OpAngle<WD, WS> op; op.in0 = R1; op.in1 = R2; op.deg = deg; op.sum_count = sum_count; \
-                             op.range_flag = range_flag; op.unit_scale = unit; launch_rows<1, 4, 1024>(op, nunits, s); } while (0)
-        if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
-#undef SLAUNCH
-    }
-    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {                                            // remainder (< 64 rows) or unaligned input
         const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
         double *dg = advance(deg, done);
         const bool vec = aligned16(A1) && aligned16(A2);
-        const dim3 grid(grid_for(rest)), block(kBlock);
-#define LAUNCH(VE, WD, WS) hipLaunchKernelGGL((k_angle_error<VE, WD, WS>), grid, block, 0, s, A1, A2, dg, sum_count, range_flag, unit, rest)
+        const dim3 grid(tile_wgs), block(kBlock);
+#define LAUNCH(VE, WD, WS) hipLaunchKernelGGL((k_angle_error<VE, WD, WS>), grid, block, 0, s, A1, A2, dg, sum_count, range_flag, unit, rest, ws)
 #define PICK(VE) do { if (deg && sum_count) LAUNCH(VE, true, true); else if (deg) LAUNCH(VE, true, false); else if (sum_count) LAUNCH(VE, false, true); else LAUNCH(VE, false, false); } while (0)
         if (vec) PICK(true); else PICK(false);
 #undef PICK
 #undef LAUNCH
     }
+    if (nunits > 0) {
+        // 1024-thread workgroups: 256 partials (or, without a workspace, 256 same-address float64 atomics at ~9 ns) at the end
+#define SLAUNCH(WD, WS) do { so3::OpAngle<WD, WS> op; op.in0 = R1; op.in1 = R2; op.deg = deg; op.sum_count = sum_count; \
+                             op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); op.ws = ws; op.ws_slot0 = tile_wgs; \
+                             launch_rows<1, 4, 1024>(op, nunits, s); } while (0)
+        if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
+#undef SLAUNCH
+    }
     return check_launch("so3_angle_error");
 }
+int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B, void *stream) {
+    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, B, stream);
+}
+int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, void *workspace,
+                       int64_t B, void *stream) {
+    return angle_error(R1, R2, deg, sum_count, range_flag, radians, workspace, B, stream);
+}
 
-int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                                int radians, int64_t B, void *stream) {
+static int project_angle_error(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                               int radians, void *workspace, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_angle_error_f32: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
@@ -1541,35 +1615,44 @@ int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, do
 #undef SMALL
         return check_launch("so3_project_angle_error_f32");
     }
-    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    const int64_t nunits = B > 0 ? stream_units(B, {M, Rtrue, R, deg}) : 0;
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    const unsigned tile_wgs = rest > 0 ? grid_for(rest) : 0u;
+    so3::ReduceWs *ws = (sum_count || range_flag) && use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
+    if (ws == nullptr && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_project_angle_error_f32");
     SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_project_angle_error_f32: null pointer");
-    const int64_t nunits = stream_units(B, {M, Rtrue, R, deg});
+    if (rest > 0) {
+        // remainder / unaligned input: the two-kernel spelling (K1 -> R -> K4) on the tail, which needs the caller's R buffer
+        SO3_CHECK_ARGS(R != nullptr, "so3_project_angle_error_f32: a < 64-row remainder or unaligned input needs the R buffer");
+        const float *Mt = M + done * 9, *Tt = Rtrue + done * 9;
+        float *Rt = R + done * 9;
+        double *dg = advance(deg, done);
+        const dim3 grid(tile_wgs), block(kBlock);
+        if (aligned16(Mt) && aligned16(Rt)) hipLaunchKernelGGL((k_project_fwd<false, true, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
+        else hipLaunchKernelGGL((k_project_fwd<false, false, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
+#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_error<false, WD, WS>), grid, block, 0, s, Rt, Tt, dg, sum_count, range_flag, unit, rest, ws)
+        if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
+#undef LAUNCH
+    }
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
-                                 op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+                                 op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
+                                 op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true); else if (deg) SLAUNCH(WR, true, false); else if (sum_count) SLAUNCH(WR, false, true); else SLAUNCH(WR, false, false); } while (0)
         if (R) PICKR(true); else PICKR(false);
 #undef PICKR
 #undef SLAUNCH
     }
-    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
-    if (rest > 0) {
-        // remainder / unaligned input: the two-kernel spelling through a temporary-free path is not possible without
-        // scratch, so the caller-provided R (or, if absent, the tail of `deg`) would be needed; instead run the tile
-        // kernels on the tail with R required.
-        SO3_CHECK_ARGS(R != nullptr, "so3_project_angle_error_f32: a < 64-row remainder or unaligned input needs the R buffer");
-        const float *Mt = M + done * 9, *Tt = Rtrue + done * 9;
-        float *Rt = R + done * 9;
-        double *dg = advance(deg, done);
-        const dim3 grid(grid_for(rest)), block(kBlock);
-        if (aligned16(Mt) && aligned16(Rt)) hipLaunchKernelGGL((k_project_fwd<false, true, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
-        else hipLaunchKernelGGL((k_project_fwd<false, false, false>), grid, block, 0, s, static_cast<const void *>(Mt), Rt, nullptr, rest);
-#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_error<false, WD, WS>), grid, block, 0, s, Rt, Tt, dg, sum_count, range_flag, unit, rest)
-        if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
-#undef LAUNCH
-    }
     return check_launch("so3_project_angle_error_f32");
+}
+int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                                int radians, int64_t B, void *stream) {
+    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, B, stream);
+}
+int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                                   int radians, void *workspace, int64_t B, void *stream) {
+    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, B, stream);
 }
 
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {

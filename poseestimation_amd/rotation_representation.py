@@ -20,7 +20,6 @@ no CPU path: a CPU tensor, or a missing libso3proj.so, raises.
 """
 from __future__ import annotations
 
-import ctypes
 import math
 
 import torch
@@ -34,6 +33,20 @@ _RANGE_MSG = "angle out of range, input probably not proper rotation matrices"  
 # --------------------------------------------------------------------------------------------
 # plumbing
 # --------------------------------------------------------------------------------------------
+# The reference's real batch sizes are 64-512 (Iterative/main.py:216, UPNA/main.py:126, 3D-Pose/configs/example.yaml:3): the
+# kernels then take 3-4 us and everything in this section is on the critical path.  Hence: the library handle and its entry
+# points are looked up once, pointers and the stream travel as plain ints (ctypes converts them through the argtypes declared
+# in _lib.py), the raw stream comes from torch's own accessor, and the device guard is a no-op on a one-GPU process.
+_L = None
+
+
+def _libh():
+    global _L
+    if _L is None:
+        _L = _lib.load()
+    return _L
+
+
 def _require_device(*tensors: torch.Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -51,32 +64,66 @@ def _require_device(*tensors: torch.Tensor) -> torch.device:
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    return t.data_ptr() if t is not None else None
 
 
-class _on_device:
-    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~4 us per call)."""
-    __slots__ = ("ctx",)
-
-    def __init__(self, dev: torch.device):
-        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+class _NoGuard:
+    __slots__ = ()
 
     def __enter__(self):
-        if self.ctx is not None:
-            self.ctx.__enter__()
+        return None
 
     def __exit__(self, *exc):
-        if self.ctx is not None:
-            return self.ctx.__exit__(*exc)
         return False
 
 
-def _stream(dev: torch.device):
-    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+_NO_GUARD = _NoGuard()
+_DEVICE_COUNT = None
+
+
+def _on_device(dev: torch.device):
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~4 us per call)."""
+    global _DEVICE_COUNT
+    if _DEVICE_COUNT is None:
+        _DEVICE_COUNT = torch.cuda.device_count()
+    if _DEVICE_COUNT <= 1 or dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(dev: torch.device) -> int:
+    """The current stream of `dev` as the integer the C ABI takes (hipStream_t)."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+_WORKSPACES = {}
+
+
+def _workspace(dev: torch.device, stream: int):
+    """The reduction workspace of (device, stream) -- include/so3proj.h: zero-filled once, then owned by that stream's calls.
+    None while the stream is being captured into a graph (a replay may run beside eager calls: the no-workspace path then)."""
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev.index, stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros((_libh().so3_reduce_workspace_bytes(),), dtype=torch.uint8, device=dev)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+_SMALL_BATCH = 1024          # csrc: kSmallBatch -- up to here a reduction is one workgroup and needs no workspace
 
 
 def _as_blocks(x: torch.Tensor) -> torch.Tensor:
     """x.view(-1, 3, 3) semantics (rotation_representation.py:199) -> contiguous (B, 9)."""
+    if x.dim() == 2 and x.shape[1] == 9 and x.is_contiguous():
+        return x
     if x.numel() % 9 != 0:
         raise RuntimeError(f"shape '[-1, 3, 3]' is invalid for input of size {x.numel()}")
     return x.reshape(-1, 9).contiguous()
@@ -86,26 +133,41 @@ def _head_input(x: torch.Tensor) -> torch.Tensor:
     """Kernel-ready (B,9) tensor: float32, bfloat16 kept as stored (math is fp32 in registers), or float64
     (its own float64 kernels, as the reference's function accepts double tensors)."""
     m = _as_blocks(x)
-    if m.dtype in (torch.float32, torch.bfloat16, torch.float64):
+    dt = m.dtype
+    if dt is torch.float32 or dt is torch.bfloat16 or dt is torch.float64:
         return m
-    if m.dtype == torch.float16:
+    if dt is torch.float16:
         return m.float()
     raise TypeError(
         f"symmetric_orthogonalization: unsupported dtype {m.dtype} (inputs: float32, bfloat16, float16, float64)")
 
 
 def _f32_blocks(t: torch.Tensor) -> torch.Tensor:
-    return _as_blocks(t).float()
+    m = _as_blocks(t)
+    return m if m.dtype is torch.float32 else m.float()
+
+
+_HEAD_FNS = {}
 
 
 def _head_fns(dtype):
     """(forward, backward) entry points and the dtype the rotation / upstream gradient travel in."""
-    lib = _lib.load()
-    if dtype == torch.bfloat16:
-        return lib.so3_project_fwd_bf16, lib.so3_project_bwd_bf16, torch.float32
-    if dtype == torch.float64:
-        return lib.so3_project_fwd_f64, lib.so3_project_bwd_f64, torch.float64
-    return lib.so3_project_fwd_f32, lib.so3_project_bwd_f32, torch.float32
+    fns = _HEAD_FNS.get(dtype)
+    if fns is None:
+        lib = _libh()
+        if dtype == torch.bfloat16:
+            fns = (lib.so3_project_fwd_bf16, lib.so3_project_bwd_bf16, torch.float32)
+        elif dtype == torch.float64:
+            fns = (lib.so3_project_fwd_f64, lib.so3_project_bwd_f64, torch.float64)
+        else:
+            fns = (lib.so3_project_fwd_f32, lib.so3_project_bwd_f32, torch.float32)
+        _HEAD_FNS[dtype] = fns
+    return fns
+
+
+def _check(code: int, what: str) -> None:
+    if code != 0:
+        _lib.check(code, what)
 
 
 # --------------------------------------------------------------------------------------------
@@ -114,13 +176,13 @@ def _head_fns(dtype):
 class _SymmetricOrthogonalization(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        dev = _require_device(x)
-        m = _head_input(x.detach())
+        dev = x.device if x.is_cuda else _require_device(x)
+        m = _head_input(x)
         b = m.shape[0]
         fn, _, out_dtype = _head_fns(m.dtype)
         r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
         with _on_device(dev):
-            _lib.check(fn(_ptr(m), _ptr(r), None, b, _stream(dev)), "so3_project_fwd")
+            _check(fn(m.data_ptr(), r.data_ptr(), None, b, _stream(dev)), "so3_project_fwd")
         ctx.save_for_backward(m)
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -132,12 +194,18 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
         (m,) = ctx.saved_tensors
         dev = m.device
         _, fn, g_dtype = _head_fns(m.dtype)
-        g = grad_r.reshape(-1, 9).contiguous().to(g_dtype)
+        g = grad_r.reshape(-1, 9)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        if g.dtype is not g_dtype:
+            g = g.to(g_dtype)
         b = m.shape[0]
         dm = torch.empty_like(m)
         with _on_device(dev):
-            _lib.check(fn(_ptr(m), _ptr(g), _ptr(dm), b, _stream(dev)), "so3_project_bwd")
-        return dm.to(ctx.in_dtype).view(ctx.in_shape)
+            _check(fn(m.data_ptr(), g.data_ptr(), dm.data_ptr(), b, _stream(dev)), "so3_project_bwd")
+        if dm.dtype is not ctx.in_dtype:
+            dm = dm.to(ctx.in_dtype)
+        return dm.view(ctx.in_shape)
 
 
 def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
@@ -149,12 +217,13 @@ def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
     """
     if isinstance(x, torch.Tensor) and not (x.requires_grad and torch.is_grad_enabled()):
         # inference / evaluation loops: no autograd node to build
-        dev = _require_device(x)
+        dev = x.device if x.is_cuda else _require_device(x)
         m = _head_input(x)
         fn, _, out_dtype = _head_fns(m.dtype)
-        r = torch.empty((m.shape[0], 3, 3), dtype=out_dtype, device=dev)
+        b = m.shape[0]
+        r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
         with _on_device(dev):
-            _lib.check(fn(_ptr(m), _ptr(r), None, m.shape[0], _stream(dev)), "so3_project_fwd")
+            _check(fn(m.data_ptr(), r.data_ptr(), None, b, _stream(dev)), "so3_project_fwd")
         return r
     return _SymmetricOrthogonalization.apply(x)
 
@@ -169,7 +238,7 @@ def symmetric_orthogonalization_with_flip(x: torch.Tensor):
     r = torch.empty((b, 3, 3), dtype=out_dtype, device=dev)
     flip = torch.empty((b,), dtype=torch.uint8, device=dev)
     with _on_device(dev):
-        _lib.check(fn(_ptr(m), _ptr(r), _ptr(flip), b, _stream(dev)), "so3_project_fwd")
+        _check(fn(_ptr(m), _ptr(r), _ptr(flip), b, _stream(dev)), "so3_project_fwd")
     return r, flip.bool()
 
 
@@ -186,8 +255,10 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
     sc = torch.empty((2,), dtype=torch.float64, device=dev) if want_sum else None
     flag = torch.empty((1,), dtype=torch.int32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_angle_error(_ptr(a), _ptr(b_), _ptr(deg), _ptr(sc), _ptr(flag),
-                                               1 if radians else 0, n, _stream(dev)), "so3_angle_error")
+        st = _stream(dev)
+        ws = _workspace(dev, st) if n > _SMALL_BATCH else None
+        _check(_libh().so3_angle_error_ws(a.data_ptr(), b_.data_ptr(), _ptr(deg), _ptr(sc), flag.data_ptr(),
+                                          1 if radians else 0, _ptr(ws), n, st), "so3_angle_error")
     return deg, sc, flag
 
 
@@ -261,8 +332,10 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     sc = None if want_deg else torch.empty((2,), dtype=torch.float64, device=dev)
     flag = torch.empty((1,), dtype=torch.int32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_project_angle_error_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
-                   "so3_project_angle_error_f32")
+        st = _stream(dev)
+        ws = _workspace(dev, st) if n > _SMALL_BATCH else None
+        _check(_libh().so3_project_angle_error_ws_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, _ptr(ws), n, st),
+               "so3_project_angle_error_f32")
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
     out = deg if want_deg else (sc if reduce == "sum_count" else sc[0] / sc[1])
@@ -281,7 +354,7 @@ def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tens
     n = a.shape[0]
     theta = torch.empty((n,), dtype=torch.float32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_geodesic_f32(_ptr(a), _ptr(b_), _ptr(theta), n, _stream(dev)), "so3_geodesic_f32")
+        _check(_libh().so3_geodesic_f32(_ptr(a), _ptr(b_), _ptr(theta), n, _stream(dev)), "so3_geodesic_f32")
     return theta
 
 
@@ -299,11 +372,15 @@ class _LossFrobenius(torch.autograd.Function):
         need_grad = r_pred.requires_grad or r_true.requires_grad
         g = torch.empty_like(p) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)              # the kernel writes the float32 mean itself
         with _on_device(dev):
-            _lib.check(_lib.load().so3_frob_loss_f32(_ptr(p), _ptr(t), _ptr(g), _ptr(loss_sum), b, _stream(dev)), "so3_frob_loss_f32")
+            st = _stream(dev)
+            ws = _workspace(dev, st) if b > _SMALL_BATCH else None
+            _check(_libh().so3_frob_loss_ws_f32(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
+                   "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
-        return loss_sum.to(torch.float32).mul_(1.0 / max(b, 1)).squeeze(0)
+        return loss
 
     @staticmethod
     @once_differentiable
@@ -337,25 +414,32 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
 class _FrobeniusHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, r_true, want_r):
-        dev = _require_device(x, r_true)
-        m = _head_input(x.detach())
-        t = _f32_blocks(r_true.detach())
+        dev = x.device if (x.is_cuda and r_true.is_cuda and x.device == r_true.device) else _require_device(x, r_true)
+        m = _head_input(x)
+        t = _f32_blocks(r_true)
         b = m.shape[0]
         if t.shape[0] != b:
             raise RuntimeError(f"frobenius_head: {b} predictions vs {t.shape[0]} targets")
         need_grad = x.requires_grad
+        # d loss / d R_true = -(R - R_true) / (B ||R - R_true||_F), the loss being differentiable in both arguments
+        # (3D-Pose/loss.py:7-11): it is rebuilt in backward from R and R_true (K3'), so R is kept whenever it is asked for
+        ctx.true_grad = r_true.requires_grad
+        want_r = want_r or ctx.true_grad
         r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if want_r else None
         dm = torch.empty_like(m) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
-        lib = _lib.load()
-        fn = lib.so3_frob_fwd_bwd_bf16 if m.dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
+        loss = torch.empty((), dtype=torch.float32, device=dev)      # the kernel writes the float32 mean itself: no launch of ours
+        lib = _libh()
+        fn = lib.so3_frob_fwd_bwd_ws_bf16 if m.dtype is torch.bfloat16 else lib.so3_frob_fwd_bwd_ws_f32
         with _on_device(dev):
-            _lib.check(fn(_ptr(m), _ptr(t), _ptr(r), _ptr(dm), _ptr(loss_sum), b, _stream(dev)), "so3_frob_fwd_bwd")
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        torch.mul(loss_sum[0], 1.0 / max(b, 1), out=loss)           # float64 sum -> float32 mean in one kernel
+            st = _stream(dev)
+            ws = _workspace(dev, st) if b > _SMALL_BATCH else None
+            _check(fn(m.data_ptr(), t.data_ptr(), _ptr(r), _ptr(dm), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st), "so3_frob_fwd_bwd")
         ctx.dm = dm
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
+        if ctx.true_grad:
+            ctx.rt = (r, t, r_true.shape, r_true.dtype)
         if want_r:
             ctx.mark_non_differentiable(r)
             return loss, r
@@ -365,13 +449,24 @@ class _FrobeniusHead(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_loss, _grad_r):
         dm = ctx.dm
-        if dm is None:
-            return None, None, None
-        # out of place: a second backward over the same graph (retain_graph, several losses) must see the stored gradient
-        # unscaled, and the tensor handed out must not alias it
-        if dm.dtype == ctx.in_dtype:
-            return (dm * grad_loss).view(ctx.in_shape), None, None
-        return (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape), None, None
+        gx = gt = None
+        if dm is not None and ctx.needs_input_grad[0]:
+            # out of place: a second backward over the same graph (retain_graph, several losses) must see the stored gradient
+            # unscaled, and the tensor handed out must not alias it
+            if dm.dtype == ctx.in_dtype:
+                gx = (dm * grad_loss).view(ctx.in_shape)
+            else:
+                gx = (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape)
+        if ctx.true_grad and ctx.needs_input_grad[1]:
+            r, t, shape, dtype = ctx.rt
+            dev = t.device
+            b = t.shape[0]
+            g = torch.empty_like(t)                              # d(mean loss)/dR_pred; the target's gradient is its negative
+            scratch = torch.empty((1,), dtype=torch.float64, device=dev)
+            with _on_device(dev):
+                _check(_libh().so3_frob_loss_f32(_ptr(r), _ptr(t), _ptr(g), _ptr(scratch), b, _stream(dev)), "so3_frob_loss_f32")
+            gt = (g * (-grad_loss)).to(dtype).view(shape)
+        return gx, gt, None
 
 
 def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool = True):
@@ -418,15 +513,14 @@ class FrobeniusHeadStep:
         self.r = torch.empty((self.batch, 3, 3), dtype=torch.float32, device=dev) if return_rotation else None
         self._sum = torch.empty((1,), dtype=torch.float64, device=dev)
         self.loss = torch.empty((), dtype=torch.float32, device=dev)
-        lib = _lib.load()
-        fn = lib.so3_frob_fwd_bwd_bf16 if dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_f32
+        lib = _libh()
+        fn = lib.so3_frob_fwd_bwd_ws_bf16 if dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_ws_f32
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
 
-        def record():
-            _lib.check(fn(_ptr(self.x), _ptr(self.r_true), _ptr(self.r), _ptr(self.dx), _ptr(self._sum), self.batch,
-                          ctypes.c_void_p(side.cuda_stream)), "so3_frob_fwd_bwd")
-            torch.mul(self._sum[0], 1.0 / max(self.batch, 1), out=self.loss)        # float64 sum -> float32 mean, one kernel
+        def record():                 # the float32 mean is written by the kernel(s); no workspace inside a graph
+            _check(fn(_ptr(self.x), _ptr(self.r_true), _ptr(self.r), _ptr(self.dx), _ptr(self._sum), _ptr(self.loss), None, self.batch,
+                      side.cuda_stream), "so3_frob_fwd_bwd")
 
         with torch.cuda.device(dev), torch.cuda.stream(side):
             record()                                                                 # warm-up outside the capture
@@ -458,7 +552,7 @@ def kabsch_rotation(P: torch.Tensor, Q: torch.Tensor, return_h: bool = False):
     r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
     h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
     with _on_device(dev):
-        _lib.check(_lib.load().so3_kabsch_f32(_ptr(p), _ptr(q), _ptr(r), _ptr(h), b, n, _stream(dev)), "so3_kabsch_f32")
+        _check(_libh().so3_kabsch_f32(_ptr(p), _ptr(q), _ptr(r), _ptr(h), b, n, _stream(dev)), "so3_kabsch_f32")
     return (r, h) if return_h else r
 
 
@@ -477,7 +571,7 @@ def rotate_point_clouds(pc: torch.Tensor, R: torch.Tensor, transposed: bool = Fa
     b, n, _ = p.shape
     out = torch.empty((b, 3, n) if transposed else (b, n, 3), dtype=torch.float32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_rotate_clouds_f32(_ptr(p), _ptr(r), _ptr(out), 1 if transposed else 0, b, n, _stream(dev)), "so3_rotate_clouds_f32")
+        _check(_libh().so3_rotate_clouds_f32(_ptr(p), _ptr(r), _ptr(out), 1 if transposed else 0, b, n, _stream(dev)), "so3_rotate_clouds_f32")
     return out
 
 
@@ -493,7 +587,7 @@ def pc_normalize(pc: torch.Tensor):
     b, n, _ = p.shape
     out, cen, sc = torch.empty_like(p), torch.empty((b, 3), dtype=torch.float32, device=dev), torch.empty((b,), dtype=torch.float32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_pc_normalize_f32(_ptr(p), _ptr(out), _ptr(cen), _ptr(sc), b, n, _stream(dev)), "so3_pc_normalize_f32")
+        _check(_libh().so3_pc_normalize_f32(_ptr(p), _ptr(out), _ptr(cen), _ptr(sc), b, n, _stream(dev)), "so3_pc_normalize_f32")
     return (out[0], cen[0], sc[0]) if single else (out, cen, sc)
 
 
@@ -518,7 +612,7 @@ def rotations_from_axis_angle_draws(theta: torch.Tensor, axis: torch.Tensor) -> 
         raise RuntimeError("rotations_from_axis_angle_draws: theta (B,) and axis (B,3) disagree")
     r = torch.empty((t.shape[0], 3, 3), dtype=torch.float32, device=dev)
     with _on_device(dev):
-        _lib.check(_lib.load().so3_rotations_axis_angle_f32(_ptr(t), _ptr(a), _ptr(r), t.shape[0], _stream(dev)), "so3_rotations_axis_angle_f32")
+        _check(_libh().so3_rotations_axis_angle_f32(_ptr(t), _ptr(a), _ptr(r), t.shape[0], _stream(dev)), "so3_rotations_axis_angle_f32")
     return r
 
 
@@ -534,7 +628,7 @@ def kabsch_rotation_synthetic(P: torch.Tensor, R_gt: torch.Tensor, sigma: float 
     r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
     h = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if return_h else None
     with _on_device(dev):
-        _lib.check(_lib.load().so3_kabsch_synth_f32(_ptr(p), _ptr(g), float(sigma), int(seed) & 0xFFFFFFFF, _ptr(r), _ptr(h), b, n, _stream(dev)),
+        _check(_libh().so3_kabsch_synth_f32(_ptr(p), _ptr(g), float(sigma), int(seed) & 0xFFFFFFFF, _ptr(r), _ptr(h), b, n, _stream(dev)),
                    "so3_kabsch_synth_f32")
     return (r, h) if return_h else r
 
@@ -560,7 +654,7 @@ class _Se3Update(torch.autograd.Function):
         b = o.shape[0]
         tp = torch.empty((b, 4, 4), dtype=torch.float32, device=dev)
         with _on_device(dev):
-            _lib.check(_lib.load().so3_se3_update_f32(_ptr(o), _ptr(t), _ptr(tp), fx, fy, b, _stream(dev)), "so3_se3_update_f32")
+            _check(_libh().so3_se3_update_f32(_ptr(o), _ptr(t), _ptr(tp), fx, fy, b, _stream(dev)), "so3_se3_update_f32")
         ctx.save_for_backward(o, t)
         ctx.meta = (model_output.shape, model_output.dtype, fx, fy)
         return tp
@@ -574,7 +668,7 @@ class _Se3Update(torch.autograd.Function):
         g = grad_t.reshape(-1, 16).contiguous().float()
         d = torch.empty_like(o)
         with _on_device(dev):
-            _lib.check(_lib.load().so3_se3_update_bwd_f32(_ptr(o), _ptr(t), _ptr(g), _ptr(d), fx, fy, o.shape[0], _stream(dev)), "so3_se3_update_bwd_f32")
+            _check(_libh().so3_se3_update_bwd_f32(_ptr(o), _ptr(t), _ptr(g), _ptr(d), fx, fy, o.shape[0], _stream(dev)), "so3_se3_update_bwd_f32")
         full = torch.zeros(shape, dtype=torch.float32, device=dev)
         full[:, :12] = d
         return full.to(dtype), None, None, None
@@ -585,9 +679,9 @@ def calculate_T_pred(model_output: torch.Tensor, T_init: torch.Tensor, device=No
 
     model_output: (B,12) = 9 numbers for the SVD head + (vx, vy, vz); T_init: (B,4,4).  Returns T_pred (B,4,4)
     float32, differentiable w.r.t. model_output (T_init is a constant, as the reference's loop detaches it).
-    `device` is accepted for signature compatibility and ignored (the result lives where the inputs do)."""
-    if rot_repr != "SVD":
-        raise NotImplementedError("calculate_T_pred: only the SVD head is implemented natively")
+    `device` is accepted for signature compatibility and ignored (the result lives where the inputs do), and so is
+    `rot_repr`: the reference never reads it -- its body always runs the SVD head on the first nine outputs
+    (Iterative/utility.py:105), whatever the string says."""
     fx, fy = get_scene_parameters()
     return _Se3Update.apply(model_output, T_init, float(fx), float(fy))
 
@@ -621,7 +715,7 @@ class _AddL1(torch.autograd.Function):
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if use_batch_mean else None
         scale = 1.0 / max(b, 1) if use_batch_mean else 1.0
         with _on_device(dev):
-            _lib.check(_lib.load().so3_add_l1_f32(_ptr(tg), _ptr(tp), _ptr(pts), _ptr(dists), _ptr(loss_sum), _ptr(dt), scale, b, n,
+            _check(_libh().so3_add_l1_f32(_ptr(tg), _ptr(tp), _ptr(pts), _ptr(dists), _ptr(loss_sum), _ptr(dt), scale, b, n,
                                                   _stream(dev)), "so3_add_l1_f32")
         ctx.dt, ctx.per_sample, ctx.in_dtype = dt, not use_batch_mean, t_pred.dtype
         if use_batch_mean:
@@ -646,7 +740,7 @@ class _AddL1Disentangled(torch.autograd.Function):
         dt = torch.empty((b, 4, 4), dtype=torch.float32, device=dev) if t_pred.requires_grad else None
         loss_sum = torch.empty((3,), dtype=torch.float64, device=dev)
         with _on_device(dev):
-            _lib.check(_lib.load().so3_add_l1_disentangled_f32(_ptr(tp), _ptr(tg), _ptr(pts), _ptr(loss_sum), _ptr(dt), 1.0 / max(b, 1),
+            _check(_libh().so3_add_l1_disentangled_f32(_ptr(tp), _ptr(tg), _ptr(pts), _ptr(loss_sum), _ptr(dt), 1.0 / max(b, 1),
                                                                b, n, _stream(dev)), "so3_add_l1_disentangled_f32")
         ctx.dt, ctx.in_dtype = dt, t_pred.dtype
         return loss_sum.sum().to(torch.float32).mul_(1.0 / max(b, 1))
@@ -691,11 +785,11 @@ def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None,
         c = class_ids.detach().reshape(-1).contiguous().to(torch.int32)
         if c.numel() != a.numel():
             raise RuntimeError("angle_error_statistics: angles and class_ids differ in length")
-    lib = _lib.load()
+    lib = _libh()
     stats = torch.empty((num_classes, len(STAT_FIELDS)), dtype=torch.float64, device=dev)
     work = torch.empty((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
     with _on_device(dev):
-        _lib.check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), _stream(dev)), "so3_angle_stats")
+        _check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), _stream(dev)), "so3_angle_stats")
     return {name: stats[:, i] for i, name in enumerate(STAT_FIELDS)}
 
 
@@ -712,7 +806,7 @@ class _Ortho6d(torch.autograd.Function):
         b = x.shape[0]
         r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
         with _on_device(dev):
-            _lib.check(_lib.load().so3_ortho6d_fwd_f32(_ptr(x), _ptr(r), b, _stream(dev)), "so3_ortho6d_fwd_f32")
+            _check(_libh().so3_ortho6d_fwd_f32(_ptr(x), _ptr(r), b, _stream(dev)), "so3_ortho6d_fwd_f32")
         ctx.save_for_backward(x)
         ctx.in_shape, ctx.in_dtype = poses.shape, poses.dtype
         return r.view(*poses.shape[:-1], 3, 3)
@@ -725,7 +819,7 @@ class _Ortho6d(torch.autograd.Function):
         g = grad_r.reshape(-1, 9).contiguous().float()
         dx = torch.empty_like(x)
         with _on_device(dev):
-            _lib.check(_lib.load().so3_ortho6d_bwd_f32(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_ortho6d_bwd_f32")
+            _check(_libh().so3_ortho6d_bwd_f32(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_ortho6d_bwd_f32")
         return dx.to(ctx.in_dtype).view(ctx.in_shape)
 
 
@@ -749,7 +843,7 @@ def _make_head(symbol: str, width: int):
             b = x.shape[0]
             r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev)
             with _on_device(dev):
-                _lib.check(getattr(_lib.load(), "so3_%s_fwd_f32" % symbol)(_ptr(x), _ptr(r), b, _stream(dev)), "so3_%s_fwd_f32" % symbol)
+                _check(getattr(_lib.load(), "so3_%s_fwd_f32" % symbol)(_ptr(x), _ptr(r), b, _stream(dev)), "so3_%s_fwd_f32" % symbol)
             ctx.save_for_backward(x)
             ctx.in_dtype = x_in.dtype
             return r
@@ -762,7 +856,7 @@ def _make_head(symbol: str, width: int):
             g = grad_r.reshape(-1, 9).contiguous().float()
             dx = torch.empty_like(x)
             with _on_device(dev):
-                _lib.check(getattr(_lib.load(), "so3_%s_bwd_f32" % symbol)(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_%s_bwd_f32" % symbol)
+                _check(getattr(_lib.load(), "so3_%s_bwd_f32" % symbol)(_ptr(x), _ptr(g), _ptr(dx), x.shape[0], _stream(dev)), "so3_%s_bwd_f32" % symbol)
             return dx.to(ctx.in_dtype)
 
     _Head.__name__ = "_Head_" + symbol

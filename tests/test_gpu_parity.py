@@ -597,6 +597,40 @@ def test_fused_head_backward_twice_over_one_graph(rr):
     assert (g1 - 3.0 * x2.grad).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("b", [512, 4000])
+def test_fused_head_is_differentiable_in_the_target_too(rr, b):
+    """The reference's loss is differentiable in both arguments (3D-Pose/loss.py:7-11: plain tensor arithmetic):
+    frobenius_head(x, R_true) hands R_true its gradient -(R - R_true) / (B ||.||_F) like loss_frobenius does, with or
+    without a gradient for x, and whether or not the rotation is asked for."""
+    gen = torch.Generator(device=DEV).manual_seed(40 + b)
+    x = torch.randn(b, 9, device=DEV, generator=gen)
+    t = rr.symmetric_orthogonalization(torch.randn(b, 9, device=DEV, generator=gen))
+    # the two-call spelling with torch's own autograd through the loss expression
+    ta = t.clone().requires_grad_(True)
+    xa = x.clone().requires_grad_(True)
+    la = torch.linalg.matrix_norm(ta - rr.symmetric_orthogonalization(xa), ord="fro").mean()
+    (2.0 * la).backward()
+    for x_grad in (True, False):
+        for want_r in (True, False):
+            tb = t.clone().requires_grad_(True)
+            xb = x.clone().requires_grad_(x_grad)
+            out = rr.frobenius_head(xb, tb, return_rotation=want_r)
+            loss = out[0] if want_r else out
+            assert loss.requires_grad
+            (2.0 * loss).backward()
+            assert tb.grad is not None and tb.grad.shape == t.shape
+            assert (tb.grad - ta.grad).abs().max().item() < 2e-7 * 512 / b + 1e-9, (x_grad, want_r)
+            if x_grad:
+                assert (xb.grad - xa.grad).abs().max().item() < 1e-5
+            else:
+                assert xb.grad is None
+    # a target without requires_grad gets none (and costs nothing)
+    xc = x.clone().requires_grad_(True)
+    tc = t.clone()
+    rr.frobenius_head(xc, tc)[0].backward()
+    assert tc.grad is None and torch.equal(xc.grad * 2.0, xa.grad) or (xc.grad * 2.0 - xa.grad).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1000), (torch.bfloat16, 3000)])
 def test_recorded_training_step_matches_the_autograd_spelling(rr, dtype, b):
     """FrobeniusHeadStep (one hipGraph replay: config #4's launch-bound step) against frobenius_head + backward; sizes on
@@ -660,6 +694,85 @@ def test_c_abi_direct_on_side_stream(pa, c_oracle):
         assert rc == 0
     torch.cuda.synchronize()
     assert sc[1].item() == 10_000 and fl.item() == 0 and sc[0].item() / 10_000 < 0.2
+
+
+@pytest.mark.parametrize("n", [1025, 4096 + 37, 1_000_000, 1_000_003])
+def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n):
+    """so3_*_ws entry points (include/so3proj.h): a caller-owned workspace replaces the zero-fill launch and the atomics on
+    the result.  Same sums as the entry points without it (to round-off: the order of the additions differs), the SAME BITS
+    from call to call (the atomics' order varies, the ticket's fixed-order sum does not), the float32 mean written by the
+    kernel, the range flag raised and cleared, and the workspace left zeroed -- on sizes with and without a remainder."""
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    t = rr.symmetric_orthogonalization(torch.randn(n, 9, device=DEV, generator=gen)).reshape(n, 9)
+    r = torch.empty(n, 9, device=DEV)
+    dm = torch.empty(n, 9, device=DEV)
+    ws = torch.zeros(lib.so3_reduce_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda a: a.data_ptr() if a is not None else None
+    f64 = lambda k: torch.full((k,), 777.0, dtype=torch.float64, device=DEV)
+
+    # K3: fused head + loss + backward
+    ls0, r0, dm0 = f64(1), torch.empty_like(r), torch.empty_like(dm)
+    assert lib.so3_frob_fwd_bwd_f32(p(x), p(t), p(r0), p(dm0), p(ls0), n, st) == 0
+    runs = []
+    for _ in range(3):
+        ls, mean = f64(1), torch.full((), -1.0, device=DEV)
+        assert lib.so3_frob_fwd_bwd_ws_f32(p(x), p(t), p(r), p(dm), p(ls), p(mean), p(ws), n, st) == 0
+        runs.append((ls.item(), mean.item()))
+        assert torch.equal(r, r0) and torch.equal(dm, dm0)
+    assert runs[0] == runs[1] == runs[2]
+    assert abs(runs[0][0] - ls0.item()) <= 1e-12 * ls0.item()
+    assert runs[0][1] == float(np.float32(runs[0][0] * (1.0 / n)))
+    # ... and without a workspace the mean comes from the finishing launch
+    ls, mean = f64(1), torch.full((), -1.0, device=DEV)
+    assert lib.so3_frob_fwd_bwd_ws_f32(p(x), p(t), None, p(dm), p(ls), p(mean), None, n, st) == 0
+    assert mean.item() == float(np.float32(ls.item() * (1.0 / n))) and abs(ls.item() - ls0.item()) <= 1e-12 * ls0.item()
+
+    # K3': stand-alone loss
+    ls0 = f64(1)
+    assert lib.so3_frob_loss_f32(p(r0), p(t), p(dm0), p(ls0), n, st) == 0
+    runs = []
+    for _ in range(2):
+        ls, mean = f64(1), torch.full((), -1.0, device=DEV)
+        assert lib.so3_frob_loss_ws_f32(p(r0), p(t), p(dm), p(ls), p(mean), p(ws), n, st) == 0
+        runs.append((ls.item(), mean.item()))
+        assert torch.equal(dm, dm0)
+    assert runs[0] == runs[1] and abs(runs[0][0] - ls0.item()) <= 1e-12 * ls0.item()
+    assert runs[0][1] == float(np.float32(runs[0][0] * (1.0 / n)))
+
+    # K4 and K1+K4: (sum, count), the flag, per-row angles untouched by the way the sum is formed
+    sc0, fl0, deg0 = f64(2), torch.full((1,), 9, dtype=torch.int32, device=DEV), f64(n)
+    assert lib.so3_angle_error(p(r0), p(t), p(deg0), p(sc0), p(fl0), 0, n, st) == 0
+    for fused in (False, True):
+        runs = []
+        for _ in range(2):
+            sc, fl, deg = f64(2), torch.full((1,), 9, dtype=torch.int32, device=DEV), f64(n)
+            if fused:
+                assert lib.so3_project_angle_error_ws_f32(p(x), p(t), p(r), p(deg), p(sc), p(fl), 0, p(ws), n, st) == 0
+            else:
+                assert lib.so3_angle_error_ws(p(r0), p(t), p(deg), p(sc), p(fl), 0, p(ws), n, st) == 0
+            runs.append(sc.tolist())
+            assert torch.equal(deg, deg0) and fl.item() == 0 and sc[1].item() == n
+        assert runs[0] == runs[1] and abs(runs[0][0] - sc0[0].item()) <= 1e-12 * sc0[0].item()
+        # sum only, flag only
+        sc = f64(2)
+        if fused:
+            assert lib.so3_project_angle_error_ws_f32(p(x), p(t), p(r), None, p(sc), None, 0, p(ws), n, st) == 0
+        else:
+            assert lib.so3_angle_error_ws(p(r0), p(t), None, p(sc), None, 0, p(ws), n, st) == 0
+        assert sc.tolist() == runs[0]
+    bad = t.clone()
+    bad[n - 3] *= 1.7                                            # a row of the remainder when there is one
+    bad[5] *= 1.7
+    for rows in (bad, t):                                         # raised, then cleared again by the next call
+        fl = torch.full((1,), 9, dtype=torch.int32, device=DEV)
+        assert lib.so3_angle_error_ws(p(r0), p(rows), None, None, p(fl), 0, p(ws), n, st) == 0
+        assert fl.item() == (1 if rows is bad else 0)
+    torch.cuda.synchronize()
+    assert int(torch.count_nonzero(ws).item()) == 0              # slots, flag and ticket are left as they were found
 
 
 def test_graph_capture_of_the_head(pa):
@@ -1090,6 +1203,9 @@ def test_g8_se3_update_forward_backward(rr):
     out = dev(g["out"]).requires_grad_(True)
     tp = rr.calculate_T_pred(out, dev(g["t_init"]), DEV)
     assert tuple(tp.shape) == (200, 4, 4)
+    # the reference never reads `rot_repr` (Iterative/utility.py:90-105 always runs the SVD head): neither do we
+    for name in ("6D", "Quat", "anything"):
+        assert torch.equal(rr.calculate_T_pred(out.detach(), dev(g["t_init"]), DEV, rot_repr=name), tp.detach())
     # the rotation block inherits the head's conditioning (s1 / gap of the 3x3 in out[:, :9]): judge the error scaled by it
     m9 = g["out"][:, :9].astype(np.float64).reshape(-1, 3, 3)
     sv = np.linalg.svd(m9, compute_uv=False)

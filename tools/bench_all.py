@@ -55,6 +55,14 @@ def main():
     timeit("K3 so3_frob_fwd_bwd_f32 (R + dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), n, st), 144 * n)
     timeit("K3 so3_frob_fwd_bwd_f32 (dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), n, st), 108 * n)
     timeit("K3' so3_frob_loss_f32 (loss + dRpred)", lambda i: lib.so3_frob_loss_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), n, st), 108 * n)
+    # the same reductions with a caller-owned workspace (what the Python mirror passes): no memset / init launch, no atomics on the result
+    ws = torch.zeros(lib.so3_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
+    lm = torch.empty((), dtype=torch.float32, device=dev)
+    timeit("K3 so3_frob_fwd_bwd_ws_f32 (R + dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 144 * n)
+    timeit("K3 so3_frob_fwd_bwd_ws_f32 (dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
+    timeit("K3' so3_frob_loss_ws_f32 (loss + dRpred, workspace)", lambda i: lib.so3_frob_loss_ws_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
+    timeit("K4 so3_angle_error_ws (fused sum,count, workspace)", lambda i: lib.so3_angle_error_ws(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, p(ws), n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_ws_f32 (sum,count, workspace)", lambda i: lib.so3_project_angle_error_ws_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, p(ws), n, st), 72 * n)
     timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
     timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
     timeit("K1+K4 so3_project_angle_error_f32 (fused sum,count)", lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st), 72 * n)
