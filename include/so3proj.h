@@ -147,6 +147,15 @@ int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *su
 int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
                                    int32_t *range_flag, int radians, void *workspace, int64_t B, void *stream);
 
+/* K4 / K1+K4 with accumulators the CALLER has zeroed: sum_count[0] and *range_flag must be 0 on entry (e.g. fresh slots of a
+ * zero-filled pool -- one memset per few hundred calls instead of an init launch in front of every kernel); the kernels add to
+ * them with one atomic per workgroup and one workgroup stores the row count into sum_count[1].  One launch per call: at 1M rows
+ * 14.8 us instead of 16.3.  Everything else as in so3_angle_error / so3_project_angle_error_f32. */
+int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                        int64_t B, void *stream);
+int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                    int32_t *range_flag, int radians, int64_t B, void *stream);
+
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
  * point_cloud/main.py:43-57). */

@@ -198,16 +198,15 @@ __device__ __forceinline__ void ticket_finish(ReduceWs *ws, unsigned slot, unsig
     __shared__ int is_last;
     __shared__ double fin[BLOCK / 64];
     if (threadIdx.x == 0) {
-        atomicAdd(&ws->part[slot], wg_total);
-        if (wg_flag) atomicOr(&ws->flag, 1);
+        // Everything that crosses workgroups here is an agent-scope atomic (performed at the memory side, past the XCDs'
+        // L2s) or a coherent load: no release fence -- a __threadfence() per workgroup writes back the XCD's whole L2, i.e.
+        // the kernel's own streamed output, and made K3 50 us instead of 31.  Order: the partial's atomic RETURNS (the
+        // old value comes back, so it has been performed) before the ticket is drawn.
+        fin[0] = atomicAdd(&ws->part[slot], wg_total);        // (the old value is parked in LDS so that the returning form is kept)
+        if (wg_flag) fin[1 % (BLOCK / 64)] = static_cast<double>(atomicOr(&ws->flag, 1));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         int last = 0;
-        if (expected != 0) {
-            // the partial is acknowledged by the memory side (it leaves vmcnt) before the ticket is drawn
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __threadfence();
-            last = atomicAdd(&ws->ticket, 1u) == expected - 1 ? 1 : 0;
-            if (last) __threadfence();
-        }
+        if (expected != 0) last = atomicAdd(&ws->ticket, 1u) == expected - 1 ? 1 : 0;
         is_last = last;
     }
     __syncthreads();
@@ -660,8 +659,10 @@ struct OpAngle : OpBase {
         }
     }
     double count = 0.0;
+    bool store_count = false;      // accumulators pre-zeroed by the caller (so3_*_acc): nobody else writes the row count
     __device__ __forceinline__ void finish(double total, bool any_flag) const {
         if (WANT_SUM) atomicAdd(sum_count, total);
+        if (WANT_SUM && store_count && blockIdx.x == 0) sum_count[1] = count;
         if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
     }
     __device__ __forceinline__ void finish_total(double total, bool any_flag) const {
@@ -706,8 +707,10 @@ struct OpProjectAngle : OpBase {
         }
     }
     double count = 0.0;
+    bool store_count = false;      // accumulators pre-zeroed by the caller (so3_*_acc): nobody else writes the row count
     __device__ __forceinline__ void finish(double total, bool any_flag) const {
         if (WANT_SUM) atomicAdd(sum_count, total);
+        if (WANT_SUM && store_count && blockIdx.x == 0) sum_count[1] = count;
         if (any_flag && range_flag != nullptr) atomicOr(range_flag, 1);
     }
     __device__ __forceinline__ void finish_total(double total, bool any_flag) const {

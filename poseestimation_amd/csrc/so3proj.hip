@@ -1553,8 +1553,10 @@ int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, 
     return frob_loss(Rpred, Rtrue, dRpred, loss_sum, loss_mean, workspace, B, stream);
 }
 
+// `prezeroed`: sum_count[0] and *range_flag are zero on entry (the caller hands out fresh slots of a zero-filled pool): no
+// init launch, the kernels add to them as they are and one workgroup stores the row count.
 static int angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
-                       int radians, void *workspace, int64_t B, void *stream) {
+                       int radians, void *workspace, bool prezeroed, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
@@ -1570,8 +1572,10 @@ static int angle_error(const float *R1, const float *R2, double *deg, double *su
     const unsigned tile_wgs = rest > 0 ? grid_for(rest) : 0u;
     so3::ReduceWs *ws = (sum_count || range_flag) && use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
     // without a workspace one tiny launch zeroes the accumulators and writes the row count (instead of two memsets + a store)
-    if (ws == nullptr && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    if (ws == nullptr && (sum_count || range_flag) && !(prezeroed && B > 0)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_angle_error");
+    const bool store_count = prezeroed && ws == nullptr;
+    if (store_count && sum_count != nullptr && nunits == 0) k_angle_init<<<1, 1, 0, s>>>(sum_count, nullptr, static_cast<double>(B));   // no engine launch to store the count
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error: null pointer");
     if (rest > 0) {                                            // remainder (< 64 rows) or unaligned input
         const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
@@ -1588,22 +1592,25 @@ static int angle_error(const float *R1, const float *R2, double *deg, double *su
         // 1024-thread workgroups: 256 partials (or, without a workspace, 256 same-address float64 atomics at ~9 ns) at the end
 #define SLAUNCH(WD, WS) do { so3::OpAngle<WD, WS> op; op.in0 = R1; op.in1 = R2; op.deg = deg; op.sum_count = sum_count; \
                              op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); op.ws = ws; op.ws_slot0 = tile_wgs; \
-                             launch_rows<1, 4, 1024>(op, nunits, s); } while (0)
+                             op.store_count = store_count; launch_rows<1, 4, 1024>(op, nunits, s); } while (0)
         if (deg && sum_count) SLAUNCH(true, true); else if (deg) SLAUNCH(true, false); else if (sum_count) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
     return check_launch("so3_angle_error");
 }
 int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B, void *stream) {
-    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, B, stream);
+    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, false, B, stream);
 }
 int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, void *workspace,
                        int64_t B, void *stream) {
-    return angle_error(R1, R2, deg, sum_count, range_flag, radians, workspace, B, stream);
+    return angle_error(R1, R2, deg, sum_count, range_flag, radians, workspace, false, B, stream);
+}
+int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B, void *stream) {
+    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, true, B, stream);
 }
 
 static int project_angle_error(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                               int radians, void *workspace, int64_t B, void *stream) {
+                               int radians, void *workspace, bool prezeroed, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_angle_error_f32: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
@@ -1619,8 +1626,10 @@ static int project_angle_error(const float *M, const float *Rtrue, float *R, dou
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     const unsigned tile_wgs = rest > 0 ? grid_for(rest) : 0u;
     so3::ReduceWs *ws = (sum_count || range_flag) && use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
-    if (ws == nullptr && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    if (ws == nullptr && (sum_count || range_flag) && !(prezeroed && B > 0)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_project_angle_error_f32");
+    const bool store_count = prezeroed && ws == nullptr;
+    if (store_count && sum_count != nullptr && nunits == 0) k_angle_init<<<1, 1, 0, s>>>(sum_count, nullptr, static_cast<double>(B));
     SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_project_angle_error_f32: null pointer");
     if (rest > 0) {
         // remainder / unaligned input: the two-kernel spelling (K1 -> R -> K4) on the tail, which needs the caller's R buffer
@@ -1638,7 +1647,7 @@ static int project_angle_error(const float *M, const float *Rtrue, float *R, dou
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
                                  op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
-                                 op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true); else if (deg) SLAUNCH(WR, true, false); else if (sum_count) SLAUNCH(WR, false, true); else SLAUNCH(WR, false, false); } while (0)
         if (R) PICKR(true); else PICKR(false);
 #undef PICKR
@@ -1648,11 +1657,15 @@ static int project_angle_error(const float *M, const float *Rtrue, float *R, dou
 }
 int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
                                 int radians, int64_t B, void *stream) {
-    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, B, stream);
+    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, false, B, stream);
+}
+int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                                    int radians, int64_t B, void *stream) {
+    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, true, B, stream);
 }
 int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
                                    int radians, void *workspace, int64_t B, void *stream) {
-    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, B, stream);
+    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, false, B, stream);
 }
 
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {

@@ -117,6 +117,29 @@ def _workspace(dev: torch.device, stream: int):
     return ws
 
 
+class _ZeroPool:
+    """Zero-filled accumulator slots for the metric kernels (so3_*_acc: sum_count[0] and the range flag must be 0 on entry):
+    one torch.zeros per 256 calls instead of an init launch in front of every kernel.  A slot is handed out once; the tensors
+    returned to the caller are views of it and keep their pool alive."""
+    SLOTS = 256
+
+    def __init__(self):
+        self.pools = {}
+
+    def take(self, dev: torch.device):
+        """(sum_count: 2 float64, flag: 1 int32), both zero."""
+        entry = self.pools.get(dev.index)
+        if entry is None or entry[1] >= self.SLOTS or torch.cuda.is_current_stream_capturing():
+            entry = [torch.zeros((self.SLOTS, 4), dtype=torch.float64, device=dev), 0]
+            if torch.cuda.is_current_stream_capturing():
+                return entry[0][0, :2], entry[0][0, 2:3].view(torch.int32)[:1]     # a graph keeps its own (captured) zero-fill
+            self.pools[dev.index] = entry
+        row = entry[0][entry[1]]
+        entry[1] += 1
+        return row[:2], row[2:3].view(torch.int32)[:1]
+
+
+_ZERO_POOL = _ZeroPool()
 _SMALL_BATCH = 1024          # csrc: kSmallBatch -- up to here a reduction is one workgroup and needs no workspace
 
 
@@ -252,14 +275,11 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
         raise RuntimeError(f"angle_error: shape mismatch {tuple(r1.shape)} vs {tuple(r2.shape)}")
     n = a.shape[0]
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
-    sc = torch.empty((2,), dtype=torch.float64, device=dev) if want_sum else None
-    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    sc, flag = _ZERO_POOL.take(dev)                 # zero-filled slots: the kernel needs no init launch in front of it
     with _on_device(dev):
-        st = _stream(dev)
-        ws = _workspace(dev, st) if n > _SMALL_BATCH else None
-        _check(_libh().so3_angle_error_ws(a.data_ptr(), b_.data_ptr(), _ptr(deg), _ptr(sc), flag.data_ptr(),
-                                          1 if radians else 0, _ptr(ws), n, st), "so3_angle_error")
-    return deg, sc, flag
+        _check(_libh().so3_angle_error_acc(a.data_ptr(), b_.data_ptr(), _ptr(deg), sc.data_ptr() if want_sum else None, flag.data_ptr(),
+                                           1 if radians else 0, n, _stream(dev)), "so3_angle_error")
+    return deg, (sc if want_sum else None), flag
 
 
 def _is_f64(*ts) -> bool:
@@ -329,12 +349,11 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     need_r = return_rotation or (n % 64 != 0) or (m.data_ptr() % 16 != 0) or (t.data_ptr() % 16 != 0)
     r = torch.empty((n, 3, 3), dtype=torch.float32, device=dev) if need_r else None
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
-    sc = None if want_deg else torch.empty((2,), dtype=torch.float64, device=dev)
-    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    sc, flag = _ZERO_POOL.take(dev)                 # zero-filled slots: the kernel needs no init launch in front of it
+    if want_deg:
+        sc = None
     with _on_device(dev):
-        st = _stream(dev)
-        ws = _workspace(dev, st) if n > _SMALL_BATCH else None
-        _check(_libh().so3_project_angle_error_ws_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, _ptr(ws), n, st),
+        _check(_libh().so3_project_angle_error_acc_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
                "so3_project_angle_error_f32")
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)

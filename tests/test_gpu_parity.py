@@ -764,12 +764,23 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
         else:
             assert lib.so3_angle_error_ws(p(r0), p(t), None, p(sc), None, 0, p(ws), n, st) == 0
         assert sc.tolist() == runs[0]
+    # accumulators zeroed by the caller (so3_*_acc): one launch, the same numbers up to the order of the atomics
+    for fused in (False, True):
+        sc, fl = torch.zeros(2, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+        if fused:
+            assert lib.so3_project_angle_error_acc_f32(p(x), p(t), p(r), None, p(sc), p(fl), 0, n, st) == 0
+        else:
+            assert lib.so3_angle_error_acc(p(r0), p(t), None, p(sc), p(fl), 0, n, st) == 0
+        assert sc[1].item() == n and fl.item() == 0 and abs(sc[0].item() - sc0[0].item()) <= 1e-12 * sc0[0].item()
     bad = t.clone()
-    bad[n - 3] *= 1.7                                            # a row of the remainder when there is one
-    bad[5] *= 1.7
+    bad[n - 3] = 3.0 * r0[n - 3]                                 # a row of the remainder when there is one: tr = 9, cosine 4
+    bad[5] = 3.0 * r0[5]
     for rows in (bad, t):                                         # raised, then cleared again by the next call
         fl = torch.full((1,), 9, dtype=torch.int32, device=DEV)
         assert lib.so3_angle_error_ws(p(r0), p(rows), None, None, p(fl), 0, p(ws), n, st) == 0
+        assert fl.item() == (1 if rows is bad else 0)
+        fl = torch.zeros(1, dtype=torch.int32, device=DEV)
+        assert lib.so3_angle_error_acc(p(r0), p(rows), None, None, p(fl), 0, n, st) == 0
         assert fl.item() == (1 if rows is bad else 0)
     torch.cuda.synchronize()
     assert int(torch.count_nonzero(ws).item()) == 0              # slots, flag and ticket are left as they were found

@@ -61,8 +61,11 @@ def main():
     timeit("K3 so3_frob_fwd_bwd_ws_f32 (R + dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 144 * n)
     timeit("K3 so3_frob_fwd_bwd_ws_f32 (dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
     timeit("K3' so3_frob_loss_ws_f32 (loss + dRpred, workspace)", lambda i: lib.so3_frob_loss_ws_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
-    timeit("K4 so3_angle_error_ws (fused sum,count, workspace)", lambda i: lib.so3_angle_error_ws(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, p(ws), n, st), 72 * n)
-    timeit("K1+K4 so3_project_angle_error_ws_f32 (sum,count, workspace)", lambda i: lib.so3_project_angle_error_ws_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, p(ws), n, st), 72 * n)
+    # ... and the metric kernels with accumulators the caller zeroed (the mirror hands out slots of a zero-filled pool): one launch
+    pool = torch.zeros(4096, 4, dtype=torch.float64, device=dev)
+    slot = lambda i: (P(pool[i % 4096].data_ptr()), P(pool[i % 4096].data_ptr() + 16))
+    timeit("K4 so3_angle_error_acc (fused sum,count, zeroed slots)", lambda i: lib.so3_angle_error_acc(p(r[i % NB]), p(rt[i % NB]), None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_acc_f32 (sum,count, zeroed slots)", lambda i: lib.so3_project_angle_error_acc_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
     timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
     timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
     timeit("K1+K4 so3_project_angle_error_f32 (fused sum,count)", lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st), 72 * n)
