@@ -100,6 +100,70 @@ def cpu_baseline(rows: int):
                       f"rotation_representation.py:199-205 (oracle/so3_oracle.py), best of {reps}, {cpu_name}"}
 
 
+# ---- the timing / reduction skeleton (no GPU in it: tests/test_distributed_gloo.py runs it with two gloo ranks and a stub step)
+METRIC = "3x3 SVD->SO(3) projections/sec @ batch 1M"
+
+
+def first_buffer(rank: int, rows: int) -> torch.Tensor:
+    """Buffer 0 of rank r is config #2 / #5's generator: torch.manual_seed(r); randn(rows, 9) on the CPU."""
+    g = torch.Generator().manual_seed(rank)
+    return torch.randn(rows, 9, generator=g)
+
+
+def timed_region(run, sync, barrier=None, now=time.perf_counter) -> float:
+    """The contract's timed region on this rank: barrier + synchronize | clock | run() | synchronize | clock | barrier.
+    Returns this rank's seconds.  The ranks start together (the opening barrier), so the job's time is the MAX over ranks
+    (max_over_ranks below); the closing barrier's own latency is not a step and stays outside the clock."""
+    if barrier is not None:
+        barrier()
+    sync()
+    t0 = now()
+    run()
+    sync()
+    wall = now() - t0
+    if barrier is not None:
+        barrier()
+    return wall
+
+
+def max_over_ranks(values, dist, device=None):
+    """Element-wise MAX of a few per-rank floats over the job (one all-reduce); the values themselves without a group."""
+    if dist is None or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.tolist()
+
+
+def headline(rows_per_gpu: int, world: int, steps: int, warmup: int, wall_s: float, config: dict) -> dict:
+    """The contract's fields: value = rows of ALL ranks x steps / the slowest rank's time (whole-job throughput, weak scaling)."""
+    total_rows = rows_per_gpu * world
+    return {"metric": METRIC, "value": total_rows * steps / wall_s, "unit": "projections/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": wall_s * 1e3 / steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": config}
+
+
+def run_skeleton(rank: int, world: int, steps: int, warmup: int, rows: int, step, sync, dist, device, config: dict, extra_times=(),
+                 run=None, do_warmup=True):
+    """Warm-up, the timed region, the MAX over ranks, the headline -- what main() does around the launches, callable with a
+    stub `step(i)` on CPU tensors.  Returns (line or None, job times): rank 0 gets the dict it will print, the others None.
+    extra_times: callables evaluated after the region on every rank (e.g. the HIP-event time), MAX-reduced with the wall time.
+    run: what the region executes instead of `steps` calls of step (main(): one replay of the hipGraph that holds them)."""
+    if do_warmup:
+        for i in range(warmup):
+            step(i)
+    if run is None:
+        def run():
+            for i in range(steps):
+                step(i)
+
+    barrier = dist.barrier if dist is not None else None
+    wall = timed_region(run, sync, barrier)
+    times = max_over_ranks([wall] + [f() for f in extra_times], dist, device)
+    line = headline(rows, world, steps, warmup, times[0], config) if rank == 0 else None
+    return line, times
+
+
 def secondary_configs(lib, dev):
     """The other BASELINE.json configs, timed briefly on rank 0 at N = 1 (reported beside the headline)."""
     P = ctypes.c_void_p
@@ -158,6 +222,49 @@ def secondary_configs(lib, dev):
     blocks.sort()
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd"] = 0.5 * (blocks[2] + blocks[3])
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd_best_block"] = blocks[0]
+
+    # torch's own floor in THIS process: an autograd.Function that launches nothing (it returns an empty scalar, its backward a
+    # stored buffer) stepped the same way -- what any custom node costs here before it does any work of its own
+    class _Floor(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, buf):
+            ctx.buf = buf
+            return x.new_empty(())
+
+        @staticmethod
+        def backward(ctx, g):
+            return ctx.buf, None
+
+    buf = torch.zeros_like(xg)
+
+    def floor(_):
+        _Floor.apply(xg, buf).backward()
+        xg.grad = None
+    for i in range(200):
+        floor(i)
+    fblocks = []
+    for _ in range(6):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(300):
+            floor(i)
+        torch.cuda.synchronize()
+        fblocks.append((time.perf_counter() - t0) / 300 * 1e6)
+    fblocks.sort()
+    c4 = out["config4_head_loss_backward_b512_bf16"]
+    c4["us_per_step_empty_autograd_function_floor"] = 0.5 * (fblocks[2] + fblocks[3])
+    c4["mirror_over_floor"] = c4["us_per_step_python_mirror_autograd"] / c4["us_per_step_empty_autograd_function_floor"]
+    # the head alone, no autograd (evaluation loops), B = 512 float32, by the host clock
+    x512 = torch.randn(b, 9, device=dev)
+    for i in range(100):
+        rr.symmetric_orthogonalization(x512)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(2000):
+        rr.symmetric_orthogonalization(x512)
+    torch.cuda.synchronize()
+    out["config1_head_b512_no_grad"] = {"us_per_call_host_clock": (time.perf_counter() - t0) / 2000 * 1e6,
+                                        "note": "symmetric_orthogonalization(x) under no autograd, 2000 calls back to back, one synchronize at the end"}
     if os.environ.get("SO3_BENCH_PROFILE_MIRROR") == "1":
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable()
@@ -222,9 +329,7 @@ def main():
 
     rows = args.rows
     # buffer 0 of rank r is config #2/#5's generator: torch.manual_seed(r); randn(rows, 9) on the CPU
-    g = torch.Generator().manual_seed(rank)
-    x0 = torch.randn(rows, 9, generator=g)
-    xs = [x0.to(dev)]
+    xs = [first_buffer(rank, rows).to(dev)]
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
     for _ in range(NBUF - 1):
         xs.append(torch.randn(rows, 9, device=dev, generator=gen))
@@ -312,12 +417,13 @@ def main():
             st = ctypes.c_void_p(stream.cuda_stream)
             torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(stream):           # a graph replays on the CURRENT stream: entered before the clock starts
-        e0.record(stream); e1.record(stream)  # (torch creates an event's handle at its first record: not inside the region either)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    config = {"workload": ("configs[4]: batch 16M sharded across 8 MI355X (2M rows per GPU, seeds 0-7), RCCL all-reduce of the mean angle error"
+                           if args.config == 5 else "configs[1]: batch 1M synthetic 3x3 Gaussian -> SO(3) projection, fp32, per GPU"),
+              "rows_per_gpu": rows, "global_rows": rows * world, "buffer_pairs_rotated": NBUF,
+              "parallelism": f"dp{world} (row shards, one all-reduce of (sum,count) for the metric)",
+              "submission": "eager launches" if args.eager else "one hipGraph of K kernel launches, replayed"}
+
+    def region():                             # the K steps, bracketed by HIP events on the launch stream
         e0.record(stream)
         if graph is not None:
             graph.replay()
@@ -325,15 +431,21 @@ def main():
             for i in range(args.steps):
                 step(i)
         e1.record(stream)
+
+    with torch.cuda.stream(stream):           # a graph replays on the CURRENT stream: entered before the clock starts
+        e0.record(stream); e1.record(stream)  # (torch creates an event's handle at its first record: not inside the region either)
+        out, (wall, ev_ms) = run_skeleton(rank, world, args.steps, args.warmup, rows, step, torch.cuda.synchronize, dist, dev, config,
+                                          extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False)
+        # per-launch spread (median and min): a second, untimed pass of 20 eager launches with an event
+        # between every two of them
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+        st = ctypes.c_void_p(stream.cuda_stream)
+        marks[0].record(stream)
+        for i in range(20):
+            step(i)
+            marks[i + 1].record(stream)
         torch.cuda.synchronize()
-        wall = time.perf_counter() - t0       # this rank's K steps; the job's time is the MAX over ranks (below), the ranks
-        if dist is not None:                  # having started together -- the closing barrier's own latency is not a step
-            dist.barrier()
-    ev_ms = e0.elapsed_time(e1)
-    if dist is not None:
-        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, ev_ms = tmax[0].item(), tmax[1].item()
+        per_launch_us = sorted(marks[i].elapsed_time(marks[i + 1]) * 1e3 for i in range(20))
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # parity metric: mean geodesic angle vs the decoy target (config #2), one all-reduce of (sum, count)
@@ -349,9 +461,9 @@ def main():
         delta = mean_angle - float(np.load(golden)["mean_angle_deg"])      # vs the reference's own number
 
     if rank == 0:
-        total_rows = rows * world
         per_launch_s = ev_ms * 1e-3 / args.steps
         achieved = BYTES_PER_PROJECTION * rows / per_launch_s / 1e9
+        achieved_host = BYTES_PER_PROJECTION * rows / (wall / args.steps) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
         if rows == ROWS_DEFAULT and os.path.exists(pmc):      # the stored figure belongs to the default row count only
@@ -359,36 +471,25 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
-        out = {
-            "metric": "3x3 SVD->SO(3) projections/sec @ batch 1M",
-            "value": total_rows * args.steps / wall,
-            "unit": "projections/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps,               # host clock around barrier + synchronize (the contract)
-            "ms_per_step_events": ev_ms / args.steps,             # HIP events on the launch stream: what `roofline` uses
-            "value_events": total_rows * args.steps / (ev_ms * 1e-3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": ("configs[4]: batch 16M sharded across 8 MI355X (2M rows per GPU, seeds 0-7), RCCL all-reduce of the mean angle error"
-                                    if args.config == 5 else "configs[1]: batch 1M synthetic 3x3 Gaussian -> SO(3) projection, fp32, per GPU"),
-                       "rows_per_gpu": rows, "global_rows": total_rows, "buffer_pairs_rotated": NBUF,
-                       "parallelism": f"dp{world} (row shards, one all-reduce of (sum,count) for the metric)",
-                       "submission": "eager launches" if args.eager else "one hipGraph of K kernel launches, replayed"},
+        out.update({
+            "ms_per_step_events": ev_ms / args.steps,             # HIP events on the launch stream (ms_per_step: the host clock of the contract)
+            "value_events": rows * world * args.steps / (ev_ms * 1e-3),
             "mean_angle_error_deg": mean_angle,
             "mean_angle_error_delta_vs_ref_deg": delta,
             "roofline": {"bound": "hbm", "kernel": k1_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # the same fraction on the contract's clock (barrier + synchronize around the K steps: ~10 us of submission
+                         # and synchronisation latency are inside it, 3 % of a 20-step region)
+                         "frac_host_clock": achieved_host / HBM_PEAK_GBS,
+                         # one launch at a time (20 eager launches, an event between every two): median and fastest
+                         "median_us": 0.5 * (per_launch_us[9] + per_launch_us[10]), "min_us": per_launch_us[0],
+                         "traffic": traffic,
                          "traffic_source": ("stored profile profiles/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                             "this workload, FETCH_SIZE doubled per the gfx950 caveat); not measured in this run") if traffic is not None else None,
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},
             "pre_timing": pre,
-        }
+        })
         if world == 1 and not args.no_secondary and graph is not None:
             # the same graph held for ~0.6 s: what the kernel sustains once the package sits at its power limit
             t_hold = time.perf_counter()

@@ -156,6 +156,16 @@ int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *s
 int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
                                     int32_t *range_flag, int radians, int64_t B, void *stream);
 
+/* float64 arguments (the reference's metric and loss functions accept double tensors; rotation_representation.py:232-233 even
+ * casts to double itself): the same quantities from float64 data in float64 arithmetic, one row per thread -- correctness
+ * entry points, not tuned.  so3_geodesic_f64 returns float64 radians, so3_frob_loss_f64's dRpred and loss_mean are float64
+ * (loss_mean = loss_sum / B), everything else as in the float32 functions. */
+int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                        int64_t B, void *stream);
+int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t B, void *stream);
+int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, int64_t B,
+                      void *stream);
+
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
  * point_cloud/main.py:43-57). */

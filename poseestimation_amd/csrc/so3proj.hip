@@ -941,6 +941,62 @@ __global__ __launch_bounds__(kBlock) void k_add_l1(const float *__restrict__ Tgt
 // ---- float64 head and backward (the reference's functions accept double tensors): the same templates over
 // T = double, one row per thread with plain loads -- a convenience path, not a benchmark configuration.
 // Four fixed sweeps, then sweeps until the wave-wide residual is below 1e-14 (at most six more).
+// ---- float64 arguments of the metrics and the loss (the reference's functions accept double tensors and, for the metrics,
+// cast to double themselves: rotation_representation.py:232-233) -- one row per thread straight from global memory: not a
+// benchmark path, but no ATen arithmetic either.  MODE 0: angle_error (float64, range flag, unit = 180/pi or 1);
+// MODE 1: compute_geodesic_distance_from_two_matrices (radians, hard clamp, no flag).
+template <int MODE, bool WANT_ROWS, bool WANT_SUM>
+__global__ __launch_bounds__(kBlock) void k_angle_f64(const double *__restrict__ R1, const double *__restrict__ R2, double *__restrict__ out,
+                                                      double *__restrict__ sum_count, int32_t *__restrict__ range_flag, double unit, int64_t B) {
+    __shared__ double red[4];
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const bool active = row < B;
+    double tr = 0.0;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tr = fma(R1[row * 9 + i], R2[row * 9 + i], tr);
+    }
+    const double c_raw = (tr - 1.0) * 0.5;
+    const bool bad = MODE == 0 && active && (c_raw < -1.1 || c_raw > 1.1);
+    double c = fmin(fmax(c_raw, -1.0), 1.0);
+    if (c_raw != c_raw) c = c_raw;                              // clamp keeps NaN
+    const double ang = so3::acos_f64(c) * unit;
+    if (MODE == 0 && range_flag != nullptr && __any(bad)) {
+        if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
+    }
+    if (WANT_ROWS && active) out[row] = ang;
+    if (WANT_SUM) {
+        const double total = block_sum(active ? ang : 0.0, red);
+        if (threadIdx.x == 0) atomicAdd(sum_count, total);
+    }
+}
+
+// loss_frobenius in float64: loss_sum += sum_b ||Rtrue_b - Rpred_b||_F, optional dRpred_b = (Rpred_b - Rtrue_b) / (B ||.||_F)
+template <bool WANT_GRAD>
+__global__ __launch_bounds__(kBlock) void k_frob_loss_f64(const double *__restrict__ Rpred, const double *__restrict__ Rtrue,
+                                                          double *__restrict__ dRpred, double *__restrict__ loss_sum, int64_t B, double inv_b) {
+    __shared__ double red[4];
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const bool active = row < B;
+    double g[9], n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        g[i] = active ? Rpred[row * 9 + i] - Rtrue[row * 9 + i] : 0.0;
+        n2 = fma(g[i], g[i], n2);
+    }
+    const double nrm = __builtin_sqrt(n2);
+    if (WANT_GRAD && active) {
+        const double gs = n2 > 0.0 ? inv_b / nrm : 0.0;         // zero difference -> zero gradient (the reference: NaN)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dRpred[row * 9 + i] = g[i] * gs;
+    }
+    const double total = block_sum(active ? nrm : 0.0, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+}
+__global__ void k_mean_from_sum_f64(const double *__restrict__ loss_sum, double *__restrict__ loss_mean, double inv_b) {
+    *loss_mean = *loss_sum * inv_b;
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(kBlock) void k_project_f64(const double *__restrict__ M, const double *__restrict__ G,
                                                         double *__restrict__ out, uint8_t *__restrict__ flip, int64_t B) {
@@ -1666,6 +1722,49 @@ int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R
 int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
                                    int radians, void *workspace, int64_t B, void *stream) {
     return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, false, B, stream);
+}
+
+int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B,
+                        void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error_f64: B");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    if (B == 0) return check_launch("so3_angle_error_f64");
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error_f64: null pointer");
+    const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
+    const dim3 grid(grid_for(B)), block(kBlock);
+#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_f64<0, WD, WS>), grid, block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B)
+    if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
+#undef LAUNCH
+    return check_launch("so3_angle_error_f64");
+}
+
+int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_geodesic_f64: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && theta != nullptr, "so3_geodesic_f64: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((k_angle_f64<1, true, false>), dim3(grid_for(B)), dim3(kBlock), 0, s, R1, R2, theta, nullptr, nullptr, 1.0, B);
+    return check_launch("so3_geodesic_f64");
+}
+
+int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f64: B");
+    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f64: loss_sum is null");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+    if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset");
+    if (B == 0) {
+        if (loss_mean != nullptr) { e = hipMemsetAsync(loss_mean, 0, sizeof(double), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset"); }
+        return 0;
+    }
+    SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f64: null pointer");
+    const double inv_b = 1.0 / static_cast<double>(B);
+    const dim3 grid(grid_for(B)), block(kBlock);
+    if (dRpred) hipLaunchKernelGGL((k_frob_loss_f64<true>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b);
+    else hipLaunchKernelGGL((k_frob_loss_f64<false>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b);
+    if (loss_mean != nullptr) k_mean_from_sum_f64<<<1, 1, 0, s>>>(loss_sum, loss_mean, inv_b);
+    return check_launch("so3_frob_loss_f64");
 }
 
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {

@@ -20,8 +20,6 @@ no CPU path: a CPU tensor, or a missing libso3proj.so, raises.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -286,13 +284,29 @@ def _is_f64(*ts) -> bool:
     return any(isinstance(t, torch.Tensor) and t.dtype == torch.float64 for t in ts)
 
 
-def _cos_f64(r1: torch.Tensor, r2: torch.Tensor) -> torch.Tensor:
-    """(tr(R1^T R2) - 1) / 2 in float64 (rotation_representation.py:232-236 / :212-216: the two traces are equal)."""
-    a = _as_blocks(r1).double()
-    b = _as_blocks(r2).double()
-    if a.shape != b.shape:
+def _f64_blocks(t: torch.Tensor) -> torch.Tensor:
+    m = _as_blocks(t)
+    return m if m.dtype is torch.float64 else m.double()
+
+
+def _angle_call_f64(r1, r2, want_rows, want_sum, radians=False, geodesic=False):
+    """float64 arguments (the reference casts to float64 before the product, rotation_representation.py:232-233, and returns
+    the arguments' dtype from the geodesic distance): the same kernels' arithmetic on float64 data, so3_*_f64."""
+    dev = _require_device(r1, r2)
+    a, b_ = _f64_blocks(r1), _f64_blocks(r2)
+    if a.shape != b_.shape:
         raise RuntimeError(f"angle_error: shape mismatch {tuple(r1.shape)} vs {tuple(r2.shape)}")
-    return ((a * b).sum(1) - 1.0) / 2.0
+    n = a.shape[0]
+    rows = torch.empty((n,), dtype=torch.float64, device=dev) if want_rows else None
+    sc = torch.empty((2,), dtype=torch.float64, device=dev) if want_sum else None
+    flag = None if geodesic else torch.empty((1,), dtype=torch.int32, device=dev)
+    with _on_device(dev):
+        if geodesic:
+            _check(_libh().so3_geodesic_f64(a.data_ptr(), b_.data_ptr(), rows.data_ptr(), n, _stream(dev)), "so3_geodesic_f64")
+        else:
+            _check(_libh().so3_angle_error_f64(a.data_ptr(), b_.data_ptr(), _ptr(rows), _ptr(sc), flag.data_ptr(), 1 if radians else 0, n,
+                                               _stream(dev)), "so3_angle_error_f64")
+    return rows, sc, flag
 
 
 def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> torch.Tensor:
@@ -303,15 +317,12 @@ def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> t
     `check=False` skips the read (and the raise) for benchmarking / graph capture.
 
     float64 arguments (the reference casts to float64 before the product, :232-233): K4 reads float32 data, so
-    double tensors take the reference's own expression in float64 on the device instead of being rounded.
+    double tensors go to its float64 twin (so3_angle_error_f64) instead of being rounded.
     """
     if _is_f64(t_R1, t_R2):
-        _require_device(t_R1, t_R2)
-        cos = _cos_f64(t_R1, t_R2)
-        if check and bool(((cos < -1.1) | (cos > 1.1)).any().item()):
-            raise ValueError(_RANGE_MSG)
-        return torch.acos(cos.clamp(-1.0, 1.0)) * (180.0 / math.pi)
-    deg, _, flag = _angle_call(t_R1, t_R2, True, False)
+        deg, _, flag = _angle_call_f64(t_R1, t_R2, True, False)
+    else:
+        deg, _, flag = _angle_call(t_R1, t_R2, True, False)
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
     return deg
@@ -322,7 +333,7 @@ def angle_error_sum_count(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = 
 
     This pair is what one all-reduce sums across GPUs (poseestimation_amd.distributed); the
     per-row vector is never materialised."""
-    _, sc, flag = _angle_call(t_R1, t_R2, False, True)
+    _, sc, flag = (_angle_call_f64 if _is_f64(t_R1, t_R2) else _angle_call)(t_R1, t_R2, False, True)
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
     return sc
@@ -363,10 +374,10 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
 
 def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
     """Geodesic distance in radians, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,); the arguments' dtype as the
-    reference (rotation_representation.py:209-227): float32 through K4', float64 through the same expression in float64."""
+    reference (rotation_representation.py:209-227): float32 through K4', float64 through so3_geodesic_f64."""
     dev = _require_device(m1, m2)
     if _is_f64(m1, m2):
-        return torch.acos(_cos_f64(m1, m2).clamp(-1.0, 1.0))
+        return _angle_call_f64(m1, m2, True, False, geodesic=True)[0]
     a, b_ = _f32_blocks(m1), _f32_blocks(m2)
     if a.shape != b_.shape:
         raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
@@ -384,19 +395,25 @@ class _LossFrobenius(torch.autograd.Function):
     @staticmethod
     def forward(ctx, r_pred, r_true):
         dev = _require_device(r_pred, r_true)
-        p, t = _f32_blocks(r_pred.detach()), _f32_blocks(r_true.detach())
+        f64 = r_pred.dtype is torch.float64 or r_true.dtype is torch.float64      # torch's promotion: the loss is float64 then
+        blocks = _f64_blocks if f64 else _f32_blocks
+        p, t = blocks(r_pred), blocks(r_true)
         if p.shape != t.shape:
             raise RuntimeError(f"loss_frobenius: shape mismatch {tuple(r_pred.shape)} vs {tuple(r_true.shape)}")
         b = p.shape[0]
         need_grad = r_pred.requires_grad or r_true.requires_grad
         g = torch.empty_like(p) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)              # the kernel writes the float32 mean itself
+        loss = torch.empty((), dtype=torch.float64 if f64 else torch.float32, device=dev)       # the mean is written by the kernel
         with _on_device(dev):
             st = _stream(dev)
-            ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-            _check(_libh().so3_frob_loss_ws_f32(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
-                   "so3_frob_loss_f32")
+            if f64:
+                _check(_libh().so3_frob_loss_f64(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), b, st),
+                       "so3_frob_loss_f64")
+            else:
+                ws = _workspace(dev, st) if b > _SMALL_BATCH else None
+                _check(_libh().so3_frob_loss_ws_f32(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
+                       "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
         return loss
@@ -420,13 +437,7 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
     A training step should use `frobenius_head`, which fuses head, loss and backward into one launch.
 
     Returns the arguments' dtype as the reference (3D-Pose/loss.py:7-11): float32 through K3'; if either argument is
-    float64 (e.g. the float64 head's output) the reference's three operations run in float64 on the device."""
-    if _is_f64(R_pred, R_true):
-        _require_device(R_pred, R_true)
-        p, t = R_pred.reshape(-1, 3, 3), R_true.reshape(-1, 3, 3)
-        if p.shape != t.shape:
-            raise RuntimeError(f"loss_frobenius: shape mismatch {tuple(R_pred.shape)} vs {tuple(R_true.shape)}")
-        return torch.linalg.matrix_norm(t - p, ord="fro").mean()
+    float64 (e.g. the float64 head's output) its float64 twin, so3_frob_loss_f64."""
     return _LossFrobenius.apply(R_pred, R_true)
 
 

@@ -119,6 +119,9 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
                 assert "so3_oracle" not in text and "libso3oracle" not in text, f
                 assert "linalg.svd" not in text and "torch.svd" not in text, f
+                if f.endswith(".py"):          # no ATen arithmetic stands in for a kernel: float64 arguments have kernels of their own
+                    for banned in ("torch.acos", ".acos(", "matrix_norm", "linalg.norm("):
+                        assert banned not in text, (f, banned)
 
 
 def test_dispatch_table_keys():

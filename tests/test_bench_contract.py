@@ -41,6 +41,12 @@ def test_bench_json_contract(mode):
     # both clocks are reported: the host clock of the contract and the HIP events the roofline uses
     assert d["ms_per_step_events"] <= d["ms_per_step"] and abs(r["avg_launch_us"] - d["ms_per_step_events"] * 1e3) < 1e-6
     assert r["traffic"] is None or "stored profile" in r["traffic_source"]
+    # the fraction on the contract's clock beside the event one, and the per-launch spread (median, fastest of 20 eager launches)
+    assert abs(r["frac_host_clock"] - 72.0 * 1_000_000 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and r["frac_host_clock"] <= r["frac"]
+    assert 0 < r["min_us"] <= r["median_us"] < 100.0
+    c4 = d["secondary"]["config4_head_loss_backward_b512_bf16"]
+    assert c4["us_per_step_empty_autograd_function_floor"] > 0 and c4["mirror_over_floor"] > 0.5
+    assert d["secondary"]["config1_head_b512_no_grad"]["us_per_call_host_clock"] > 0
     # the kernel is named by the library from the launch's own template arguments, not by a literal in bench.py
     assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false>,") and r["kernel"].endswith(">")
     if mode == "graph":

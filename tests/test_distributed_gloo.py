@@ -52,3 +52,61 @@ def test_two_rank_mean_angle_allreduce(tmp_path, total):
     assert res[0][0] == res[1][0]                               # identical on every rank
     assert abs(res[0][0] - res[0][1]) < 1e-9                    # equals the unsharded mean
     assert res[0][2] == 0 and res[0][3] == res[1][2] and res[1][3] == total
+
+
+# ---- bench.py's N > 1 path without a GPU: the timing / reduction skeleton under two gloo ranks -------------------------
+def _bench_worker(rank, world, port, out_dir, config5):
+    import json
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        rows, steps, warmup = (2_000 if config5 else 1_000), 6, 2
+        x = bench.first_buffer(rank, rows)                     # rank r <-> seed r (configs[1] and configs[4])
+        calls = []
+
+        def step(i):                                           # a stub step on CPU tensors: rank 1 is the slow one
+            calls.append(i)
+            time.sleep(0.002 * (1 + rank))
+
+        config = {"workload": "stub", "rows_per_gpu": rows, "global_rows": rows * world}
+        line, times = bench.run_skeleton(rank, world, steps, warmup, rows, step, lambda: None, dist, None, config,
+                                         extra_times=(lambda: 100.0 + rank,))
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"line": line, "times": times, "calls": len(calls), "x0": x[0].tolist(), "own": None}, fh)
+        if rank == 0:                                          # what main() does with the line: exactly one JSON line, rank 0 only
+            with open(os.path.join(out_dir, "stdout.txt"), "a") as fh:
+                fh.write(json.dumps(line) + "\n")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config5", [False, True])
+def test_bench_skeleton_with_two_ranks(tmp_path, config5):
+    """bench.py's timed region, MAX-reduce of the clocks and headline (bench.run_skeleton: the code main() runs around its
+    launches) with world_size 2 on CPU: value = global rows x steps / the SLOWEST rank's wall time, n_gpus = world, one
+    line from rank 0, seeds by rank."""
+    import json
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path), config5), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    rows, steps, warmup = (2_000 if config5 else 1_000), 6, 2
+    assert res[1]["line"] is None and res[0]["line"] is not None
+    lines = open(tmp_path / "stdout.txt").read().splitlines()
+    assert len(lines) == 1 and json.loads(lines[0]) == res[0]["line"]
+    line = res[0]["line"]
+    assert line["n_gpus"] == world and line["steps"] == steps and line["warmup"] == warmup and line["scaling"] == "weak"
+    assert res[0]["calls"] == res[1]["calls"] == steps + warmup
+    # both ranks hold the same job times: the MAX over ranks of the wall clock and of the extra (event) time
+    assert res[0]["times"] == res[1]["times"] and res[0]["times"][1] == 101.0
+    wall = res[0]["times"][0]
+    assert wall >= steps * 0.004                               # the slow rank's 4 ms per step, not rank 0's 2 ms
+    assert wall < steps * 0.004 * 3
+    assert abs(line["value"] - rows * world * steps / wall) <= 1e-9 * line["value"]
+    assert abs(line["ms_per_step"] - wall * 1e3 / steps) < 1e-12
+    for r in range(world):                                     # rank r's first buffer is randn under seed r
+        g = torch.Generator().manual_seed(r)
+        assert res[r]["x0"] == torch.randn(rows, 9, generator=g)[0].tolist()
