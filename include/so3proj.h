@@ -133,7 +133,8 @@ int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, do
  *              points above.  (Batches of <= 1024 rows run as one workgroup and never touch it; input that cannot take the
  *              streaming engine -- e.g. a bfloat16 view starting at an odd row -- falls back to the memset + atomics path.)
  *   loss_mean  out optional 1 float: (float)(loss_sum / B) -- what loss_frobenius returns (3D-Pose/loss.py:11), so the host
- *              side needs no launch of its own to turn the float64 sum into the float32 mean.
+ *              side needs no launch of its own to turn the float64 sum into the float32 mean.  (so3_frob_fwd_bwd_ws_*: with it,
+ *              loss_sum may be NULL for batches of <= 1024 rows.)
  * Everything else as in so3_frob_fwd_bwd_* / so3_frob_loss_f32 / so3_angle_error / so3_project_angle_error_f32. */
 size_t so3_reduce_workspace_bytes(void);
 int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
@@ -155,6 +156,12 @@ int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *s
                         int64_t B, void *stream);
 int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
                                     int32_t *range_flag, int radians, int64_t B, void *stream);
+
+/* dst[i] = src[i] * (*factor), factor a float32 scalar IN DEVICE MEMORY, n elements (float32 / bfloat16; dst may be src).
+ * The last step of the chain rule for K3's stored gradient: `loss.backward()` hands the upstream factor over as a 0-dim device
+ * tensor, and scaling by it is one launch here instead of a float() / mul / to(bfloat16) chain of the host framework. */
+int so3_scale_f32(const float *src, const float *factor, float *dst, int64_t n, void *stream);
+int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, void *stream);
 
 /* float64 arguments (the reference's metric and loss functions accept double tensors; rotation_representation.py:232-233 even
  * casts to double itself): the same quantities from float64 data in float64 arithmetic, one row per thread -- correctness

@@ -38,7 +38,7 @@ int check_launch(const char *what) {
     return e == hipSuccess ? 0 : fail((int)e, what);
 }
 
-inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- tile movers ----------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(static_cast<uint32_t>(b) << 16); }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_small(const void *__restri
     if (threadIdx.x == 0) {
         double total = 0.0;
         for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
-        *loss_sum = total;
+        if (loss_sum != nullptr) *loss_sum = total;
         if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * (1.0 / static_cast<double>(B)));   // float64 sum / B, rounded once
     }
 }
@@ -361,6 +361,37 @@ __global__ __launch_bounds__(kSmallBatch) void k_frob_loss_small(const float *__
         for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) total += red[w];
         *loss_sum = total;
         if (loss_mean != nullptr) *loss_mean = static_cast<float>(total * (1.0 / static_cast<double>(B)));
+    }
+}
+
+// dst[i] = src[i] * (*factor): the chain rule's last step for a gradient that was computed at unit upstream scale in the forward
+// launch (K3 stores d loss / dM; autograd hands loss.backward() the upstream factor as a 0-dim DEVICE tensor).  One launch
+// instead of torch's float() / mul / to(bfloat16) chain around a 4-us kernel.  16 bytes per thread; n counts elements.
+template <bool BF16>
+__global__ __launch_bounds__(kBlock) void k_scale(const void *__restrict__ src, const float *__restrict__ factor, void *__restrict__ dst, int64_t n) {
+    const float f = *factor;
+    constexpr int kPer = BF16 ? 8 : 4;
+    const int64_t i0 = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * kPer;
+    if (i0 + kPer <= n && aligned16(static_cast<const char *>(src) + i0 * (BF16 ? 2 : 4)) && aligned16(static_cast<char *>(dst) + i0 * (BF16 ? 2 : 4))) {
+        if constexpr (BF16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(src) + i0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = static_cast<uint32_t>(f32_to_bf16(bf16_to_f32(static_cast<uint16_t>(w[k] & 0xFFFFu)) * f))
+                       | static_cast<uint32_t>(f32_to_bf16(bf16_to_f32(static_cast<uint16_t>(w[k] >> 16)) * f)) << 16;
+            *reinterpret_cast<uint4 *>(static_cast<uint16_t *>(dst) + i0) = uint4{o[0], o[1], o[2], o[3]};
+        } else {
+            float4 v = *reinterpret_cast<const float4 *>(static_cast<const float *>(src) + i0);
+            v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+            *reinterpret_cast<float4 *>(static_cast<float *>(dst) + i0) = v;
+        }
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + kPer; ++i) {
+            if constexpr (BF16) static_cast<uint16_t *>(dst)[i] = f32_to_bf16(bf16_to_f32(static_cast<const uint16_t *>(src)[i]) * f);
+            else static_cast<float *>(dst)[i] = static_cast<const float *>(src)[i] * f;
+        }
     }
 }
 
@@ -1441,9 +1472,9 @@ inline bool use_workspace(void *workspace, int64_t nunits, unsigned tile_wgs) {
 template <bool BF16>
 int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
-    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_fwd_bwd: loss_sum is null");
+    SO3_CHECK_ARGS(loss_sum != nullptr || (loss_mean != nullptr && B > 0 && B <= kSmallBatch), "so3_frob_fwd_bwd: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (B > 0 && B <= kSmallBatch) {                    // one workgroup, one launch: the kernel writes loss_sum (and the mean) itself
+    if (B > 0 && B <= kSmallBatch) {                    // one workgroup, one launch: the kernel writes loss_sum and / or the mean itself
         SO3_CHECK_ARGS(M != nullptr && Rtrue != nullptr, "so3_frob_fwd_bwd: null pointer");
         const dim3 grid(1), block(static_cast<unsigned>((B + 63) / 64 * 64));
         const float inv = 1.0f / static_cast<float>(B);
@@ -1722,6 +1753,23 @@ int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R
 int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
                                    int radians, void *workspace, int64_t B, void *stream) {
     return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, false, B, stream);
+}
+
+int so3_scale_f32(const float *src, const float *factor, float *dst, int64_t n, void *stream) {
+    SO3_CHECK_ARGS(n >= 0, "so3_scale_f32: n");
+    if (n == 0) return 0;
+    SO3_CHECK_ARGS(src != nullptr && factor != nullptr && dst != nullptr, "so3_scale_f32: null pointer");
+    hipLaunchKernelGGL((k_scale<false>), dim3(static_cast<unsigned>((n + 4 * kBlock - 1) / (4 * kBlock))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const void *>(src), factor, static_cast<void *>(dst), n);
+    return check_launch("so3_scale_f32");
+}
+int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, void *stream) {
+    SO3_CHECK_ARGS(n >= 0, "so3_scale_bf16: n");
+    if (n == 0) return 0;
+    SO3_CHECK_ARGS(src != nullptr && factor != nullptr && dst != nullptr, "so3_scale_bf16: null pointer");
+    hipLaunchKernelGGL((k_scale<true>), dim3(static_cast<unsigned>((n + 8 * kBlock - 1) / (8 * kBlock))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       src, factor, dst, n);
+    return check_launch("so3_scale_bf16");
 }
 
 int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B,

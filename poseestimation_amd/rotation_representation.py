@@ -457,14 +457,14 @@ class _FrobeniusHead(torch.autograd.Function):
         want_r = want_r or ctx.true_grad
         r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if want_r else None
         dm = torch.empty_like(m) if need_grad else None
-        loss_sum = torch.empty((1,), dtype=torch.float64, device=dev)
+        loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if b > _SMALL_BATCH or b == 0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)      # the kernel writes the float32 mean itself: no launch of ours
         lib = _libh()
         fn = lib.so3_frob_fwd_bwd_ws_bf16 if m.dtype is torch.bfloat16 else lib.so3_frob_fwd_bwd_ws_f32
         with _on_device(dev):
             st = _stream(dev)
             ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-            _check(fn(m.data_ptr(), t.data_ptr(), _ptr(r), _ptr(dm), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st), "so3_frob_fwd_bwd")
+            _check(fn(m.data_ptr(), t.data_ptr(), _ptr(r), _ptr(dm), _ptr(loss_sum), loss.data_ptr(), _ptr(ws), b, st), "so3_frob_fwd_bwd")
         ctx.dm = dm
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -482,8 +482,16 @@ class _FrobeniusHead(torch.autograd.Function):
         gx = gt = None
         if dm is not None and ctx.needs_input_grad[0]:
             # out of place: a second backward over the same graph (retain_graph, several losses) must see the stored gradient
-            # unscaled, and the tensor handed out must not alias it
-            if dm.dtype == ctx.in_dtype:
+            # unscaled, and the tensor handed out must not alias it.  One launch of ours (so3_scale_*) instead of torch's
+            # float() / mul / to(bfloat16) chain: the upstream factor is a 0-dim float32 device tensor.
+            if grad_loss.dtype is torch.float32 and grad_loss.is_cuda and dm.dtype is ctx.in_dtype:
+                dev = dm.device
+                gx = torch.empty_like(dm)
+                fn = _libh().so3_scale_bf16 if dm.dtype is torch.bfloat16 else _libh().so3_scale_f32
+                with _on_device(dev):
+                    _check(fn(dm.data_ptr(), grad_loss.data_ptr(), gx.data_ptr(), dm.numel(), _stream(dev)), "so3_scale")
+                gx = gx.view(ctx.in_shape)
+            elif dm.dtype == ctx.in_dtype:
                 gx = (dm * grad_loss).view(ctx.in_shape)
             else:
                 gx = (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape)

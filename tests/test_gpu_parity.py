@@ -597,6 +597,32 @@ def test_fused_head_backward_twice_over_one_graph(rr):
     assert (g1 - 3.0 * x2.grad).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scale_by_a_device_scalar(rr, dtype):
+    """so3_scale_*: dst = src * (*factor) with the factor in device memory -- what _FrobeniusHead.backward launches instead of
+    torch's float() / mul / to(bfloat16) chain.  Bit-equal to that chain, for ragged lengths and unaligned views."""
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    fn = lib.so3_scale_bf16 if dtype == torch.bfloat16 else lib.so3_scale_f32
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    base = torch.randn(40_000, device=DEV, generator=gen).to(dtype)
+    factor = torch.tensor(-0.37, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for off, n in ((0, 4608), (0, 4607), (1, 4608), (3, 1), (0, 0), (2, 39_990)):
+        src = base[off:off + n]
+        dst = torch.full((n + 8,), 7.0, device=DEV).to(dtype)
+        assert fn(src.data_ptr(), factor.data_ptr(), dst[3:].data_ptr(), n, st) == 0
+        assert torch.equal(dst[3:3 + n], (src.float() * factor).to(dtype)) and (dst[:3].float() == 7).all() and (dst[3 + n:].float() == 7).all()
+    # through autograd: an upstream factor that is not 1, bfloat16 and float32 storage
+    x = torch.randn(512, 9, device=DEV, generator=gen).to(dtype).requires_grad_(True)
+    t = rr.symmetric_orthogonalization(torch.randn(512, 9, device=DEV, generator=gen))
+    loss, _ = rr.frobenius_head(x, t)
+    (loss * 2.5).backward()
+    x1 = x.detach().clone().requires_grad_(True)
+    rr.frobenius_head(x1, t)[0].backward()
+    assert x.grad.dtype == dtype and torch.equal(x.grad, (x1.grad.float() * 2.5).to(dtype))
+
+
 @pytest.mark.parametrize("b", [512, 4000])
 def test_fused_head_is_differentiable_in_the_target_too(rr, b):
     """The reference's loss is differentiable in both arguments (3D-Pose/loss.py:7-11: plain tensor arithmetic):
