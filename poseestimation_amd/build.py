@@ -33,8 +33,32 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_fastcall(force: bool = False, verbose: bool = False):
+    """The CPython entry for enqueue-only calls (csrc/fastcall.c), next to the package.  Optional: returns None when no C
+    compiler or Python.h is available -- the mirror then calls through ctypes."""
+    import sysconfig
+    src = os.path.join(CSRC, "fastcall.c")
+    out = os.path.join(_HERE, "_so3fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cc = shutil.which("gcc") or shutil.which("cc")
+    inc = sysconfig.get_paths().get("include")
+    if cc is None or inc is None or not os.path.exists(os.path.join(inc, "Python.h")):
+        return None
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-I", inc, "-o", out + ".tmp", src]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    os.replace(out + ".tmp", out)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 (cross-compiles without a GPU).  Returns the .so path."""
+    build_fastcall(force, verbose)
     if not force and not is_stale():
         return LIB
     cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]

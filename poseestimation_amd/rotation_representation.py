@@ -45,6 +45,29 @@ def _libh():
     return _L
 
 
+try:                                  # csrc/fastcall.c: METH_FASTCALL entry for the enqueue-only calls (ctypes: ~2.5 us per call)
+    from . import _so3fast
+except ImportError:                   # not built (no C compiler / Python.h): every call goes through ctypes
+    _so3fast = None
+_FAST = {}
+
+
+def _fn(name: str):
+    """The C-ABI entry point `name` as a callable taking plain ints / None (pointers, sizes, the stream) and returning the int
+    status: through _so3fast when it is built, else the ctypes function (argtypes declared in _lib.py).  Integer arguments only."""
+    f = _FAST.get(name)
+    if f is None:
+        cfn = getattr(_libh(), name)
+        if _so3fast is not None:
+            import ctypes
+            import functools
+            f = functools.partial(_so3fast.call, ctypes.cast(cfn, ctypes.c_void_p).value)
+        else:
+            f = cfn
+        _FAST[name] = f
+    return f
+
+
 def _require_device(*tensors: torch.Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -175,13 +198,12 @@ def _head_fns(dtype):
     """(forward, backward) entry points and the dtype the rotation / upstream gradient travel in."""
     fns = _HEAD_FNS.get(dtype)
     if fns is None:
-        lib = _libh()
         if dtype == torch.bfloat16:
-            fns = (lib.so3_project_fwd_bf16, lib.so3_project_bwd_bf16, torch.float32)
+            fns = (_fn("so3_project_fwd_bf16"), _fn("so3_project_bwd_bf16"), torch.float32)
         elif dtype == torch.float64:
-            fns = (lib.so3_project_fwd_f64, lib.so3_project_bwd_f64, torch.float64)
+            fns = (_fn("so3_project_fwd_f64"), _fn("so3_project_bwd_f64"), torch.float64)
         else:
-            fns = (lib.so3_project_fwd_f32, lib.so3_project_bwd_f32, torch.float32)
+            fns = (_fn("so3_project_fwd_f32"), _fn("so3_project_bwd_f32"), torch.float32)
         _HEAD_FNS[dtype] = fns
     return fns
 
@@ -275,7 +297,7 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
     sc, flag = _ZERO_POOL.take(dev)                 # zero-filled slots: the kernel needs no init launch in front of it
     with _on_device(dev):
-        _check(_libh().so3_angle_error_acc(a.data_ptr(), b_.data_ptr(), _ptr(deg), sc.data_ptr() if want_sum else None, flag.data_ptr(),
+        _check(_fn("so3_angle_error_acc")(a.data_ptr(), b_.data_ptr(), _ptr(deg), sc.data_ptr() if want_sum else None, flag.data_ptr(),
                                            1 if radians else 0, n, _stream(dev)), "so3_angle_error")
     return deg, (sc if want_sum else None), flag
 
@@ -364,7 +386,7 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     if want_deg:
         sc = None
     with _on_device(dev):
-        _check(_libh().so3_project_angle_error_acc_f32(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
+        _check(_fn("so3_project_angle_error_acc_f32")(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
                "so3_project_angle_error_f32")
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
@@ -412,7 +434,7 @@ class _LossFrobenius(torch.autograd.Function):
                        "so3_frob_loss_f64")
             else:
                 ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-                _check(_libh().so3_frob_loss_ws_f32(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
+                _check(_fn("so3_frob_loss_ws_f32")(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
                        "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
@@ -446,10 +468,13 @@ class _FrobeniusHead(torch.autograd.Function):
     def forward(ctx, x, r_true, want_r):
         dev = x.device if (x.is_cuda and r_true.is_cuda and x.device == r_true.device) else _require_device(x, r_true)
         m = _head_input(x)
-        t = _f32_blocks(r_true)
         b = m.shape[0]
-        if t.shape[0] != b:
-            raise RuntimeError(f"frobenius_head: {b} predictions vs {t.shape[0]} targets")
+        if r_true.dtype is torch.float32 and r_true.is_contiguous() and r_true.numel() == 9 * b:
+            t = r_true                                               # (B,3,3) or (B,9) as stored: only its address is needed
+        else:
+            t = _f32_blocks(r_true)
+            if t.shape[0] != b:
+                raise RuntimeError(f"frobenius_head: {b} predictions vs {t.shape[0]} targets")
         need_grad = x.requires_grad
         # d loss / d R_true = -(R - R_true) / (B ||R - R_true||_F), the loss being differentiable in both arguments
         # (3D-Pose/loss.py:7-11): it is rebuilt in backward from R and R_true (K3'), so R is kept whenever it is asked for
@@ -459,8 +484,7 @@ class _FrobeniusHead(torch.autograd.Function):
         dm = torch.empty_like(m) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if b > _SMALL_BATCH or b == 0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)      # the kernel writes the float32 mean itself: no launch of ours
-        lib = _libh()
-        fn = lib.so3_frob_fwd_bwd_ws_bf16 if m.dtype is torch.bfloat16 else lib.so3_frob_fwd_bwd_ws_f32
+        fn = _fn("so3_frob_fwd_bwd_ws_bf16" if m.dtype is torch.bfloat16 else "so3_frob_fwd_bwd_ws_f32")
         with _on_device(dev):
             st = _stream(dev)
             ws = _workspace(dev, st) if b > _SMALL_BATCH else None
@@ -487,7 +511,7 @@ class _FrobeniusHead(torch.autograd.Function):
             if grad_loss.dtype is torch.float32 and grad_loss.is_cuda and dm.dtype is ctx.in_dtype:
                 dev = dm.device
                 gx = torch.empty_like(dm)
-                fn = _libh().so3_scale_bf16 if dm.dtype is torch.bfloat16 else _libh().so3_scale_f32
+                fn = _fn("so3_scale_bf16" if dm.dtype is torch.bfloat16 else "so3_scale_f32")
                 with _on_device(dev):
                     _check(fn(dm.data_ptr(), grad_loss.data_ptr(), gx.data_ptr(), dm.numel(), _stream(dev)), "so3_scale")
                 gx = gx.view(ctx.in_shape)

@@ -141,3 +141,27 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_fastcall_module_reaches_the_library_without_a_gpu():
+    """poseestimation_amd/_so3fast (csrc/fastcall.c): the METH_FASTCALL entry the mirror uses for its enqueue-only calls.  No
+    compute here: the version call, argument conversion (None = null pointer, ints above 2^63, negative ints) and an error
+    status that the library raises before it touches the device."""
+    import ctypes
+    from poseestimation_amd import _lib, build
+    if build.build_fastcall() is None:
+        pytest.skip("no C compiler / Python.h: the mirror calls through ctypes")
+    from poseestimation_amd import _so3fast
+    lib = _lib.load()
+    addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+    assert _so3fast.call(addr("so3_version")) == lib.so3_version() == 100
+    assert _so3fast.call(addr("so3_version"), 1, None, 2 ** 63 + 5, -1) == 100          # extra integer arguments are ignored
+    assert _so3fast.call(addr("so3_scale_f32"), None, None, None, 5, None) != 0          # null pointers: SO3_ERR_INVALID
+    assert b"so3_scale_f32" in lib.so3_last_error()
+    assert _so3fast.call(addr("so3_project_fwd_f32"), None, None, None, 0, None) == 0     # B = 0: nothing to do, no launch
+    with pytest.raises(TypeError):
+        _so3fast.call()
+    with pytest.raises(ValueError):
+        _so3fast.call(0)
+    with pytest.raises(TypeError):
+        _so3fast.call(addr("so3_version"), 1.5)
