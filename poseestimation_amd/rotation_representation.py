@@ -208,6 +208,14 @@ def _head_fns(dtype):
     return fns
 
 
+def _no_double_backward() -> None:
+    """What torch's once_differentiable decorator guards against, at a fraction of its price (a no_grad context per call): these
+    backward functions launch kernels autograd cannot see, so backward-of-backward (create_graph=True) must fail loudly."""
+    if torch.is_grad_enabled():
+        raise RuntimeError("trying to differentiate twice a function that was marked with @once_differentiable "
+                           "(poseestimation_amd kernels do not support double backward; the reference never uses it)")
+
+
 def _check(code: int, what: str) -> None:
     if code != 0:
         _lib.check(code, what)
@@ -232,8 +240,8 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
         return r
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, grad_r):
+        _no_double_backward()
         (m,) = ctx.saved_tensors
         dev = m.device
         _, fn, g_dtype = _head_fns(m.dtype)
@@ -464,8 +472,11 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
 
 
 class _FrobeniusHead(torch.autograd.Function):
+    """One differentiable output (the loss); the rotation, which carries no gradient, leaves through `box` instead of being a
+    second output that autograd would have to wrap, mark and track."""
+
     @staticmethod
-    def forward(ctx, x, r_true, want_r):
+    def forward(ctx, x, r_true, want_r, box):
         dev = x.device if (x.is_cuda and r_true.is_cuda and x.device == r_true.device) else _require_device(x, r_true)
         m = _head_input(x)
         b = m.shape[0]
@@ -494,14 +505,12 @@ class _FrobeniusHead(torch.autograd.Function):
         ctx.in_dtype = x.dtype
         if ctx.true_grad:
             ctx.rt = (r, t, r_true.shape, r_true.dtype)
-        if want_r:
-            ctx.mark_non_differentiable(r)
-            return loss, r
-        return loss, torch.empty(0, device=dev)
+        box.append(r)
+        return loss
 
     @staticmethod
-    @once_differentiable
-    def backward(ctx, grad_loss, _grad_r):
+    def backward(ctx, grad_loss):
+        _no_double_backward()
         dm = ctx.dm
         gx = gt = None
         if dm is not None and ctx.needs_input_grad[0]:
@@ -528,7 +537,7 @@ class _FrobeniusHead(torch.autograd.Function):
             with _on_device(dev):
                 _check(_libh().so3_frob_loss_f32(_ptr(r), _ptr(t), _ptr(g), _ptr(scratch), b, _stream(dev)), "so3_frob_loss_f32")
             gt = (g * (-grad_loss)).to(dtype).view(shape)
-        return gx, gt, None
+        return gx, gt, None, None
 
 
 def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool = True):
@@ -543,8 +552,9 @@ def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool 
         r64 = symmetric_orthogonalization(x)
         loss64 = loss_frobenius(R_true.to(torch.float64), r64)
         return (loss64, r64.detach()) if return_rotation else loss64
-    loss, r = _FrobeniusHead.apply(x, R_true, return_rotation)
-    return (loss, r) if return_rotation else loss
+    box = []
+    loss = _FrobeniusHead.apply(x, R_true, return_rotation, box)
+    return (loss, box[0]) if return_rotation else loss
 
 
 class FrobeniusHeadStep:
