@@ -548,7 +548,7 @@ def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool 
     float64 x: the fused kernel is float32 / bfloat16 only, so the float64 head and the float64 loss are composed
     (same values and dtypes as the reference's two calls).
     """
-    if _is_f64(x):
+    if x.dtype is torch.float64:
         r64 = symmetric_orthogonalization(x)
         loss64 = loss_frobenius(R_true.to(torch.float64), r64)
         return (loss64, r64.detach()) if return_rotation else loss64
