@@ -157,6 +157,11 @@ int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *s
 int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
                                     int32_t *range_flag, int radians, int64_t B, void *stream);
 
+/* Diagnostic: K1 one row per thread (the same arithmetic, bit for bit, as so3_project_fwd_f32) plus, per row, the device's own
+ * verdict: hard[b] = 1 where the quaternion fast path did not certify its result and the row was redone by the Jacobi path.
+ * For tests that search for inputs the certificate wrongly accepts (tests/test_gpu_parity.py); not a production entry point. */
+int so3_project_fwd_diag_f32(const float *M, float *R, uint8_t *hard, int64_t B, void *stream);
+
 /* dst[i] = src[i] * (*factor), factor a float32 scalar IN DEVICE MEMORY, n elements (float32 / bfloat16; dst may be src).
  * The last step of the chain rule for K3's stored gradient: `loss.backward()` hands the upstream factor over as a 0-dim device
  * tensor, and scaling by it is one launch here instead of a float() / mul / to(bfloat16) chain of the host framework. */

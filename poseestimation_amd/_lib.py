@@ -36,6 +36,7 @@ SYMBOLS = {
     "so3_angle_error_f64": (_INT, [_P, _P, _P, _P, _P, _INT, _I64, _P]),
     "so3_geodesic_f64": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_frob_loss_f64": (_INT, [_P, _P, _P, _P, _P, _I64, _P]),
+    "so3_project_fwd_diag_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_scale_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_scale_bf16": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_reduce_workspace_bytes": (ctypes.c_size_t, []),

@@ -972,6 +972,23 @@ __global__ __launch_bounds__(kBlock) void k_add_l1(const float *__restrict__ Tgt
 // ---- float64 head and backward (the reference's functions accept double tensors): the same templates over
 // T = double, one row per thread with plain loads -- a convenience path, not a benchmark configuration.
 // Four fixed sweeps, then sweeps until the wave-wide residual is below 1e-14 (at most six more).
+// Diagnostic twin of K1 (tests/test_gpu_parity.py: the adversarial search on the fast path's certificate): one row per thread,
+// R as every forward kernel computes it (project_rotation<float>: the same IEEE operations as the packed engine) and, beside it,
+// the DEVICE's own verdict -- did the fast path settle the row, or did it hand it to the Jacobi path.
+__global__ __launch_bounds__(kBlock) void k_project_diag(const float *__restrict__ M, float *__restrict__ R, uint8_t *__restrict__ hard, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const bool active = row < B;
+    float m[9], r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = active ? M[row * 9 + i] : ((i & 3) == 0 ? 1.f : 0.f);
+    const bool h = so3::project_rotation<float>(m, r);
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[row * 9 + i] = r[i];
+        hard[row] = h ? 1 : 0;
+    }
+}
+
 // ---- float64 arguments of the metrics and the loss (the reference's functions accept double tensors and, for the metrics,
 // cast to double themselves: rotation_representation.py:232-233) -- one row per thread straight from global memory: not a
 // benchmark path, but no ATen arithmetic either.  MODE 0: angle_error (float64, range flag, unit = 180/pi or 1);
@@ -1753,6 +1770,14 @@ int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R
 int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
                                    int radians, void *workspace, int64_t B, void *stream) {
     return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, false, B, stream);
+}
+
+int so3_project_fwd_diag_f32(const float *M, float *R, uint8_t *hard, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd_diag_f32: B");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(M != nullptr && R != nullptr && hard != nullptr, "so3_project_fwd_diag_f32: null pointer");
+    hipLaunchKernelGGL(k_project_diag, dim3(grid_for(B)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), M, R, hard, B);
+    return check_launch("so3_project_fwd_diag_f32");
 }
 
 int so3_scale_f32(const float *src, const float *factor, float *dst, int64_t n, void *stream) {
