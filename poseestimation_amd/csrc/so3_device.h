@@ -476,6 +476,7 @@ constexpr float kQuatTau = 1e-3f;       // first pass
 constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
 constexpr int kQuatExtra = 2;           // how many further refinements a row may take
 constexpr float kQuatConv = 4e-4f;
+constexpr float kQuatUlps = 1.2e-7f;    // 2 ulp: the round-off of a float32 Rayleigh quotient, added to every measured move of lambda
 constexpr float kQuatResid = 8e-7f;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
 constexpr float kQuatWindowLo = 3.7252903e-9f, kQuatWindowHi = 17179869184.0f;   // 2^-28 <= |M|_F^2 <= 2^34 (see quat_rotation, step 1)
 constexpr float kQuatCurv = 0.5f;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
@@ -559,7 +560,11 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
     const typename R::mask separated = R::gt(trace, (l2 * lam_after) * tau);
     // the scale of (2) is the LARGER of the two: a shift far above the spectrum has a huge, healthy-looking adjugate
     const T lmax2 = R::max(l2, lam_before * lam_before);
-    const typename R::mask converged = R::le(R::abs(lam_before - lam_after) * (lmax2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
+    // ... plus what float32 cannot see: lambda itself carries ~2 ulp of round-off however still the iteration stands (a move of
+    // exactly zero proved nothing: round 3's search on the device found rows with a gap of 7e-6 s1 accepted that way, their
+    // rotation off by 0.7).  With the floor, (2) also bounds the gap from below: gap >= 2 ulp lambda / kQuatConv ~ 3e-4 lambda.
+    const T moved = R::fma(R::max(R::abs(lam_before), R::abs(lam_after)), R::splat(S(kQuatUlps)), R::abs(lam_before - lam_after));
+    const typename R::mask converged = R::le(moved * (lmax2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
     const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
     return separated & converged & topmost;
 }
