@@ -1197,7 +1197,11 @@ constexpr int kStatLdsClasses = 16;
 constexpr int kStatBlock = 1024;
 template <int LCLS, bool FIRST>
 __global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restrict__ deg, const int32_t *__restrict__ cls,
-                                                           int ncls, StatWork *w, int64_t B, int pass, double *__restrict__ stats) {
+                                                           int ncls, StatWork *w, int64_t B, int pass, double *__restrict__ stats, int mode) {
+    // gfx950 only: the 64-class instantiation holds 128 KB of histograms + 16 KB of sums in LDS (the CU has 160 KB; 64 KB parts
+    // could not build it), one 1024-thread workgroup per CU
+    static_assert(sizeof(unsigned int) * 2 * LCLS * 256 + sizeof(double) * (FIRST ? LCLS : 1) * 8 * (FIRST ? (LCLS <= 16 ? 16 : 4) : 1)
+                      + sizeof(unsigned long long) * 2 * kMaxClasses + 64 <= 160 * 1024, "k_stats_pass: LDS budget of a gfx950 CU");
     constexpr bool LDS = true;
     constexpr int kSlots = LCLS <= 16 ? 16 : 4;
     __shared__ unsigned int sh[2][LCLS][256];
@@ -1233,16 +1237,28 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restr
                 else atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
             }
     };
-    // two rows per thread and trip: one 16-byte and one 8-byte load (B even part), the odd last row by itself
-    const int64_t pairs = B / 2;
+    // two rows per thread and trip: one 16-byte and one 8-byte load where both arrays allow it from row `head` on (mode 0 / 1:
+    // head = 0 / 1 -- views like deg[1:], cls[1:] are 8 / 4 bytes off), two scalar loads each otherwise (mode 2); a leading
+    // and an odd last row by themselves
+    const int64_t head = mode == 1 ? 1 : 0;
+    const int64_t pairs = (B - head) / 2;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kStatBlock + threadIdx.x; i < pairs; i += static_cast<int64_t>(gridDim.x) * kStatBlock) {
-        const double2 a = reinterpret_cast<const double2 *>(deg)[i];
+        double2 a;
         int2 c = make_int2(0, 0);
-        if (cls) c = reinterpret_cast<const int2 *>(cls)[i];
+        if (mode == 2) {
+            a.x = deg[2 * i]; a.y = deg[2 * i + 1];
+            if (cls) { c.x = cls[2 * i]; c.y = cls[2 * i + 1]; }
+        } else {
+            a = reinterpret_cast<const double2 *>(deg + head)[i];
+            if (cls) c = reinterpret_cast<const int2 *>(cls + head)[i];
+        }
         row(a.x, c.x);
         row(a.y, c.y);
     }
-    if ((B & 1) && blockIdx.x == 0 && threadIdx.x == 0) row(deg[B - 1], cls ? cls[B - 1] : 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (head == 1 && B > 0) row(deg[0], cls ? cls[0] : 0);
+        if ((B - head) & 1) row(deg[B - 1], cls ? cls[B - 1] : 0);
+    }
     __syncthreads();
     if (LDS) {
         for (int i = threadIdx.x; i < 2 * ncls * 256; i += kStatBlock) {
@@ -1978,11 +1994,16 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     StatWork *w = static_cast<StatWork *>(workspace);
     const hipError_t e = hipMemsetAsync(w, 0, sizeof(StatWork), s);
     if (e != hipSuccess) return fail(static_cast<int>(e), "so3_angle_stats: memset");
+    // 16-byte loads of deg and 8-byte loads of cls from row 0 (mode 0) or row 1 (mode 1) on, wherever both arrays are aligned there
+    auto vec_ok = [&](int64_t head) {
+        return (reinterpret_cast<uintptr_t>(deg + head) & 15u) == 0 && (cls == nullptr || (reinterpret_cast<uintptr_t>(cls + head) & 7u) == 0);
+    };
+    const int mode = vec_ok(0) ? 0 : (vec_ok(1) ? 1 : 2);
     const int64_t want = (B / 2 + kStatBlock - 1) / kStatBlock;
     const int64_t cap = 2 * static_cast<int64_t>(device_cus());
     const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));
     for (int pass = 0; pass < kStatPasses; ++pass) {
-#define PASS(LC, FI) k_stats_pass<LC, FI><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, pass, stats)
+#define PASS(LC, FI) k_stats_pass<LC, FI><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, pass, stats, mode)
         if (ncls <= kStatLdsClasses) { if (pass == 0) PASS(kStatLdsClasses, true); else PASS(kStatLdsClasses, false); }
         else { if (pass == 0) PASS(kMaxClasses, true); else PASS(kMaxClasses, false); }
 #undef PASS

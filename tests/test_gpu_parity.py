@@ -125,6 +125,59 @@ def test_ragged_batches_and_unaligned_pointers(rr, c_oracle, b):
     assert np.quantile(np.abs(r - c_oracle.project(x[::2])), 0.9) < 1e-6
 
 
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_offset_views_row_by_row_against_the_oracle(rr, c_oracle, off):
+    """Views that start at row 1, 2 or 3 of a tensor (base pointers 4 / 8 / 12 bytes off 16-byte alignment: the shards of an
+    uneven split) stream through the engine's 16-byte buffer loads and stores.  EVERY row of K1, K2, K3 and K4 on such a
+    view is compared with the float64 oracle in the conditioned measure -- a shifted or stale element anywhere in a misaligned
+    block shows up as an O(1) error in that row -- and a bfloat16 view at an even row offset likewise."""
+    from oracle import so3_oracle as so
+    b = 64 * 37 + 11                                         # whole units and a remainder
+    rng = np.random.default_rng(100 + off)
+    x = rng.standard_normal((b + 4, 9)).astype(np.float32)
+    t = so.symmetric_orthogonalization_np(rng.standard_normal((b + 4, 9))).astype(np.float32).reshape(-1, 9)
+    g = rng.standard_normal((b + 4, 9)).astype(np.float32)
+    xs, ts, gs = x[off:off + b], t[off:off + b], g[off:off + b]
+    ref, s, d = so.symmetric_orthogonalization_np(xs, return_parts=True)
+    gap = np.where(d < 0, s[:, 1] - s[:, 2], s[:, 1] + s[:, 2]) / s[:, 0]
+    cond = lambda got, want: (np.abs(np.asarray(got, np.float64).reshape(b, -1) - np.asarray(want).reshape(b, -1)).max(1) * gap).max()
+    xd, td, gd = dev(x), dev(t), dev(g)
+    assert xd[off:off + b].data_ptr() % 16 == (36 * off) % 16 != 0
+    # K1 (+ flip flags), K2
+    xv = xd[off:off + b].clone().requires_grad_(True) if False else xd[off:off + b].detach().requires_grad_(True)
+    r = rr.symmetric_orthogonalization(xv)
+    assert cond(r.detach().cpu().numpy(), ref) < 2e-6 and orth_err(r.detach().cpu().numpy()).max() < 1e-5
+    r2, flip = rr.symmetric_orthogonalization_with_flip(xd[off:off + b])
+    assert torch.equal(r2, r.detach()) and np.array_equal(flip.cpu().numpy(), d < 0)
+    r.backward(gd[off:off + b].view(b, 3, 3))
+    dref = so.projection_backward_np(xs.astype(np.float64), gs.astype(np.float64))
+    rel = np.abs(xv.grad.cpu().numpy().reshape(b, 9) - dref.reshape(b, 9)).max(1) * gap * gap * s[:, 0]
+    assert rel.max() < 2e-5
+    # K3 on the views (R, dM, loss), K3' stand-alone
+    xk = xd[off:off + b].detach().requires_grad_(True)
+    loss, rk = rr.frobenius_head(xk, td[off:off + b])
+    loss.backward()
+    lref, dxref, _ = so.frobenius_fwd_bwd_np(xs, ts)
+    assert torch.equal(rk, r.detach()) and abs(loss.item() - lref) < 2e-6
+    assert (np.abs(xk.grad.cpu().numpy().reshape(b, 9) - dxref.reshape(b, 9)).max(1) * gap * gap * s[:, 0] * b).max() < 5e-5
+    # K4 per row and fused, K4', K1+K4
+    deg = rr.angle_error(r.detach().view(b, 9)[:], td[off:off + b])
+    dref_deg = so.angle_error_np(r.detach().cpu().numpy(), ts)
+    assert np.abs(deg.cpu().numpy() - dref_deg).max() < 1e-9
+    sc = rr.angle_error_sum_count(r.detach(), td[off:off + b])
+    assert sc[1].item() == b and abs(sc[0].item() - dref_deg.sum()) < 1e-8 * b
+    fused = rr.head_angle_error(xd[off:off + b], td[off:off + b])
+    assert np.abs(fused.cpu().numpy() - dref_deg).max() < 1e-9
+    # bfloat16 storage at an even row offset (dword aligned: the engine) and an odd one (the tile kernels)
+    xb = dev(x).bfloat16()
+    for o2 in (2 * (off // 2 + 1), 2 * (off // 2) + 1):
+        xbv = xb[o2:o2 + b - 4]
+        rb = rr.symmetric_orthogonalization(xbv).cpu().numpy()
+        refb, sb, db = so.symmetric_orthogonalization_np(xbv.float().cpu().numpy(), return_parts=True)
+        gapb = np.where(db < 0, sb[:, 1] - sb[:, 2], sb[:, 1] + sb[:, 2]) / sb[:, 0]
+        assert (np.abs(rb - refb).reshape(len(rb), -1).max(1) * gapb).max() < 2e-6, o2
+
+
 def test_float64_head_and_backward(rr):
     """Double tensors go through the float64 kernels (the reference's function accepts them) and come back double."""
     from oracle import so3_oracle as so
@@ -1090,6 +1143,20 @@ def test_angle_error_statistics_match_numpy(rr, n, ncls):
         assert np.array_equal(got[k].cpu().numpy(), ref[k]), k
     assert np.abs(got["mean"].cpu().numpy() - ref["mean"]).max() < 1e-10
     assert np.abs(got["std"].cpu().numpy() - ref["std"]).max() < 1e-8
+    # sliced views: deg[1:] is 8 bytes, cls[1:] 4 bytes off the alignment of the kernel's 16- / 8-byte loads (a peeled first
+    # row), and views whose offsets disagree take scalar loads -- the same exact answers
+    ad, cd = dev(ang, torch.float64), None if cls is None else dev(cls, torch.int32)
+    for lo_a, lo_c in ((1, 1), (1, 0), (2, 1), (3, 3)):
+        m = n - 3
+        if m < 1:
+            continue
+        a_view = ad[lo_a:lo_a + m]
+        c_view = None if cd is None else cd[lo_c:lo_c + m]
+        got = rr.angle_error_statistics(a_view, c_view, ncls)
+        ref = so.angle_statistics_np(ang[lo_a:lo_a + m], None if cls is None else cls[lo_c:lo_c + m], ncls)
+        for k in ("count", "max", "median", "acc30", "acc15", "acc7.5"):
+            assert np.array_equal(got[k].cpu().numpy(), ref[k], equal_nan=True), (k, lo_a, lo_c)
+        assert np.allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-10, equal_nan=True)
 
 
 def test_angle_error_statistics_end_to_end_and_nan(rr):
