@@ -1439,7 +1439,11 @@ inline void *advance_bytes(void *p, int64_t bytes) { return p ? static_cast<char
 #ifndef SO3_K1_DMA
 #define SO3_K1_DMA 0
 #endif
+#ifndef SO3_K2_DMA
+#define SO3_K2_DMA 0
+#endif
 constexpr bool K1_DMA = SO3_K1_DMA != 0;
+constexpr bool K2_DMA = SO3_K2_DMA != 0;     // K2 / K3 with float32 storage
 template <bool BF16>
 int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
@@ -1479,7 +1483,7 @@ int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream
     const int64_t nunits = stream_units(B, {M, G, dM});
     if (nunits > 0) {
         so3::OpProjectBwd<EB> op; op.in0 = M; op.in1 = G; op.out0 = dM;
-        launch_rows<2, 2, 256>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
+        launch_rows<2, 2, 256, K2_DMA && !BF16>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
@@ -1548,7 +1552,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (nunits > 0) {
 #define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
                              op.loss_sum = loss_sum; op.inv_b = inv_b; op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); \
-                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256, K2_DMA && !BF16>(op, nunits, s); } while (0)
         if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
