@@ -6,7 +6,6 @@
 // owns row l of each) from up to three input arrays, computes, and writes up to two output arrays; wave w takes
 // rounds w, w+W, w+2W, ...  A round's units travel as one block
 //     HBM --buffer_load_dwordx4 nt--> VGPR --ds_write_b128--> LDS --ds_read_b32 (stride 9)--> lane
-//     HBM --buffer_load_dwordx4 nt lds---------------------> LDS   (DMA build: float32 inputs, no VGPR staging)
 // and back  lane --ds_write_b32--> LDS --ds_read_b128--> VGPR --buffer_store_dwordx4 nt--> HBM.
 // Design points (measurements in DESIGN.md):
 //   * NPL = 2 packs two independent matrices into the halves of v_pk_* operands (so3_device.h): a Jacobi
@@ -49,7 +48,6 @@ constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data
 #endif
 constexpr int kLoadCpol = SO3_LOAD_CPOL, kStoreCpol = SO3_STORE_CPOL;
 constexpr int kStreamNt = 2;                     // the cloud kernels' once-read points
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -75,8 +73,6 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
     static constexpr int kBytes = G * kUnitBytes;                // the round's block
     static constexpr int kVec4 = kBytes / 16;
     static constexpr int kLoads = (kVec4 + 63) / 64;             // float4 per lane (the last one partial)
-    static constexpr int kTailLanes = kVec4 - 64 * (kLoads - 1); // lanes of the last load that carry data
-    static constexpr int kImageBytes = G * kUnitRows * N * 4;    // the float32 image of the block, without padding
     // The LDS image is ALWAYS float32 (bfloat16 is converted once per block on its way in or out): lanes then read their
     // rows with ds_read_b32 at a 9-dword stride, conflict-free, whatever the storage type.  (Sub-dword reads of a bf16
     // image at an 18-byte stride made K1 with bf16 input slower than with float32 input while moving half the bytes.)
@@ -100,18 +96,6 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
         for (int j = 0; j < kLoads; ++j)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[j]), rs, (lane + 64 * j) * 16, 0, kStoreCpol);
     }
-    // LDS-DMA: the block straight from HBM into the wave's image (float32: the image is the storage format), 1 KiB per
-    // wave-instruction, lane l's 16 bytes at image + 1024 j + 16 l; the lanes of the last load that lie beyond the block are
-    // masked (they would land in the neighbouring image).  `img` is wave-uniform (M0).
-    // MASK = false: the image is padded to whole loads instead (the lanes beyond the block are dropped by the range check and
-    // write zeros into the padding) -- no exec-masked branch, which keeps the waitcnt pass's count of pending operations exact.
-    template <bool MASK> static __device__ __forceinline__ void fetch_lds(char *img, rsrc_t rs, int lane) {
-        static_assert(EB == 4, "LDS-DMA needs the storage format to be the image format");
-#pragma unroll
-        for (int j = 0; j < kLoads; ++j)
-            if (!MASK || j + 1 < kLoads || kTailLanes == 64 || lane < kTailLanes)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(img + j * 1024), 16, lane * 16, j * 1024, 0, kLoadCpol);
-    }
     // registers (storage type, 16 B per lane and load) -> float32 image in LDS
     static __device__ __forceinline__ void to_lds(char *slot, const f32x4 (&v)[kLoads], int lane) {
         f32x4 *t4 = reinterpret_cast<f32x4 *>(slot);
@@ -129,12 +113,10 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
         }
     }
     // float32 image in LDS -> registers in the storage type
-    // (MASK: the image is not padded to whole loads -- lanes beyond the block keep zeros and are cut off by the store's descriptor)
-    template <bool MASK = false> static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
+    static __device__ __forceinline__ void from_lds(f32x4 (&v)[kLoads], const char *slot, int lane) {
         const f32x4 *t4 = reinterpret_cast<const f32x4 *>(slot);
 #pragma unroll
         for (int j = 0; j < kLoads; ++j) {
-            if (MASK && j + 1 == kLoads && kTailLanes != 64 && lane >= kTailLanes) { v[j] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
             if constexpr (EB == 4) {
                 v[j] = t4[lane + 64 * j];
             } else {
@@ -160,7 +142,7 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
     }
 };
 template <int N, int G> struct UnitIO<0, N, G> {
-    static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0, kImageBytes = 0;
+    static constexpr int kBytes = 0, kVec4 = 0, kLoads = 1, kSlotBytes = 0;
 };
 
 // Per-row side outputs (flip flags, angles): one element per row, contiguous across the lanes of a unit.
@@ -262,9 +244,8 @@ template <int NPL> struct RowCtx {
 // WPS = resident waves per SIMD the register budget is sized for (the host launches CUs * 4 * WPS * 64 / BLOCK
 // workgroups); wave w of the grid takes rounds w, w + W, w + 2W, ... (static deal: tickets, two rounds in flight and
 // s_setprio were measured in round 2 and bought nothing).
-// DMA = the round's input blocks go straight into LDS (buffer_load_dwordx4 ... lds), no VGPR staging and no ds_write_b128:
-//   two LDS images per wave, the next round's loads are issued into the idle one as soon as the current round's rows
-//   are in registers.  float32 inputs only (the LDS image IS the storage format).
+// (Inputs straight into LDS -- buffer_load_dwordx4 ... lds, two images per wave, no VGPR staging -- was built and measured in
+// round 3: the copy through the engine 2 % faster, K1 5-14 % SLOWER, K2 / K3 no better; it lives in the history, not here.)
 // STAMP (diagnostic builds only, instantiated by tools/ubench/k1_anatomy.hip from its own translation unit): per wave
 //   {s_memrealtime entry, exit, s_memtime entry, cycles | XCC << 28 | HW_ID << 32, rounds done << 48, 0} and the
 //   begin / end of the arithmetic of the wave's first four rounds.
@@ -278,7 +259,7 @@ template <class Op> struct EngineIO {
     };
 };
 
-template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false, bool DMA = false>
+template <class Op, int NPL, int WPS, int BLOCK, bool STAMP = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename LaneT<NPL>::type T;
@@ -288,23 +269,15 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     typedef typename IO::I2 I2;
     typedef typename IO::O0 O0;
     typedef typename IO::O1 O1;
-    static_assert(!DMA || ((Op::kIn0 == 4) && (Op::kIn1 == 0 || Op::kIn1 == 4) && (Op::kIn2 == 0 || Op::kIn2 == 4)),
-                  "LDS-DMA lands the storage format in LDS: float32 inputs only");
     constexpr int kWaves = BLOCK / 64;
     // LDS slot of a wave: the images of the round's input blocks side by side; outputs are staged over them once the
-    // rows are in registers.  Images are padded to whole 1-KiB loads; only when the two images per wave of the DMA build would
-    // not fit the CU's 160 KiB are they cut to the exact block size and the partial last load lane-masked (kExact).
-    constexpr int kPadIn = I0::kSlotBytes + I1::kSlotBytes + I2::kSlotBytes, kPadOut = O0::kSlotBytes + O1::kSlotBytes;
-    constexpr bool kExact = DMA && 2 * (kPadIn > kPadOut ? kPadIn : kPadOut) * 4 * WPS + 1024 > 160 * 1024;
-    constexpr int kIn0B = kExact ? I0::kBytes : I0::kSlotBytes, kIn1B = kExact ? I1::kBytes : I1::kSlotBytes, kIn2B = kExact ? I2::kBytes : I2::kSlotBytes;
-    constexpr int kOut0B = kExact ? O0::kImageBytes : O0::kSlotBytes, kOut1B = kExact ? O1::kImageBytes : O1::kSlotBytes;
+    // rows are in registers.  Images are padded to whole 1-KiB loads.
+    constexpr int kIn0B = I0::kSlotBytes, kIn1B = I1::kSlotBytes, kIn2B = I2::kSlotBytes;
+    constexpr int kOut0B = O0::kSlotBytes, kOut1B = O1::kSlotBytes;
     constexpr int kInBytes = kIn0B + kIn1B + kIn2B;
     constexpr int kOutBytes = kOut0B + kOut1B;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
-    // Two arrays, not one of twice the size: distinct LDS objects carry distinct alias scopes down to the waitcnt pass, so a
-    // ds access to one image waits only for the LDS-DMA loads that target THAT image (and never for the other one's, in flight).
-    __shared__ __attribute__((aligned(16))) char lds_a[kWaves][kSlot];
-    __shared__ __attribute__((aligned(16))) char lds_b[kWaves][DMA ? kSlot : 16];
+    __shared__ __attribute__((aligned(16))) char lds[kWaves][kSlot];
     __shared__ double red[Op::kReduce ? kWaves : 1];
     __shared__ int red_flag[Op::kReduce ? kWaves : 1];
 
@@ -357,49 +330,16 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 }
                 wave_lds_fence();
                 f32x4 v0[O0::kLoads], v1[O1::kLoads];
-                if constexpr (Op::kOut0 != 0) O0::template from_lds<kExact>(v0, img, lane);
-                if constexpr (Op::kOut1 != 0) O1::template from_lds<kExact>(v1, img + kOut0B, lane);
+                if constexpr (Op::kOut0 != 0) O0::from_lds(v0, img, lane);
+                if constexpr (Op::kOut1 != 0) O1::from_lds(v1, img + kOut0B, lane);
                 wave_lds_fence();
                 const int cnt = units_of(t);            // an odd tail's phantom unit is cut off by the descriptor
                 if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, t * NPL, cnt), v0, lane);
                 if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, t * NPL, cnt), v1, lane);
             }
         };
-        if constexpr (DMA) {
-            char *img_a = lds_a[wave_in_block], *img_b = lds_b[wave_in_block];
-            auto issue = [&](char *img, int64_t tr) {       // past the last round the descriptors are empty: no traffic
-                const int cnt = units_of(tr);
-                const int64_t u = cnt > 0 ? tr * NPL : 0;
-                I0::template fetch_lds<kExact>(img, I0::rsrc(op.in0, u, cnt), lane);
-                if constexpr (Op::kIn1 != 0) I1::template fetch_lds<kExact>(img + kIn0B, I1::rsrc(op.in1, u, cnt), lane);
-                if constexpr (Op::kIn2 != 0) I2::template fetch_lds<kExact>(img + kIn0B + kIn1B, I2::rsrc(op.in2, u, cnt), lane);
-            };
-            // One round: the rows of round t (out of `cur`) are in registers; the next round's loads go into `nxt`, the results
-            // are staged over `cur`, and the next round's rows are taken at the END -- behind this round's stores, so the wait
-            // for nxt's loads is vmcnt(#stores), never a drain (and the same count on every path into the loop: taken at the top
-            // of the body instead, the first round's vmcnt(0) merges into the loop header).  False after the wave's last round.
-            auto round = [&](char *cur, char *nxt, Rows<T, Op> &rows) -> bool {
-                const int64_t tn = t + stride;
-                issue(nxt, tn);
-                phase(3);
-                op.template compute<T, NPL>(rows, ctx);
-                phase(4);
-                if (STAMP) ++rounds_done;
-                put_rows(cur, rows);
-                if (tn >= nrounds) return false;
-                t = tn;
-                wave_lds_fence();
-                take_rows(nxt, rows);
-                wave_lds_fence();
-                return true;
-            };
-            issue(img_a, t);
-            Rows<T, Op> rows;
-            take_rows(img_a, rows);                         // (the waitcnt pass holds these reads until the image's DMA has landed)
-            wave_lds_fence();
-            while (round(img_a, img_b, rows) && round(img_b, img_a, rows)) {}
-        } else {
-            char *slot = lds_a[wave_in_block];
+        {
+            char *slot = lds[wave_in_block];
             // One round is in flight in registers behind the round that sits in LDS.
             f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
             auto issue = [&](int64_t tr) {                  // past the last round the descriptors are empty: the loads

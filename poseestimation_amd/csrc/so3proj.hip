@@ -1366,15 +1366,14 @@ inline int device_cus() {
     return cus[dev];
 }
 
-// Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads;
-// DMA: inputs straight into LDS (float32 inputs only).
+// Launch an operation on the streaming engine: NPL matrices per lane, WPS resident waves per SIMD, BLOCK threads.
 // The name of a k_rows instantiation as a profiler prints it: the runtime's own (mangled) name of the kernel behind the host
 // stub, demangled, without the "void " in front and the parameter list behind.
 thread_local const char *g_last_kernel = "";
-template <class Op, int NPL, int WPS, int BLOCK, bool DMA>
+template <class Op, int NPL, int WPS, int BLOCK>
 const char *rows_kernel_name(hipStream_t s) {
     static const std::string name = [s] {
-        const char *mangled = hipKernelNameRefByPtr(reinterpret_cast<const void *>(&so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), s);
+        const char *mangled = hipKernelNameRefByPtr(reinterpret_cast<const void *>(&so3::k_rows<Op, NPL, WPS, BLOCK, false>), s);
         if (mangled == nullptr) return std::string("so3::k_rows<?>");
         int status = 0;
         char *d = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
@@ -1392,15 +1391,15 @@ const char *rows_kernel_name(hipStream_t s) {
     return name.c_str();
 }
 
-template <int NPL, int WPS, int BLOCK, bool DMA = false, class Op>
+template <int NPL, int WPS, int BLOCK, class Op>
 void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     constexpr int kWaves = BLOCK / 64;
-    g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK, DMA>(s);
+    g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK>(s);
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     const int64_t want = (rounds + kWaves - 1) / kWaves;
     const int64_t cap = static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;   // CUs x 4 SIMDs x WPS wave slots
     const dim3 grid(static_cast<unsigned>(want < cap ? want : cap)), block(BLOCK);
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), grid, block, 0, s, op, nunits, nullptr);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), grid, block, 0, s, op, nunits, nullptr);
 }
 
 // Rows [0, 64*nunits) go to the engine when every pointer is dword aligned (every float32 array is; a bfloat16 view that
@@ -1436,14 +1435,6 @@ inline const void *advance_bytes(const void *p, int64_t bytes) { return p ? stat
 inline void *advance_bytes(void *p, int64_t bytes) { return p ? static_cast<char *>(p) + bytes : nullptr; }
 
 // ---- K1 --------------------------------------------------------------------------------------------
-#ifndef SO3_K1_DMA
-#define SO3_K1_DMA 0
-#endif
-#ifndef SO3_K2_DMA
-#define SO3_K2_DMA 0
-#endif
-constexpr bool K1_DMA = SO3_K1_DMA != 0;
-constexpr bool K2_DMA = SO3_K2_DMA != 0;     // K2 / K3 with float32 storage
 template <bool BF16>
 int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd: B");
@@ -1453,9 +1444,8 @@ int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream)
     constexpr int EB = BF16 ? 2 : 4;
     const int64_t nunits = stream_units(B, {M, R});
     if (nunits > 0) {
-        constexpr bool kDma = K1_DMA && !BF16;
-        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256, kDma>(op, nunits, s); }
-        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256, kDma>(op, nunits, s); }
+        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256>(op, nunits, s); }
+        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256>(op, nunits, s); }
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
@@ -1483,7 +1473,7 @@ int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream
     const int64_t nunits = stream_units(B, {M, G, dM});
     if (nunits > 0) {
         so3::OpProjectBwd<EB> op; op.in0 = M; op.in1 = G; op.out0 = dM;
-        launch_rows<2, 2, 256, K2_DMA && !BF16>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
+        launch_rows<2, 2, 256>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
@@ -1552,7 +1542,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (nunits > 0) {
 #define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
                              op.loss_sum = loss_sum; op.inv_b = inv_b; op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); \
-                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256, K2_DMA && !BF16>(op, nunits, s); } while (0)
+                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
         if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }

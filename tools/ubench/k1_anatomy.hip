@@ -1,6 +1,6 @@
 // k1_anatomy: stand-alone timing / in-kernel-stamp tool for the streaming K1 kernel.
-// Instantiates the SAME kernel template the library ships (csrc/so3_rows.h) -- K1 and a copy through the engine,
-// register-staged and LDS-DMA -- times each with hipEvents over rotating buffers, and (STAMP build of the same
+// Instantiates the SAME kernel template the library ships (csrc/so3_rows.h) -- K1 and a copy through the engine --
+// times each with hipEvents over rotating buffers, and (STAMP build of the same
 // template) reports per-wave lifetimes and the shader clock from s_memtime / s_memrealtime.
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -o k1_anatomy k1_anatomy.hip
 #include <hip/hip_runtime.h>
@@ -38,7 +38,7 @@ struct OpCopy : so3::OpBase {
     }
 };
 
-template <class Op, int NPL, int WPS, bool DMA, int BLOCK = 256>
+template <class Op, int NPL, int WPS, int BLOCK = 256>
 void run(const char *what, float **in, float **out, unsigned long long *stamps_d) {
     const int64_t nunits = ROWS / 64;
     const int64_t rounds = (nunits + NPL - 1) / NPL;
@@ -48,18 +48,18 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
     for (int i = 0; i < 5; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
     const int K = g_launches;
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < K; ++i)
-        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
+        hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / K;
     // stamped build of the same template: wave lifetimes and clock
     CHECK(hipMemset(stamps_d, 0, 8 * 46 * 8192));
-    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true, DMA>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
+    hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
     const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, rounds);
     std::vector<unsigned long long> st6(6 * nw);
@@ -75,7 +75,7 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st6[6 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
     {   // per-wave dump for offline analysis (tools/wave_csv.py, tools/phase_csv.py)
-        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_dma%d_npl%d_wps%d.csv", what, DMA ? 1 : 0, NPL, WPS);
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_npl%d_wps%d.csv", what, NPL, WPS);
         FILE *fh = fopen(name, "w");
         if (fh) {
             fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc,first_wait_cyc,phases\n");
@@ -89,9 +89,9 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
             fclose(fh);
         }
     }
-    printf("%-8s dma=%d NPL=%d WPS=%d block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("%-8s NPL=%d WPS=%d block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           what, DMA ? 1 : 0, NPL, WPS, BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           what, NPL, WPS, BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
     fflush(stdout);
 }
@@ -107,14 +107,11 @@ int main(int argc, char **argv) {
     g_launches = argc > 1 ? atoi(argv[1]) : 1000;
     typedef so3::OpProject<4, false> K1;
     for (int rep = 0; rep < 3; ++rep) {
-        run<K1, 2, 3, false>("k1", in, out, stamps);
-        run<K1, 2, 3, true>("k1", in, out, stamps);
-        run<OpCopy, 2, 3, false>("copy", in, out, stamps);
-        run<OpCopy, 2, 3, true>("copy", in, out, stamps);
+        run<K1, 2, 3>("k1", in, out, stamps);
+        run<OpCopy, 2, 3>("copy", in, out, stamps);
     }
-    run<K1, 2, 4, true>("k1", in, out, stamps);
-    run<OpCopy, 2, 4, true>("copy", in, out, stamps);
-    run<OpCopy, 1, 4, true>("copy", in, out, stamps);
-    run<OpCopy, 1, 8, true>("copy", in, out, stamps);
+    run<OpCopy, 2, 4>("copy", in, out, stamps);
+    run<OpCopy, 1, 4>("copy", in, out, stamps);
+    run<OpCopy, 1, 8>("copy", in, out, stamps);
     return 0;
 }
