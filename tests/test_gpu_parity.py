@@ -10,12 +10,13 @@ Tolerances (float32 path):
     (flip); asserted as  err * gap/s1 < 3e-6  and  < 1e-5 absolute on well-conditioned rows.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, orth_err, well_conditioned
+from conftest import ROOT, load_golden, orth_err, well_conditioned
 
 pytestmark = pytest.mark.gpu
 
@@ -863,6 +864,58 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
         assert fl.item() == (1 if rows is bad else 0)
     torch.cuda.synchronize()
     assert int(torch.count_nonzero(ws).item()) == 0              # slots, flag and ticket are left as they were found
+
+
+def test_hard_rows_cost_is_bounded(rr):
+    """The worst case of K1 / K3 is on record and bounded (tools/k1_hard_rows.py, profiles/r03_k1_hard_rows.txt): a batch whose
+    rows are HARD for the fast path (ties, near-reflections, rank deficiency: the packed Jacobi body runs on top of the fast
+    path for every wave that holds one) costs at most 2.4 x a Gaussian batch for K1 and 1.7 x for K3 (measured: 1.7-2.1 and
+    1.35-1.5; round 2: 1.9-2.0 already at 1 % hard rows), and rows that are merely far from unit scale cost nothing extra (they
+    were hard in round 2: 1.6 x)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
+    hr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hr)
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    n, nb = 1_000_000, 3
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    out = [torch.empty(n, 9, device=DEV) for _ in range(nb)]
+    dm = [torch.empty(n, 9, device=DEV) for _ in range(nb)]
+    ls = torch.empty(1, dtype=torch.float64, device=DEV)
+    rt = hr.haar(n, torch.device(DEV), gen).reshape(n, 9).contiguous()
+
+    def timed(fn):
+        best = float("inf")
+        for _ in range(3):
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(40):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 40 * 1e3)
+        return best
+
+    def both(xs):
+        k1 = timed(lambda i: lib.so3_project_fwd_f32(xs[i % nb].data_ptr(), out[i % nb].data_ptr(), None, n, st))
+        k3 = timed(lambda i: lib.so3_frob_fwd_bwd_f32(xs[i % nb].data_ptr(), rt.data_ptr(), out[i % nb].data_ptr(), dm[i % nb].data_ptr(),
+                                                      ls.data_ptr(), n, st))
+        return k1, k3
+
+    g1, g3 = both([torch.randn(n, 9, device=DEV, generator=gen) for _ in range(nb)])
+    report = {}
+    for name, cap1, cap3 in (("near-reflection", 2.4, 1.7), ("entries in {-1,0,1}", 2.4, 1.7), ("generic ties", 2.4, 1.7), ("rank one", 2.4, 1.7),
+                             ("1e5 * Gaussian", 1.15, 1.15), ("rank two", 1.15, 1.15)):
+        xs = [hr.family(name, n, torch.device(DEV), gen).reshape(n, 9).contiguous() for _ in range(nb)]
+        k1, k3 = both(xs)
+        report[name] = (round(k1 / g1, 2), round(k3 / g3, 2))
+        assert k1 <= cap1 * g1 and k3 <= cap3 * g3, (name, k1, g1, k3, g3, report)
+        del xs
 
 
 def test_graph_capture_of_the_head(pa):
