@@ -569,48 +569,17 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
     return separated & converged & topmost;
 }
 
-// r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
-// `prescale` (optional): the exact power of two a row outside the scale window was multiplied by (1 elsewhere) -- the backward
-// from the rotation works on the same prescaled matrix.
+// The exact power of two a row outside the fast path's scale window was multiplied by (1 elsewhere): the backward from the
+// rotation works on the same prescaled matrix.
 template <class T> struct Prescale {
     T factor;
     bool any;          // wave-uniform: some row of the wave has factor != 1
 };
-template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9], Prescale<T> *prescale = nullptr) {
+// The fast path on a matrix whose |M|_F^2 = f is known; in_window: the rows whose f lies inside the scale window (the others are
+// declared hard at the end -- after the prescale these are zero, infinite and NaN rows).
+template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation_core(const T (&m)[9], T f, typename Tr<T>::mask in_window, T (&r)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
-    // 1. scale.  Every step below is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the tests
-    // compare like with like), so the fast path works on the matrix as it comes as long as |M|_F^2 stays within
-    // [2^-28, 2^34] (the Rayleigh quotient's numerator lambda |q|^2 ~ 64 lambda^7 must stay finite -- rows between 2^34.4 and
-    // 2^36, inside round 2's window, came out hard -- and sixth powers of the entries a few orders clear of the underflow
-    // threshold: entries between 2e-5 and 4e4).  Network outputs are O(1): no unconditional prescale (it cost
-    // 9 packed and 16 plain instructions per pair of matrices).
-    T m[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) m[i] = m_in[i];
-    T f = m[0] * m[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
-    // Rows outside the window get an exact power-of-two prescale (largest |entry| -> [0.5, 1); R does not depend on the scale)
-    // under a wave-uniform branch; rows inside it are multiplied by 1 -- their bits do not change.  Zero, infinite and NaN
-    // rows stay outside the window and are declared hard at the end.
-    {
-        const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
-        const bool any_outside = wave_any(R::any(R::mnot(inside)));
-        if (prescale != nullptr) { prescale->factor = R::splat(S(1)); prescale->any = any_outside; }
-        if (__builtin_expect(any_outside, 0)) {
-            T mx = R::max(R::max(R::abs(m[0]), R::abs(m[1])), R::abs(m[2]));
-            mx = R::max(mx, R::max(R::max(R::abs(m[3]), R::abs(m[4])), R::abs(m[5])));
-            mx = R::max(mx, R::max(R::max(R::abs(m[6]), R::abs(m[7])), R::abs(m[8])));
-            const T sc = R::sel(inside, R::splat(S(1)), R::ldexp(R::splat(S(1)), R::neg_frexp_exp(mx)));
-            if (prescale != nullptr) prescale->factor = sc;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) m[i] = m[i] * sc;
-            f = m[0] * m[0];
-#pragma unroll
-            for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
-        }
-    }
     // 2. K (order w, x, y, z)
     const T tr = (m[0] + m[4]) + m[8];
     const T two = R::splat(S(2));
@@ -696,21 +665,23 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
     // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
     // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
-    const T l22 = lam2 * lam2;
-    const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
-                                              & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
-    typename R::mask frozen = settled | hopeless;
+    if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
+        const T l22 = lam2 * lam2;
+        const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
+                                                  & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
+        typename R::mask frozen = settled | hopeless;
 #pragma unroll 1
-    for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
-        T q3[4], trace3;
-        const T lam3 = rayleigh<T>(k, q);
-        dominant_column<T>(k, lam3, q3, trace3);
-        const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+        for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
+            T q3[4], trace3;
+            const T lam3 = rayleigh<T>(k, q);
+            dominant_column<T>(k, lam3, q3, trace3);
+            const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
-        shift = R::sel(frozen, shift, lam3);
-        settled = settled | (settled3 & R::mnot(frozen));
-        frozen = settled | hopeless;
+            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
+            shift = R::sel(frozen, shift, lam3);
+            settled = settled | (settled3 & R::mnot(frozen));
+            frozen = settled | hopeless;
+        }
     }
     // 7. R(q), q = (w, x, y, z) unnormalised
     const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
@@ -723,8 +694,43 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
     r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    const typename R::mask in_window = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
     return R::mnot(settled & finite & in_window);
+}
+
+// r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
+// `prescale` (optional): the exact power of two a row outside the scale window was multiplied by (1 elsewhere).
+template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9], Prescale<T> *prescale = nullptr) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    // 1. scale.  Every step of the core is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the tests
+    // compare like with like), so the fast path works on the matrix as it comes as long as |M|_F^2 stays within
+    // [2^-28, 2^34] (the Rayleigh quotient's numerator lambda |q|^2 ~ 64 lambda^7 must stay finite -- rows between 2^34.4 and
+    // 2^36, inside round 2's window, came out hard -- and sixth powers of the entries a few orders clear of the underflow
+    // threshold: entries between 2e-5 and 4e4).  Network outputs are O(1): no unconditional prescale (it cost
+    // 9 packed and 16 plain instructions per pair of matrices), and the common path works on m_in itself, without a copy.
+    T f = m_in[0] * m_in[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) f = R::fma(m_in[i], m_in[i], f);
+    const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
+    const bool any_outside = wave_any(R::any(R::mnot(inside)));
+    if (prescale != nullptr) { prescale->factor = R::splat(S(1)); prescale->any = any_outside; }
+    if (__builtin_expect(!any_outside, 1)) return quat_rotation_core<T>(m_in, f, inside, r);
+    // Rows outside the window get an exact power-of-two prescale (largest |entry| -> [0.5, 1); R does not depend on the scale)
+    // under this wave-uniform branch; rows inside it are multiplied by 1 -- their bits do not change.  Zero, infinite and NaN
+    // rows stay outside the window and are declared hard by the core.
+    T m[9];
+    T mx = R::max(R::max(R::abs(m_in[0]), R::abs(m_in[1])), R::abs(m_in[2]));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[3]), R::abs(m_in[4])), R::abs(m_in[5])));
+    mx = R::max(mx, R::max(R::max(R::abs(m_in[6]), R::abs(m_in[7])), R::abs(m_in[8])));
+    const T sc = R::sel(inside, R::splat(S(1)), R::ldexp(R::splat(S(1)), R::neg_frexp_exp(mx)));
+    if (prescale != nullptr) prescale->factor = sc;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = m_in[i] * sc;
+    T f2 = m[0] * m[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) f2 = R::fma(m[i], m[i], f2);
+    const typename R::mask inside2 = R::ge(f2, R::splat(S(kQuatWindowLo))) & R::le(f2, R::splat(S(kQuatWindowHi)));
+    return quat_rotation_core<T>(m, f2, inside2, r);
 }
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
