@@ -53,6 +53,7 @@ inline float cos_rev(float x) { return std::cos(6.28318530717958647692f * x); }
 inline int frexp_exp(float x) { int e = 0; if (x != 0.0f && std::isfinite(x)) std::frexp(x, &e); return e; }
 inline int frexp_exp(double x) { int e = 0; if (x != 0.0 && std::isfinite(x)) std::frexp(x, &e); return e; }
 inline bool any_lane(bool p) { return p; }
+inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 #else
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }       // v_rsq_f32, 1 ulp
 __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }     // v_sqrt_f32, 1 ulp
@@ -61,6 +62,7 @@ __device__ __forceinline__ float cos_rev(float x) { return __builtin_amdgcn_cosf
 __device__ __forceinline__ int frexp_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }   // 0 for 0, inf and NaN
 __device__ __forceinline__ int frexp_exp(double x) { return __builtin_amdgcn_frexp_exp(x); }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }   // v_med3_f32
 #endif
 }  // namespace hw
 
@@ -106,6 +108,10 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ float abs(float a) { return fabsf(a); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+    // clamp / max as ONE v_med3_f32 (fmaxf / fminf each come with a canonicalising v_max x, x in front when x is not known to be quiet);
+    // NaN in: some finite bound out -- only used where a NaN row is declared hard anyway
+    static __device__ __forceinline__ float clamp(float x, float lo, float hi) { return hw::med3(x, lo, hi); }
+    static __device__ __forceinline__ float max_fast(float a, float b) { return hw::med3(a, b, __builtin_inff()); }
     static __device__ __forceinline__ float cos_rev(float x) { return hw::cos_rev(x); }          // cos(2 pi x), hardware accuracy
     static __device__ __forceinline__ float copysign(float a, float b) { return copysignf(a, b); }
     static __device__ __forceinline__ float rsq(float x) { return hw::rsq(x); }
@@ -137,6 +143,8 @@ template <> struct Tr<f32x2> {
     static __device__ __forceinline__ f32x2 abs(f32x2 a) { return __builtin_elementwise_abs(a); }
     static __device__ __forceinline__ f32x2 max(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
     static __device__ __forceinline__ f32x2 vmin(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+    static __device__ __forceinline__ f32x2 clamp(f32x2 x, f32x2 lo, f32x2 hi) { return f32x2{hw::med3(x.x, lo.x, hi.x), hw::med3(x.y, lo.y, hi.y)}; }
+    static __device__ __forceinline__ f32x2 max_fast(f32x2 a, f32x2 b) { return f32x2{hw::med3(a.x, b.x, __builtin_inff()), hw::med3(a.y, b.y, __builtin_inff())}; }
     static __device__ __forceinline__ f32x2 cos_rev(f32x2 x) { return f32x2{hw::cos_rev(x.x), hw::cos_rev(x.y)}; }
     static __device__ __forceinline__ f32x2 copysign(f32x2 a, f32x2 b) { return f32x2{copysignf(a.x, b.x), copysignf(a.y, b.y)}; }
     static __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{hw::rsq(x.x), hw::rsq(x.y)}; }
@@ -177,6 +185,8 @@ template <> struct Tr<double> {           // one matrix per lane in float64 (so3
     static __device__ __forceinline__ double abs(double a) { return __builtin_fabs(a); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double clamp(double x, double lo, double hi) { return __builtin_fmax(__builtin_fmin(x, hi), lo); }
+    static __device__ __forceinline__ double max_fast(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double cos_rev(double x) { return ::cos(6.28318530717958647692 * x); }
     static __device__ __forceinline__ double copysign(double a, double b) { return __builtin_copysign(a, b); }
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }          // correctly rounded
@@ -559,11 +569,12 @@ __device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam
     const T l2 = lam_after * lam_after;
     const typename R::mask separated = R::gt(trace, (l2 * lam_after) * tau);
     // the scale of (2) is the LARGER of the two: a shift far above the spectrum has a huge, healthy-looking adjugate
-    const T lmax2 = R::max(l2, lam_before * lam_before);
+    const T lmax = R::max_fast(lam_before, lam_after);          // (a settled row's lambda is positive: criterion 3)
+    const T lmax2 = lmax * lmax;
     // ... plus what float32 cannot see: lambda itself carries ~2 ulp of round-off however still the iteration stands (a move of
     // exactly zero proved nothing: round 3's search on the device found rows with a gap of 7e-6 s1 accepted that way, their
     // rotation off by 0.7).  With the floor, (2) also bounds the gap from below: gap >= 2 ulp lambda / kQuatConv ~ 3e-4 lambda.
-    const T moved = R::fma(R::max(R::abs(lam_before), R::abs(lam_after)), R::splat(S(kQuatUlps)), R::abs(lam_before - lam_after));
+    const T moved = R::fma(lmax, R::splat(S(kQuatUlps)), R::abs(lam_before - lam_after));
     const typename R::mask converged = R::le(moved * (lmax2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
     const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
     return separated & converged & topmost;
@@ -612,7 +623,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
         const T cfn = (cf * inv_f) * inv_f, dn = (di * di) * inv_f;                               // cf / f^2,  det^2 / f^3
         const T p = R::max(R::fma(cfn, R::splat(S(-1.0 / 3.0)), R::splat(S(1.0 / 9.0))), R::splat(S(1e-12)));
         const T q = R::fma(dn, R::splat(S(0.5)), R::fma(cfn, R::splat(S(-1.0 / 6.0)), R::splat(S(1.0 / 27.0))));
-        const T x = R::max(R::vmin(q * R::rsq((p * p) * p), R::splat(S(1))), R::splat(S(-1)));
+        const T x = R::clamp(q * R::rsq((p * p) * p), R::splat(S(-1)), R::splat(S(1)));
         const T ax = R::abs(x);
         T poly = R::fma(ax, R::splat(S(-0.0187293)), R::splat(S(0.0742610)));
         poly = R::fma(poly, ax, R::splat(S(-0.2121144)));
@@ -640,61 +651,67 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
     // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round of 128 rows in five), and only
     // the rows that failed take it.
-    T q[4], trace;
-    dominant_column<T>(k, lam, q, trace);
-    T res2, ref2;
-    T lam2 = rayleigh<T>(k, q, res2, ref2);
-    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
-    T shift = lam;                               // the shift the current q was computed at
-    if (wave_any(R::any(R::mnot(accurate)))) {
-        T q2[4], trace2;
-        dominant_column<T>(k, lam2, q2, trace2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = R::sel(accurate, q[i], q2[i]);
-        trace = R::sel(accurate, trace, trace2);
-        shift = R::sel(accurate, lam, lam2);
-    }
-    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
-    typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
-    // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
+    // (Control flow: the two rare regions below do not MERGE back into the common path -- each ends in its own copy of what
+    // follows it.  Merged, the compiler resolved the phis of q / trace / shift with 17 register moves per round on the COMMON path.)
+    // 7. R(q), q = (w, x, y, z) unnormalised; the hard mask
+    auto finish = [&](const T (&qq)[4], typename R::mask settled_) -> typename R::mask {
+        const T nq = R::fma(qq[3], qq[3], R::fma(qq[2], qq[2], R::fma(qq[1], qq[1], qq[0] * qq[0])));
+        const T s2 = R::rcp(nq) * two;
+        const T w = qq[0], x = qq[1], y = qq[2], z = qq[3];
+        const T xs = x * s2, ys = y * s2, zs = z * s2;
+        const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+        const T one = R::splat(S(1));
+        r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
+        r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
+        r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
+        const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
+        return R::mnot(settled_ & finite & in_window);
+    };
+    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled), and up to two more
+    // refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
     // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
-    // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
-    // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
+    // root was still on its way.  Each is judged by how far the quotient of q lies from the shift q was computed at.
     // A row whose gap product does not reach half the second pass's threshold, or whose curvature P'' does not reach half of
     // criterion (4)'s bar (a near-reflection: refining lambda does not move either by a factor of two), cannot be settled
     // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
     // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
     // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
-    if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
-        const T l22 = lam2 * lam2;
-        const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
-                                                  & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
-        typename R::mask frozen = settled | hopeless;
+    auto settle = [&](T (&qq)[4], T trace_, T shift_, T lam_first, T lam_quot) -> typename R::mask {
+        typename R::mask settled = quat_settled<T>(lam_first, lam_quot, trace_, R::splat(S(kQuatTau)), twoc2, f);
+        if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
+            const T l22 = lam_quot * lam_quot;
+            const typename R::mask hopeless = R::mnot(R::gt(trace_, (l22 * lam_quot) * R::splat(S(0.5f * kQuatTau2)))
+                                                      & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
+            typename R::mask frozen = settled | hopeless;
 #pragma unroll 1
-        for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
-            T q3[4], trace3;
-            const T lam3 = rayleigh<T>(k, q);
-            dominant_column<T>(k, lam3, q3, trace3);
-            const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+            for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
+                T q3[4], trace3;
+                const T lam3 = rayleigh<T>(k, qq);
+                dominant_column<T>(k, lam3, q3, trace3);
+                const typename R::mask settled3 = quat_settled<T>(shift_, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
-            shift = R::sel(frozen, shift, lam3);
-            settled = settled | (settled3 & R::mnot(frozen));
-            frozen = settled | hopeless;
+                for (int i = 0; i < 4; ++i) qq[i] = R::sel(frozen, qq[i], q3[i]);
+                shift_ = R::sel(frozen, shift_, lam3);
+                settled = settled | (settled3 & R::mnot(frozen));
+                frozen = settled | hopeless;
+            }
+            return finish(qq, settled);
         }
+        return finish(qq, settled);
+    };
+    T q[4], trace;
+    dominant_column<T>(k, lam, q, trace);
+    T res2, ref2;
+    const T lam2 = rayleigh<T>(k, q, res2, ref2);
+    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
+    if (__builtin_expect(wave_any(R::any(R::mnot(accurate))), 0)) {
+        T q2[4], trace2;
+        dominant_column<T>(k, lam2, q2, trace2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q2[i] = R::sel(accurate, q[i], q2[i]);
+        return settle(q2, R::sel(accurate, trace, trace2), R::sel(accurate, lam, lam2) /* the shift q was computed at */, lam, lam2);
     }
-    // 7. R(q), q = (w, x, y, z) unnormalised
-    const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    const T s2 = R::rcp(nq) * two;
-    const T w = q[0], x = q[1], y = q[2], z = q[3];
-    const T xs = x * s2, ys = y * s2, zs = z * s2;
-    const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
-    const T one = R::splat(S(1));
-    r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
-    r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
-    r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
-    const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    return R::mnot(settled & finite & in_window);
+    return settle(q, trace, lam, lam, lam2);
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.

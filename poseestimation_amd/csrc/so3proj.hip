@@ -1444,6 +1444,8 @@ int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream)
     constexpr int EB = BF16 ? 2 : 4;
     const int64_t nunits = stream_units(B, {M, R});
     if (nunits > 0) {
+        // two matrices per lane, three waves per SIMD: against one matrix per lane at four / five / six / eight waves (round 3, the fast
+        // path, one device): 14.6-14.9 us against 15.6 / 14.9 / 16.6 (spills) / 18.4
         if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, 256>(op, nunits, s); }
         else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, 256>(op, nunits, s); }
     }
