@@ -651,67 +651,61 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
     // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round of 128 rows in five), and only
     // the rows that failed take it.
-    // (Control flow: the two rare regions below do not MERGE back into the common path -- each ends in its own copy of what
-    // follows it.  Merged, the compiler resolved the phis of q / trace / shift with 17 register moves per round on the COMMON path.)
-    // 7. R(q), q = (w, x, y, z) unnormalised; the hard mask
-    auto finish = [&](const T (&qq)[4], typename R::mask settled_) -> typename R::mask {
-        const T nq = R::fma(qq[3], qq[3], R::fma(qq[2], qq[2], R::fma(qq[1], qq[1], qq[0] * qq[0])));
-        const T s2 = R::rcp(nq) * two;
-        const T w = qq[0], x = qq[1], y = qq[2], z = qq[3];
-        const T xs = x * s2, ys = y * s2, zs = z * s2;
-        const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
-        const T one = R::splat(S(1));
-        r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
-        r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
-        r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
-        const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-        return R::mnot(settled_ & finite & in_window);
-    };
-    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled), and up to two more
-    // refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
+    T q[4], trace;
+    dominant_column<T>(k, lam, q, trace);
+    T res2, ref2;
+    T lam2 = rayleigh<T>(k, q, res2, ref2);
+    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
+    T shift = lam;                               // the shift the current q was computed at
+    if (__builtin_expect(wave_any(R::any(R::mnot(accurate))), 0)) {
+        T q2[4], trace2;
+        dominant_column<T>(k, lam2, q2, trace2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = R::sel(accurate, q[i], q2[i]);
+        trace = R::sel(accurate, trace, trace2);
+        shift = R::sel(accurate, lam, lam2);
+    }
+    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
+    typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
+    // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
     // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
-    // root was still on its way.  Each is judged by how far the quotient of q lies from the shift q was computed at.
+    // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
+    // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
     // A row whose gap product does not reach half the second pass's threshold, or whose curvature P'' does not reach half of
     // criterion (4)'s bar (a near-reflection: refining lambda does not move either by a factor of two), cannot be settled
     // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
     // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
     // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
-    auto settle = [&](T (&qq)[4], T trace_, T shift_, T lam_first, T lam_quot) -> typename R::mask {
-        typename R::mask settled = quat_settled<T>(lam_first, lam_quot, trace_, R::splat(S(kQuatTau)), twoc2, f);
-        if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
-            const T l22 = lam_quot * lam_quot;
-            const typename R::mask hopeless = R::mnot(R::gt(trace_, (l22 * lam_quot) * R::splat(S(0.5f * kQuatTau2)))
-                                                      & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
-            typename R::mask frozen = settled | hopeless;
+    if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
+        const T l22 = lam2 * lam2;
+        const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
+                                                  & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
+        typename R::mask frozen = settled | hopeless;
 #pragma unroll 1
-            for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
-                T q3[4], trace3;
-                const T lam3 = rayleigh<T>(k, qq);
-                dominant_column<T>(k, lam3, q3, trace3);
-                const typename R::mask settled3 = quat_settled<T>(shift_, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+        for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
+            T q3[4], trace3;
+            const T lam3 = rayleigh<T>(k, q);
+            dominant_column<T>(k, lam3, q3, trace3);
+            const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) qq[i] = R::sel(frozen, qq[i], q3[i]);
-                shift_ = R::sel(frozen, shift_, lam3);
-                settled = settled | (settled3 & R::mnot(frozen));
-                frozen = settled | hopeless;
-            }
-            return finish(qq, settled);
+            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
+            shift = R::sel(frozen, shift, lam3);
+            settled = settled | (settled3 & R::mnot(frozen));
+            frozen = settled | hopeless;
         }
-        return finish(qq, settled);
-    };
-    T q[4], trace;
-    dominant_column<T>(k, lam, q, trace);
-    T res2, ref2;
-    const T lam2 = rayleigh<T>(k, q, res2, ref2);
-    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
-    if (__builtin_expect(wave_any(R::any(R::mnot(accurate))), 0)) {
-        T q2[4], trace2;
-        dominant_column<T>(k, lam2, q2, trace2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q2[i] = R::sel(accurate, q[i], q2[i]);
-        return settle(q2, R::sel(accurate, trace, trace2), R::sel(accurate, lam, lam2) /* the shift q was computed at */, lam, lam2);
     }
-    return settle(q, trace, lam, lam, lam2);
+    // 7. R(q), q = (w, x, y, z) unnormalised
+    const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
+    const T s2 = R::rcp(nq) * two;
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T xs = x * s2, ys = y * s2, zs = z * s2;
+    const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const T one = R::splat(S(1));
+    r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
+    r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
+    r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
+    const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
+    return R::mnot(settled & finite & in_window);
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
