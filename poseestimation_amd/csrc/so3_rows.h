@@ -232,6 +232,7 @@ template <int NPL> struct RowCtx {
     int lane;
     double acc;             // per-lane float64 partial of the operation's reduction
     bool flag;              // per-lane sticky flag (K4: cosine out of range)
+    const char *img1;       // LDS image of the second input's block (operations with kLateIn1 read their rows from it themselves)
 };
 
 #ifndef SO3_HOST_MODEL
@@ -293,6 +294,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.lane = lane;
     ctx.acc = 0.0;
     ctx.flag = false;
+    ctx.img1 = nullptr;
     if (t < nrounds) {
         auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
             const int64_t left = nunits - tr * NPL;
@@ -316,7 +318,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail,
                 const int u = ctx.exists[k] ? k : 0;    // whose lanes work on the round's first unit instead (results dropped)
                 I0::read_row(img, u, lane, k, rows.a);
-                if constexpr (Op::kIn1 != 0) I1::read_row(img + kIn0B, u, lane, k, rows.b);
+                if constexpr (Op::kIn1 != 0 && !Op::kLateIn1) I1::read_row(img + kIn0B, u, lane, k, rows.b);
                 if constexpr (Op::kIn2 != 0) I2::read_row(img + kIn0B + kIn1B, u, lane, k, rows.c);
             }
         };
@@ -340,6 +342,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         };
         {
             char *slot = lds[wave_in_block];
+            ctx.img1 = slot + kIn0B;
             // One round is in flight in registers behind the round that sits in LDS.
             f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
             auto issue = [&](int64_t tr) {                  // past the last round the descriptors are empty: the loads
@@ -417,6 +420,15 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 
 #endif  // !SO3_HOST_MODEL
 
+#ifndef SO3_HOST_MODEL
+// The rows of the second input for an operation with kLateIn1 (called from its compute(), before the results are staged).
+template <class T, class Op, int NPL> __device__ __forceinline__ void late_in1(const RowCtx<NPL> &ctx, T (&b)[Op::kIn1N]) {
+    typedef UnitIO<Op::kIn1, Op::kIn1N, NPL> I1;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) I1::read_row(ctx.img1, ctx.exists[k] ? k : 0, ctx.lane, k, b);
+}
+#endif
+
 // ---- the operations --------------------------------------------------------------------------------------
 struct OpBase {
     static constexpr int kIn2 = 0;                                         // most operations have at most two inputs
@@ -424,6 +436,9 @@ struct OpBase {
     const void *in0 = nullptr, *in1 = nullptr, *in2 = nullptr;
     void *out0 = nullptr, *out1 = nullptr;
     static constexpr bool kReduce = false;
+    // kLateIn1: the operation reads the second input's rows out of LDS itself (late_in1), where it first needs them -- for K2 / K3 /
+    // K1+K4 that is AFTER the projection, whose ~110 live registers the 18 of a second input's rows would otherwise sit beside
+    static constexpr bool kLateIn1 = false;
 #ifndef SO3_HOST_MODEL
     ReduceWs *ws = nullptr;        // reduction workspace (nullptr: atomics onto host-initialised accumulators)
     unsigned ws_slot0 = 0;         // slots below this one were filled by the remainder kernel launched before the engine
@@ -461,9 +476,14 @@ struct OpProject : OpBase {
 template <int M_BYTES>
 struct OpProjectBwd : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
+    static constexpr bool kLateIn1 = true;
     template <class T, int NPL>
-    __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &) const {
-        project_backward_rows<T>(rows.a, rows.b, rows.o0);
+    __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &ctx) const {
+        T r[9];
+        HardRows<T> h;
+        project_rotation_frames<true, T>(rows.a, r, h);
+        late_in1<T, OpProjectBwd, NPL>(ctx, rows.b);              // G: only now
+        backward_given_rotation<T>(rows.a, r, rows.b, h, rows.o0);
     }
 };
 
@@ -472,6 +492,7 @@ template <int M_BYTES, bool WANT_DM, bool WANT_R>
 struct OpFrobHead : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_DM ? M_BYTES : 0, kOut1 = WANT_R ? 4 : 0;
     static constexpr bool kReduce = true;
+    static constexpr bool kLateIn1 = true;
     double *loss_sum = nullptr;
     float inv_b = 0.f;
     template <class T, int NPL>
@@ -484,6 +505,7 @@ struct OpFrobHead : OpBase {
         HardRows<T> hard;
         if constexpr (WANT_DM) project_rotation_frames<true, T>(m, r, hard);
         else project_rotation_frames<false, T>(m, r, hard);
+        late_in1<T, OpFrobHead, NPL>(ctx, rows.b);                // Rtrue: only now
         T g[9];
         T n2 = R::splat(0.f);
 #pragma unroll
@@ -618,6 +640,7 @@ template <int M_BYTES, bool WANT_R, bool WANT_DEG, bool WANT_SUM>
 struct OpProjectAngle : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_R ? 4 : 0, kOut1 = 0;
     static constexpr bool kReduce = true;
+    static constexpr bool kLateIn1 = true;
     double *deg = nullptr, *sum_count = nullptr;
     int32_t *range_flag = nullptr;
     double unit_scale = 1.0;
@@ -625,6 +648,7 @@ struct OpProjectAngle : OpBase {
     __device__ __forceinline__ void compute(Rows<T, OpProjectAngle> &rows, RowCtx<NPL> &ctx) const {
         T r[9];
         project_rotation<T>(rows.a, r);
+        late_in1<T, OpProjectAngle, NPL>(ctx, rows.b);            // Rtrue: only now
         if (WANT_R) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];

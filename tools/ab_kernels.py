@@ -20,12 +20,13 @@ p = lambda t: P(t.data_ptr())
 libs = {}
 for path in sys.argv[1:]:
     lib = ctypes.CDLL(path)
-    for name in ("so3_project_fwd_f32", "so3_project_bwd_f32", "so3_frob_fwd_bwd_ws_f32", "so3_reduce_workspace_bytes"):
+    for name in ("so3_project_fwd_f32", "so3_project_bwd_f32", "so3_frob_fwd_bwd_ws_f32", "so3_reduce_workspace_bytes", "so3_project_angle_error_acc_f32"):
         res, args = _lib.SYMBOLS[name]
         getattr(lib, name).restype = res
         getattr(lib, name).argtypes = args
     libs[os.path.basename(path).replace("libso3proj_", "").replace(".so", "")] = lib
 ws = torch.zeros(32768, dtype=torch.uint8, device=dev)
+pool = torch.zeros(4096, 4, dtype=torch.float64, device=dev)
 rt = r[0].clone()
 list(libs.values())[0].so3_project_fwd_f32(p(torch.randn(n, 9, device=dev)), p(rt), None, n, st)
 
@@ -47,6 +48,7 @@ kernels = {
     "K1": lambda lib: (lambda i: lib.so3_project_fwd_f32(p(x[i % NB]), p(r[i % NB]), None, n, st)),
     "K2": lambda lib: (lambda i: lib.so3_project_bwd_f32(p(x[i % NB]), p(g[i % NB]), p(dm[i % NB]), n, st)),
     "K3 R+dM": lambda lib: (lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt), p(r[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st)),
+    "K1+K4": lambda lib: (lambda i: lib.so3_project_angle_error_acc_f32(p(x[i % NB]), p(rt), None, None, P(pool[i % 4096].data_ptr()), P(pool[i % 4096].data_ptr() + 16), 0, n, st)),
     "K3 dM": lambda lib: (lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt), None, p(dm[i % NB]), p(ls), p(lm), p(ws), n, st)),
 }
 best = {(k, name): 1e9 for k in kernels for name in libs}
