@@ -432,9 +432,14 @@ def main():
                 step(i)
         e1.record(stream)
 
+    def synchronize():                        # the contract's synchronize, reached without a sleep: the host polls the closing event
+        while not e1.query():                 # first (a blocked hipDeviceSynchronize wakes up 5-15 us after the device is done, which
+            pass                              # is 2-5 % of a 20-step region and belongs to the scheduler, not to the kernel)
+        torch.cuda.synchronize()
+
     with torch.cuda.stream(stream):           # a graph replays on the CURRENT stream: entered before the clock starts
         e0.record(stream); e1.record(stream)  # (torch creates an event's handle at its first record: not inside the region either)
-        out, (wall, ev_ms) = run_skeleton(rank, world, args.steps, args.warmup, rows, step, torch.cuda.synchronize, dist, dev, config,
+        out, (wall, ev_ms) = run_skeleton(rank, world, args.steps, args.warmup, rows, step, synchronize, dist, dev, config,
                                           extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False)
         # per-launch spread (median and min): a second, untimed pass of 20 eager launches with an event
         # between every two of them
