@@ -320,7 +320,11 @@ def main():
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SO3_BENCH_BACKEND", "nccl")      # "gloo": two ranks on ONE device (RCCL refuses a shared GPU): the test of this path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from poseestimation_amd import _lib
     from poseestimation_amd import rotation_representation as rr

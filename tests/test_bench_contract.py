@@ -65,6 +65,36 @@ def test_bench_under_an_initialised_process_group_rccl_one_rank():
     assert abs(d["mean_angle_error_delta_vs_ref_deg"]) < 1e-4                      # the all-reduced metric, vs the reference's number
 
 
+def test_bench_with_two_ranks_sharing_the_device():
+    """bench.py's N > 1 path end to end with TWO processes on the GPU box: both ranks on cuda:0 (RCCL refuses two ranks on one
+    GPU, so the process group is gloo -- SO3_BENCH_BACKEND), each with its own buffers, its own hipGraph and its own timed
+    region between the same two barriers; the clocks MAX-reduced, the (sum, count) pair all-reduced, ONE line from rank 0 with
+    n_gpus = 2 and value = 2 x rows x steps / the slower rank's time.  (The ranks share the card, so the value is a bookkeeping
+    check, not a throughput: what a real node gives is the driver's to measure.)"""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, SO3_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2",
+                   LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--rows", "500000"]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines0 = [l for l in outs[0][0].splitlines() if l.strip()]
+    lines1 = [l for l in outs[1][0].splitlines() if l.strip()]
+    assert len(lines0) == 1 and len(lines1) == 0                    # exactly one JSON line, from rank 0
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak"
+    assert d["config"]["rows_per_gpu"] == 500_000 and d["config"]["global_rows"] == 1_000_000 and d["config"]["parallelism"].startswith("dp2")
+    assert abs(d["value"] - 1_000_000 * 30 / (d["ms_per_step"] * 30 * 1e-3)) / d["value"] < 1e-9
+    assert d["ms_per_step_events"] <= d["ms_per_step"] * 1.001
+    assert 120.0 < d["mean_angle_error_deg"] < 133.0               # the all-reduced metric over both ranks' rows (seeds 0 and 1)
+    assert "cpu_baseline" not in d and "secondary" not in d         # rank 0 at N = 1 only
+
+
 def test_bench_config5_shape_on_one_rank():
     """--config 5 = BASELINE configs[4]: 2M rows per GPU (16M over 8), rank r seeded with r; one rank of it fits here."""
     d = _run_bench("--config", "5", "--no-cpu-baseline", "--no-secondary")
