@@ -246,13 +246,13 @@ template <class T> __device__ __forceinline__ void rotate(V3<T> &p, V3<T> &q) {
 __device__ __forceinline__ bool wave_any(bool p) { return hw::any_lane(p); }
 
 // A unit vector orthogonal to the unit vector u: e_k x u, k = index of the smallest |u_k| (z first).
-template <class S> __device__ __forceinline__ V3<S> any_perp(V3<S> u) {
-    const S ax = Tr<S>::abs(u.x), ay = Tr<S>::abs(u.y), az = Tr<S>::abs(u.z);
-    V3<S> w;
-    if (az <= ax && az <= ay) w = mk<S>(-u.y, u.x, S(0));
-    else if (ay <= ax) w = mk<S>(u.z, S(0), -u.x);
-    else w = mk<S>(S(0), -u.z, u.y);
-    return scale<S>(w, Tr<S>::rsq(dot(w, w)));
+template <class T> __device__ __forceinline__ V3<T> any_perp(V3<T> u) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    const T ax = R::abs(u.x), ay = R::abs(u.y), az = R::abs(u.z), zero = R::splat(S(0));
+    const typename R::mask mz = R::le(az, ax) & R::le(az, ay), my = R::le(ay, ax);
+    const V3<T> w = sel<T>(mz, mk<T>(-u.y, u.x, zero), sel<T>(my, mk<T>(u.z, zero, -u.x), mk<T>(zero, -u.z, u.y)));
+    return scale<T>(w, R::rsq(dot(w, w)));
 }
 
 template <class T> struct SignedSvd {
@@ -395,31 +395,21 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
     const typename R::mask degenerate = R::le(nx, tiny) | R::le(nw, R::fma(lost * qy, qy, tiny)) | R::le(nt1, tiny)
                                         | R::le(nr2, R::fma(lost * pt, pt, tiny));
     if (__builtin_expect(R::any(degenerate), 0)) {
-#pragma unroll
-        for (int i = 0; i < R::kLanes; ++i) {
-            if (R::lane_of(degenerate, i)) {
-            const S f0 = R::get(n0, i), f1 = R::get(n1, i), f2 = R::get(n2, i);
-            const bool b0 = (f0 >= f1) && (f0 >= f2);
-            const bool b1 = (f1 >= f2);
-            const V3<S> big = b0 ? lane3<T>(a0, i) : (b1 ? lane3<T>(a1, i) : lane3<T>(a2, i));
-            const S nb = b0 ? f0 : (b1 ? f1 : f2);
-            const V3<S> q0 = lane3<T>(mr0, i), q1 = lane3<T>(mr1, i), q2 = lane3<T>(mr2, i);
-            V3<S> su1, sv1;
-            if (nb <= K::tiny) {                     // M == 0  ->  identity (matches the reference)
-                su1 = mk<S>(S(1), S(0), S(0));
-                sv1 = su1;
-            } else {
-                su1 = scale<S>(big, Tr<S>::rsq(nb));
-                const V3<S> st1 = axpy<S>(su1.z, q2, axpy<S>(su1.y, q1, scale<S>(q0, su1.x)));
-                sv1 = scale<S>(st1, Tr<S>::rsq(dot(st1, st1)));
-            }
-            set_lane3<T>(u1, i, su1);
-            set_lane3<T>(v1, i, sv1);
-            set_lane3<T>(u2, i, any_perp<S>(su1));
-            set_lane3<T>(v2, i, any_perp<S>(sv1));
-            if (WANT_S) { R::set(nt1, i, nb); R::set(nr2, i, S(0)); }
-            }
-        }
+        // (generic over T like everything else: round 2 looped over the halves of a packed pair with scalar code under a divergent
+        // branch -- a batch of rank-one rows paid 10 % of its time there)
+        const typename R::mask b0 = R::ge(n0, n1) & R::ge(n0, n2), b1 = R::ge(n1, n2);
+        const V3<T> big = sel<T>(b0, a0, sel<T>(b1, a1, a2));
+        const T nb = R::sel(b0, n0, R::sel(b1, n1, n2));
+        const typename R::mask null = R::le(nb, tiny);                    // M == 0  ->  identity (matches the reference)
+        const V3<T> ex = mk<T>(R::splat(S(1)), R::splat(S(0)), R::splat(S(0)));
+        const V3<T> su1 = sel<T>(null, ex, scale<T>(big, R::rsq(nb)));
+        const V3<T> st1 = axpy<T>(su1.z, mr2, axpy<T>(su1.y, mr1, scale<T>(mr0, su1.x)));
+        const V3<T> sv1 = sel<T>(null, ex, scale<T>(st1, R::rsq(dot(st1, st1))));
+        u1 = sel<T>(degenerate, su1, u1);
+        v1 = sel<T>(degenerate, sv1, v1);
+        u2 = sel<T>(degenerate, any_perp<T>(su1), u2);
+        v2 = sel<T>(degenerate, any_perp<T>(sv1), v2);
+        if (WANT_S) { nt1 = R::sel(degenerate, nb, nt1); nr2 = R::sel(degenerate, R::splat(S(0)), nr2); }
     }
     o.u1 = u1; o.u2 = u2; o.u3 = cross<T>(u1, u2);
     o.v1 = v1; o.v2 = v2; o.v3 = cross<T>(v1, v2);
