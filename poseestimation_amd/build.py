@@ -56,9 +56,43 @@ def build_fastcall(force: bool = False, verbose: bool = False):
     return out
 
 
+def build_autograd_node(force: bool = False, verbose: bool = False):
+    """frobenius_head's autograd node in C++ (csrc/autograd_node.cpp), next to the package: plain g++ against torch's headers and
+    libraries (no device code, no HIP headers), ~40 s.  Optional: returns None when it cannot be built -- the mirror then uses
+    its Python autograd.Function."""
+    import sysconfig
+    src = os.path.join(CSRC, "autograd_node.cpp")
+    out = os.path.join(_HERE, "_so3node" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cxx = shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        return None
+    try:
+        import torch
+        from torch.utils import cpp_extension
+    except ImportError:
+        return None
+    incs = [i for i in cpp_extension.include_paths() if os.path.isdir(i)] + [sysconfig.get_paths()["include"]]
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=_so3node", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-deprecated-declarations",
+           *["-isystem" + i for i in incs], "-o", out + ".tmp", src,
+           "-L" + libdir, "-Wl,-rpath," + libdir, "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    os.replace(out + ".tmp", out)
+    return out
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 (cross-compiles without a GPU).  Returns the .so path."""
     build_fastcall(force, verbose)
+    build_autograd_node(force, verbose)
     if not force and not is_stale():
         return LIB
     cmd = [hipcc(), *HIPCC_FLAGS, "-o", LIB + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]

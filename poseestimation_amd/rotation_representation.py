@@ -68,6 +68,26 @@ def _fn(name: str):
     return f
 
 
+try:                                  # csrc/autograd_node.cpp: frobenius_head's autograd node without the interpreter in forward / backward
+    from . import _so3node
+except ImportError:                   # not built: the Python autograd.Function below serves every case
+    _so3node = None
+_NODE_BOUND = False
+
+
+def _node():
+    """_so3node with the C-ABI addresses handed over (once), or None."""
+    global _NODE_BOUND
+    if _so3node is not None and not _NODE_BOUND:
+        import ctypes
+        lib = _libh()
+        addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+        _so3node.bind(addr("so3_frob_fwd_bwd_ws_f32"), addr("so3_frob_fwd_bwd_ws_bf16"), addr("so3_scale_f32"), addr("so3_scale_bf16"),
+                      addr("so3_last_error"), _SMALL_BATCH)
+        _NODE_BOUND = True
+    return _so3node
+
+
 def _require_device(*tensors: torch.Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -552,6 +572,18 @@ def frobenius_head(x: torch.Tensor, R_true: torch.Tensor, return_rotation: bool 
         r64 = symmetric_orthogonalization(x)
         loss64 = loss_frobenius(R_true.to(torch.float64), r64)
         return (loss64, r64.detach()) if return_rotation else loss64
+    node = _node()
+    if node is not None and type(x) is torch.Tensor and type(R_true) is torch.Tensor and x.is_cuda and x.dim() >= 2:
+        # the C++ node: same launches, no interpreter inside forward / backward; it declines (None) what it does not cover
+        dev = x.device
+        st = _stream(dev)
+        ws = 0
+        if x.shape[0] > _SMALL_BATCH:
+            w = _workspace(dev, st)
+            ws = w.data_ptr() if w is not None else 0
+        res = node.frobenius_head(x, R_true, return_rotation, st, ws)
+        if res is not None:
+            return res if return_rotation else res[0]
     box = []
     loss = _FrobeniusHead.apply(x, R_true, return_rotation, box)
     return (loss, box[0]) if return_rotation else loss

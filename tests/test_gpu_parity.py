@@ -711,6 +711,59 @@ def test_fused_head_is_differentiable_in_the_target_too(rr, b):
     assert tc.grad is None and torch.equal(xc.grad * 2.0, xa.grad) or (xc.grad * 2.0 - xa.grad).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1), (torch.bfloat16, 3000), (torch.float32, 70_000)])
+def test_cpp_autograd_node_equals_the_python_function(rr, dtype, b):
+    """frobenius_head goes through csrc/autograd_node.cpp when the arguments are its case; the Python class _FrobeniusHead is
+    what it replaces.  Same launches, so: loss, rotation and gradient bit for bit, with and without the rotation, with an upstream
+    factor, twice over one graph; what the node declines (a strided x, float16, a target that wants its gradient) still works;
+    backward of backward fails loudly."""
+    if rr._node() is None:
+        pytest.skip("_so3node not built")
+    gen = torch.Generator(device=DEV).manual_seed(b)
+    x = torch.randn(b, 9, device=DEV, generator=gen).to(dtype)
+    t = rr.symmetric_orthogonalization(torch.randn(b, 9, device=DEV, generator=gen))
+    for want_r in (True, False):
+        for shape in ((b, 9), (b, 3, 3)):
+            xn = x.clone().view(shape).requires_grad_(True)
+            xp = x.clone().view(shape).requires_grad_(True)
+            out = rr.frobenius_head(xn, t, return_rotation=want_r)
+            assert "FrobeniusHeadNode" in (out[0] if want_r else out).grad_fn.name()
+            box = []
+            lp = rr._FrobeniusHead.apply(xp, t, want_r, box)
+            ln = out[0] if want_r else out
+            assert ln.dtype == torch.float32 and ln.dim() == 0 and torch.equal(ln, lp)
+            if want_r:
+                assert out[1].shape == (b, 3, 3) and not out[1].requires_grad and torch.equal(out[1], box[0])
+            (ln * 1.5).backward(retain_graph=True)
+            (lp * 1.5).backward()
+            assert xn.grad.shape == shape and xn.grad.dtype == dtype and torch.equal(xn.grad, xp.grad)
+            g1 = xn.grad.clone()
+            xn.grad = None
+            (ln * 1.5).backward()                                                  # the stored gradient was not scaled in place
+            assert torch.equal(xn.grad, g1)
+    # no gradient wanted: nothing saved, nothing returned
+    ln, rn = rr.frobenius_head(x, t)
+    box = []
+    lp = rr._FrobeniusHead.apply(x, t, True, box)
+    assert not ln.requires_grad and ln.grad_fn is None and torch.equal(ln, lp) and torch.equal(rn, box[0])
+    # declined cases take the Python class and give the same numbers
+    xs = torch.randn(b, 18, device=DEV, generator=gen).to(dtype)[:, ::2]           # strided
+    xs.requires_grad_(True)
+    ls, _ = rr.frobenius_head(xs, t)
+    assert "FrobeniusHeadNode" not in ls.grad_fn.name()
+    tg = t.clone().requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    lg, _ = rr.frobenius_head(xg, tg)
+    assert "FrobeniusHeadNode" not in lg.grad_fn.name()
+    lg.backward()
+    assert tg.grad is not None and xg.grad is not None
+    # double backward is refused, as by the Python class
+    xd = x.clone().requires_grad_(True)
+    ld, _ = rr.frobenius_head(xd, t)
+    with pytest.raises(RuntimeError, match="differentiate twice"):
+        torch.autograd.grad(ld, xd, create_graph=True)
+
+
 @pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1000), (torch.bfloat16, 3000)])
 def test_recorded_training_step_matches_the_autograd_spelling(rr, dtype, b):
     """FrobeniusHeadStep (one hipGraph replay: config #4's launch-bound step) against frobenius_head + backward; sizes on
