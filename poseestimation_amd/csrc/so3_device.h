@@ -578,7 +578,7 @@ template <class T> struct Prescale {
 };
 // The fast path on a matrix whose |M|_F^2 = f is known; in_window: the rows whose f lies inside the scale window (the others are
 // declared hard at the end -- after the prescale these are zero, infinite and NaN rows).
-template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation_core(const T (&m)[9], T f, typename Tr<T>::mask in_window, T (&r)[9]) {
+template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::mask quat_rotation_core(const T (&m)[9], T f, typename Tr<T>::mask in_window, T (&r)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
     // 2. K (order w, x, y, z)
@@ -635,6 +635,23 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
         const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
         lam = R::fma(-p, R::rcp(dp), lam);
+    }
+    // 4b. Rows that no eigenvector will settle, known from the quartic alone: P'(lambda) = (l1 - l2)(l1 - l3)(l1 - l4) is the gap
+    // product the adjugate's trace measures in step 6, P''(lambda) the curvature criterion (4) asks for.  A row that misses a
+    // quarter of either bar at Newton's lambda (half of what `hopeless` asks below at the Rayleigh quotient), or lies outside the
+    // scale window (zero, Inf, NaN), is HARD whatever steps 5-7 would say -- a per-row rule, so its result does not depend on its
+    // wave-mates; none in 2e7 Gaussian rows -- and a wave in which EVERY row is leaves here for the Jacobi path without paying
+    // for eigenvectors it would discard: a batch of zeros (a dead head) 15.3 us per 1M rows instead of 19.7.  (Batches of
+    // near-reflections or rank-one rows do not profit: Newton's lambda is still far from a multiple root on 2-7 % of such rows,
+    // so some row of nearly every wave only shows its hand in step 6.  SKIP: the instantiation that also writes flip flags has no
+    // registers to spare for the second way out.)
+    typename R::mask early_hard;
+    {
+        const T l2 = lam * lam;
+        const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
+        early_hard = R::mnot(R::gt(dp, (l2 * lam) * R::splat(S(0.25f * kQuatTau2)))
+                             & R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(0.25f * kQuatCurv))) & in_window);
+        if (SKIP && __builtin_expect(!wave_any(R::any(R::mnot(early_hard))), 0)) return early_hard;      // r is not used for hard rows
     }
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
     // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
@@ -695,12 +712,12 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
     r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    return R::mnot(settled & finite & in_window);
+    return R::mnot(settled & finite & in_window) | early_hard;
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
 // `prescale` (optional): the exact power of two a row outside the scale window was multiplied by (1 elsewhere).
-template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9], Prescale<T> *prescale = nullptr) {
+template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::mask quat_rotation(const T (&m_in)[9], T (&r)[9], Prescale<T> *prescale = nullptr) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
     // 1. scale.  Every step of the core is homogeneous in M (K and lambda scale with M, the adjugate with its cube, all the tests
@@ -715,7 +732,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
     const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
     const bool any_outside = wave_any(R::any(R::mnot(inside)));
     if (prescale != nullptr) { prescale->factor = R::splat(S(1)); prescale->any = any_outside; }
-    if (__builtin_expect(!any_outside, 1)) return quat_rotation_core<T>(m_in, f, inside, r);
+    if (__builtin_expect(!any_outside, 1)) return quat_rotation_core<T, SKIP>(m_in, f, inside, r);
     // Rows outside the window get an exact power-of-two prescale (largest |entry| -> [0.5, 1); R does not depend on the scale)
     // under this wave-uniform branch; rows inside it are multiplied by 1 -- their bits do not change.  Zero, infinite and NaN
     // rows stay outside the window and are declared hard by the core.
@@ -731,7 +748,7 @@ template <class T> __device__ __forceinline__ typename Tr<T>::mask quat_rotation
 #pragma unroll
     for (int i = 1; i < 9; ++i) f2 = R::fma(m[i], m[i], f2);
     const typename R::mask inside2 = R::ge(f2, R::splat(S(kQuatWindowLo))) & R::le(f2, R::splat(S(kQuatWindowHi)));
-    return quat_rotation_core<T>(m, f2, inside2, r);
+    return quat_rotation_core<T, SKIP>(m, f2, inside2, r);
 }
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
@@ -748,9 +765,9 @@ template <class T> struct HardRows {
     SignedSvd<T> frames;
     Prescale<T> prescale;            // of the rows the fast path settled (WANT_BWD only)
 };
-template <bool WANT_BWD, class T> __device__ __forceinline__ void project_rotation_frames(const T (&m)[9], T (&r)[9], HardRows<T> &h) {
+template <bool WANT_BWD, class T, bool SKIP = true> __device__ __forceinline__ void project_rotation_frames(const T (&m)[9], T (&r)[9], HardRows<T> &h) {
     typedef Tr<T> R;
-    h.hard = quat_rotation<T>(m, r, WANT_BWD ? &h.prescale : nullptr);
+    h.hard = quat_rotation<T, SKIP>(m, r, WANT_BWD ? &h.prescale : nullptr);
     h.any = wave_any(R::any(h.hard));
     if (__builtin_expect(h.any, 0)) {
         h.frames = signed_svd<WANT_BWD, T>(m);
@@ -760,9 +777,9 @@ template <bool WANT_BWD, class T> __device__ __forceinline__ void project_rotati
         for (int j = 0; j < 9; ++j) r[j] = R::sel(h.hard, rj[j], r[j]);
     }
 }
-template <class T> __device__ __forceinline__ typename Tr<T>::mask project_rotation(const T (&m)[9], T (&r)[9]) {
+template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::mask project_rotation(const T (&m)[9], T (&r)[9]) {
     HardRows<T> h;
-    project_rotation_frames<false, T>(m, r, h);
+    project_rotation_frames<false, T, SKIP>(m, r, h);
     return h.hard;
 }
 template <> __device__ __forceinline__ bool project_rotation<double>(const double (&m)[9], double (&r)[9]) {

@@ -458,7 +458,7 @@ struct OpProject : OpBase {
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
         const T (&m)[9] = rows.a;
         T (&r)[9] = rows.o0;
-        project_rotation<T>(m, r);
+        project_rotation<T, !FLIP>(m, r);
         if (FLIP) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {

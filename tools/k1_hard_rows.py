@@ -4,7 +4,7 @@ of the rows are HARD for the quaternion fast path (they are redone by the Jacobi
 
 Families: rank two (one singular value 0: not hard), near-reflections (-R + noise: all singular values close, det < 0),
 small integers (entries in {-1, 0, 1}: ties and rank deficiency), 1e5 * Gaussian (outside the fast path's scale window:
-prescaled, not hard since round 3), generic ties (s2 = s3, det < 0, general position), rank one.  The reference (torch.svd -> LAPACK / gesvdj) has no such cliff: this table puts ours on record.
+prescaled, not hard since round 3), generic ties (s2 = s3, det < 0, general position), rank one, all zero (a dead head).  The reference (torch.svd -> LAPACK / gesvdj) has no such cliff: this table puts ours on record.
 
 usage: k1_hard_rows.py [--lib path/to/libso3proj.so] [--rows N]      (prints a table; profiles/r03_k1_hard_rows.txt)
 """
@@ -60,6 +60,8 @@ def family(name, n, dev, gen):
         s[:, 0] += 1.0
         s[:, 2] = -s[:, 1] * (1 - 1e-6)
         return (u * s.unsqueeze(1)) @ v.transpose(1, 2)
+    if name == "all zero":                # a dead head: outside the scale window, every wave leaves the fast path after the quartic
+        return torch.zeros(n, 3, 3, device=dev)
     if name == "rank one":
         a, b = torch.randn(n, 3, 1, device=dev, generator=gen), torch.randn(n, 1, 3, device=dev, generator=gen)
         return a @ b
@@ -110,7 +112,7 @@ def main():
     print("%-22s %6s | %9s %7s | %9s %7s" % ("family of hard rows", "share", "K1 us", "x Gauss", "K3 us", "x Gauss"))
     print("%-22s %6s | %9.2f %7.2f | %9.2f %7.2f" % ("Gaussian (none hard)", "0 %", g1, 1.0, g3, 1.0))
     worst = 1.0
-    for name in ("rank two", "near-reflection", "entries in {-1,0,1}", "1e5 * Gaussian", "generic ties", "rank one"):
+    for name in ("rank two", "near-reflection", "entries in {-1,0,1}", "1e5 * Gaussian", "generic ties", "rank one", "all zero"):
         for share in (0.01, 0.10, 1.0):
             xs = []
             for b in range(nb):
