@@ -1,12 +1,15 @@
-// frobenius_head's autograd node in C++ (the Python class _FrobeniusHead in rotation_representation.py is its twin and serves
-// every case this one declines).  Config #4 (B = 512, bfloat16: 3D-Pose/main.py:60,85,90) is launch-bound: the kernels take 4 us,
+// The autograd nodes of the launch-bound training step in C++: frobenius_head (the fused spelling), and symmetric_orthogonalization
+// and loss_frobenius (the reference's own two-call spelling, 3D-Pose/main.py:60,85).  The Python classes _FrobeniusHead,
+// _SymmetricOrthogonalization and _LossFrobenius in rotation_representation.py are their twins and serve every case these decline.  Config #4 (B = 512, bfloat16: 3D-Pose/main.py:60,85,90) is launch-bound: the kernels take 4 us,
 // a Python autograd.Function costs 30 us of interpreter and engine bookkeeping before it launches anything.  A C++ node takes the
 // interpreter out of forward and backward; what it launches is the same C ABI (include/so3proj.h), reached through function
 // addresses the Python side hands over once (no link-time dependency on libso3proj.so, no HIP headers here: the stream is an
 // integer from torch's accessor, the device guard is c10's generic one).
 //
-// Handles: x float32 / bfloat16, contiguous, (B,9) or (B,3,3), B >= 1; R_true float32, contiguous, same device, not requiring
-// grad.  Anything else: the caller uses the Python class.
+// frobenius_head handles: x float32 / bfloat16, contiguous, (B,9) or (B,3,3), B >= 1; R_true float32, contiguous, same device, not
+// requiring grad.  symmetric_orthogonalization: x float32 / bfloat16, contiguous, numel a multiple of 9, requiring grad.
+// loss_frobenius: two float32 contiguous tensors of B x 9 elements on one device, at least one requiring grad.  Anything else:
+// the caller uses the Python class.
 #include <torch/extension.h>
 #include <c10/core/DeviceGuard.h>
 
@@ -16,13 +19,26 @@ typedef int (*FrobFn)(const void *M, const float *Rtrue, float *R, void *dM, dou
                       int64_t B, void *stream);                                      // so3_frob_fwd_bwd_ws_{f32,bf16}
 typedef int (*ScaleFn)(const void *src, const float *factor, void *dst, int64_t n, void *stream);   // so3_scale_{f32,bf16}
 typedef const char *(*ErrFn)();                                                      // so3_last_error
+typedef int (*FwdFn)(const void *M, float *R, uint8_t *flip, int64_t B, void *stream);             // so3_project_fwd_{f32,bf16}
+typedef int (*BwdFn)(const void *M, const float *G, void *dM, int64_t B, void *stream);            // so3_project_bwd_{f32,bf16}
+typedef int (*LossFn)(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace,
+                      int64_t B, void *stream);                                      // so3_frob_loss_ws_f32
 
 struct Entry {
     FrobFn frob_f32 = nullptr, frob_bf16 = nullptr;
     ScaleFn scale_f32 = nullptr, scale_bf16 = nullptr;
+    FwdFn fwd_f32 = nullptr, fwd_bf16 = nullptr;
+    BwdFn bwd_f32 = nullptr, bwd_bf16 = nullptr;
+    LossFn loss_f32 = nullptr;
     ErrFn last_error = nullptr;
     int64_t small_batch = 0;
 } g_entry;
+
+void no_double_backward() {
+    TORCH_CHECK(!at::GradMode::is_enabled(),
+                "trying to differentiate twice a function that was marked with @once_differentiable "
+                "(poseestimation_amd kernels do not support double backward; the reference never uses it)");
+}
 
 void check(int code, const char *what) {
     TORCH_CHECK(code == 0, what, " failed with code ", code, ": ", g_entry.last_error ? g_entry.last_error() : "");
@@ -62,9 +78,7 @@ struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grads) {
-        TORCH_CHECK(!at::GradMode::is_enabled(),
-                    "trying to differentiate twice a function that was marked with @once_differentiable "
-                    "(poseestimation_amd kernels do not support double backward; the reference never uses it)");
+        no_double_backward();
         const at::Tensor dm = ctx->saved_data["dm"].toTensor();
         const at::Tensor &g = grads[0];
         at::Tensor gx;
@@ -83,12 +97,96 @@ struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
     }
 };
 
-void bind(int64_t frob_f32, int64_t frob_bf16, int64_t scale_f32, int64_t scale_bf16, int64_t last_error, int64_t small_batch) {
-    g_entry.frob_f32 = reinterpret_cast<FrobFn>(frob_f32);
-    g_entry.frob_bf16 = reinterpret_cast<FrobFn>(frob_bf16);
-    g_entry.scale_f32 = reinterpret_cast<ScaleFn>(scale_f32);
-    g_entry.scale_bf16 = reinterpret_cast<ScaleFn>(scale_bf16);
-    g_entry.last_error = reinterpret_cast<ErrFn>(last_error);
+// symmetric_orthogonalization(x) with x requiring grad: K1 forward, K2 backward (rotation_representation.py:192-206 and its autograd).
+struct ProjectNode : public torch::autograd::Function<ProjectNode> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &x, int64_t stream) {
+        const int64_t b = x.numel() / 9;
+        at::Tensor r = at::empty({b, 3, 3}, x.options().dtype(at::kFloat));
+        {
+            c10::DeviceGuard guard(x.device());
+            check((x.scalar_type() == at::kBFloat16 ? g_entry.fwd_bf16 : g_entry.fwd_f32)(x.data_ptr(), static_cast<float *>(r.data_ptr()), nullptr, b,
+                                                                                         reinterpret_cast<void *>(stream)),
+                  "so3_project_fwd");
+        }
+        ctx->save_for_backward({x});
+        ctx->saved_data["stream"] = stream;
+        return r;
+    }
+    static variable_list backward(AutogradContext *ctx, variable_list grads) {
+        no_double_backward();
+        const at::Tensor x = ctx->get_saved_variables()[0];
+        at::Tensor g = grads[0];
+        if (!g.defined()) return {at::Tensor(), at::Tensor()};
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        at::Tensor dm = at::empty_like(x);
+        check((x.scalar_type() == at::kBFloat16 ? g_entry.bwd_bf16 : g_entry.bwd_f32)(x.data_ptr(), static_cast<const float *>(g.data_ptr()), dm.data_ptr(),
+                                                                                     x.numel() / 9, reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+              "so3_project_bwd");
+        return {dm, at::Tensor()};
+    }
+};
+
+// loss_frobenius(a, b) = mean_b ||b - a||_F, differentiable in both arguments (3D-Pose/loss.py:7-11).  K3' writes the loss and its
+// gradient with respect to its FIRST pointer; the loss is symmetric, so the argument that wants a gradient goes first (the
+// reference's call sites pass the network's rotation second, 3D-Pose/main.py:85) and the other one's, if asked for, is the negative.
+struct FrobLossNode : public torch::autograd::Function<FrobLossNode> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &a, const at::Tensor &b_, int64_t stream, int64_t workspace) {
+        const int64_t b = a.numel() / 9;
+        const bool first = a.requires_grad();              // gradient is taken with respect to `a` (else `b_`)
+        const at::Tensor &p = first ? a : b_, &t = first ? b_ : a;
+        const bool need_grad = a.requires_grad() || b_.requires_grad();
+        at::Tensor g = need_grad ? at::empty_like(p) : at::Tensor();
+        at::Tensor loss_sum = at::empty({1}, a.options().dtype(at::kDouble));
+        at::Tensor loss = at::empty({}, a.options());
+        {
+            c10::DeviceGuard guard(a.device());
+            check(g_entry.loss_f32(static_cast<const float *>(p.data_ptr()), static_cast<const float *>(t.data_ptr()),
+                                   g.defined() ? static_cast<float *>(g.data_ptr()) : nullptr, static_cast<double *>(loss_sum.data_ptr()),
+                                   static_cast<float *>(loss.data_ptr()), reinterpret_cast<void *>(workspace), b, reinterpret_cast<void *>(stream)),
+                  "so3_frob_loss_f32");
+        }
+        if (need_grad) {
+            ctx->saved_data["g"] = g;
+            ctx->saved_data["first"] = first;
+            ctx->saved_data["other_shape"] = t.sizes().vec();
+            ctx->saved_data["stream"] = stream;
+        }
+        return loss;
+    }
+    static variable_list backward(AutogradContext *ctx, variable_list grads) {
+        no_double_backward();
+        const at::Tensor g = ctx->saved_data["g"].toTensor();
+        const bool first = ctx->saved_data["first"].toBool();
+        const at::Tensor &gl = grads[0];
+        at::Tensor mine, other;
+        if (gl.defined()) {
+            if (gl.scalar_type() == at::kFloat && gl.is_cuda() && gl.numel() == 1) {
+                mine = at::empty_like(g);
+                check(g_entry.scale_f32(g.data_ptr(), static_cast<const float *>(gl.data_ptr()), mine.data_ptr(), g.numel(),
+                                        reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+                      "so3_scale");
+            } else {
+                mine = g * gl;
+            }
+            if (ctx->needs_input_grad(first ? 1 : 0)) other = mine.neg().view(ctx->saved_data["other_shape"].toIntVector());
+        }
+        return first ? variable_list{mine, other, at::Tensor(), at::Tensor()} : variable_list{other, mine, at::Tensor(), at::Tensor()};
+    }
+};
+
+void bind(const py::dict &addresses, int64_t small_batch) {
+    auto at_ = [&](const char *name) -> int64_t { return addresses[name].cast<int64_t>(); };
+    g_entry.frob_f32 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_ws_f32"));
+    g_entry.frob_bf16 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_ws_bf16"));
+    g_entry.scale_f32 = reinterpret_cast<ScaleFn>(at_("so3_scale_f32"));
+    g_entry.scale_bf16 = reinterpret_cast<ScaleFn>(at_("so3_scale_bf16"));
+    g_entry.fwd_f32 = reinterpret_cast<FwdFn>(at_("so3_project_fwd_f32"));
+    g_entry.fwd_bf16 = reinterpret_cast<FwdFn>(at_("so3_project_fwd_bf16"));
+    g_entry.bwd_f32 = reinterpret_cast<BwdFn>(at_("so3_project_bwd_f32"));
+    g_entry.bwd_bf16 = reinterpret_cast<BwdFn>(at_("so3_project_bwd_bf16"));
+    g_entry.loss_f32 = reinterpret_cast<LossFn>(at_("so3_frob_loss_ws_f32"));
+    g_entry.last_error = reinterpret_cast<ErrFn>(at_("so3_last_error"));
     g_entry.small_batch = small_batch;
 }
 
@@ -105,9 +203,29 @@ py::object frobenius_head(const at::Tensor &x, const at::Tensor &r_true, bool wa
     return py::make_tuple(out[0], out.size() > 1 ? py::cast(out[1]) : py::none());
 }
 
+// None unless x is the node's case (then the rotation, (B,3,3) float32, with its gradient path).
+py::object symmetric_orthogonalization(const at::Tensor &x, int64_t stream) {
+    const auto dt = x.scalar_type();
+    if (g_entry.fwd_f32 == nullptr || !x.is_cuda() || (dt != at::kFloat && dt != at::kBFloat16) || !x.is_contiguous() || x.numel() < 9 ||
+        x.numel() % 9 != 0 || !x.requires_grad() || !at::GradMode::is_enabled())
+        return py::none();
+    return py::cast(ProjectNode::apply(x, stream));
+}
+
+// None unless (a, b) is the node's case (then the 0-dim float32 mean).
+py::object loss_frobenius(const at::Tensor &a, const at::Tensor &b, int64_t stream, int64_t workspace) {
+    if (g_entry.loss_f32 == nullptr || !a.is_cuda() || a.scalar_type() != at::kFloat || b.scalar_type() != at::kFloat || !a.is_contiguous() ||
+        !b.is_contiguous() || a.numel() < 9 || a.numel() % 9 != 0 || b.numel() != a.numel() || b.device() != a.device() ||
+        !((a.requires_grad() || b.requires_grad()) && at::GradMode::is_enabled()) || (a.numel() / 9 > g_entry.small_batch && workspace == 0))
+        return py::none();
+    return py::cast(FrobLossNode::apply(a, b, stream, workspace));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
-    m.def("bind", &bind, "addresses of the C-ABI entry points (so3_frob_fwd_bwd_ws_*, so3_scale_*, so3_last_error) and kSmallBatch");
+    m.def("bind", &bind, "addresses of the C-ABI entry points by name (a dict) and kSmallBatch");
     m.def("frobenius_head", &frobenius_head);
+    m.def("symmetric_orthogonalization", &symmetric_orthogonalization);
+    m.def("loss_frobenius", &loss_frobenius);
 }

@@ -82,8 +82,9 @@ def _node():
         import ctypes
         lib = _libh()
         addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
-        _so3node.bind(addr("so3_frob_fwd_bwd_ws_f32"), addr("so3_frob_fwd_bwd_ws_bf16"), addr("so3_scale_f32"), addr("so3_scale_bf16"),
-                      addr("so3_last_error"), _SMALL_BATCH)
+        _so3node.bind({name: addr(name) for name in (
+            "so3_frob_fwd_bwd_ws_f32", "so3_frob_fwd_bwd_ws_bf16", "so3_scale_f32", "so3_scale_bf16", "so3_project_fwd_f32", "so3_project_fwd_bf16",
+            "so3_project_bwd_f32", "so3_project_bwd_bf16", "so3_frob_loss_ws_f32", "so3_last_error")}, _SMALL_BATCH)
         _NODE_BOUND = True
     return _so3node
 
@@ -296,6 +297,11 @@ def symmetric_orthogonalization(x: torch.Tensor) -> torch.Tensor:
         with _on_device(dev):
             _check(fn(m.data_ptr(), r.data_ptr(), None, b, _stream(dev)), "so3_project_fwd")
         return r
+    node = _node()
+    if node is not None and type(x) is torch.Tensor and x.is_cuda:
+        r = node.symmetric_orthogonalization(x, _stream(x.device))          # the C++ node; None for what it does not cover
+        if r is not None:
+            return r
     return _SymmetricOrthogonalization.apply(x)
 
 
@@ -488,6 +494,17 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
 
     Returns the arguments' dtype as the reference (3D-Pose/loss.py:7-11): float32 through K3'; if either argument is
     float64 (e.g. the float64 head's output) its float64 twin, so3_frob_loss_f64."""
+    node = _node()
+    if node is not None and type(R_pred) is torch.Tensor and type(R_true) is torch.Tensor and R_pred.is_cuda:
+        dev = R_pred.device
+        st = _stream(dev)
+        ws = 0
+        if R_pred.numel() > 9 * _SMALL_BATCH:
+            w = _workspace(dev, st)
+            ws = w.data_ptr() if w is not None else 0
+        loss = node.loss_frobenius(R_pred, R_true, st, ws)                   # the C++ node; None for what it does not cover
+        if loss is not None:
+            return loss
     return _LossFrobenius.apply(R_pred, R_true)
 
 

@@ -182,6 +182,12 @@ def test_autograd_node_declines_what_it_does_not_cover():
     assert rr._node() is _so3node                                                    # binds the addresses out of libso3proj.so
     for xi, ti in ((x, t), (x.half(), t), (x[:, :8], t), (x.t().contiguous().t(), t), (x, t.double()), (x, t[:4]), (torch.randn(9), t)):
         assert _so3node.frobenius_head(xi, ti, True, 0, 0) is None
+    xg = x.clone().requires_grad_(True)
+    assert _so3node.symmetric_orthogonalization(xg, 0) is None and _so3node.loss_frobenius(xg.view(8, 3, 3), t, 0, 0) is None   # CPU tensors
     with pytest.raises(RuntimeError, match="HIP device only"):                       # the mirror's own error for CPU tensors is unchanged
         rr.frobenius_head(x, t)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        rr.symmetric_orthogonalization(xg)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        rr.loss_frobenius(xg.view(8, 3, 3), t)
 

@@ -764,6 +764,51 @@ def test_cpp_autograd_node_equals_the_python_function(rr, dtype, b):
         torch.autograd.grad(ld, xd, create_graph=True)
 
 
+@pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 3), (torch.float32, 70_000)])
+def test_cpp_nodes_of_the_two_call_spelling_equal_the_python_functions(rr, dtype, b):
+    """The reference's own spelling -- out = symmetric_orthogonalization(out); loss = loss_frobenius(R, out); loss.backward()
+    (3D-Pose/main.py:60,85,90) -- goes through csrc/autograd_node.cpp's ProjectNode and FrobLossNode; the Python classes are
+    what they replace.  Same launches: rotation, loss and every gradient bit for bit, in either argument order of the loss."""
+    if rr._node() is None:
+        pytest.skip("_so3node not built")
+    gen = torch.Generator(device=DEV).manual_seed(7 + b)
+    x = torch.randn(b, 9, device=DEV, generator=gen).to(dtype)
+    t = rr.symmetric_orthogonalization(torch.randn(b, 9, device=DEV, generator=gen))
+    for swapped in (True, False):                                          # the reference passes (R, out): the prediction second
+        xn = x.clone().requires_grad_(True)
+        xp = x.clone().requires_grad_(True)
+        rn = rr.symmetric_orthogonalization(xn)
+        rp = rr._SymmetricOrthogonalization.apply(xp)
+        assert "ProjectNode" in rn.grad_fn.name() and rn.shape == (b, 3, 3) and rn.dtype == torch.float32 and torch.equal(rn, rp)
+        ln = rr.loss_frobenius(t, rn) if swapped else rr.loss_frobenius(rn, t)
+        lp = rr._LossFrobenius.apply(t, rp) if swapped else rr._LossFrobenius.apply(rp, t)
+        assert "FrobLossNode" in ln.grad_fn.name() and ln.dim() == 0 and ln.dtype == torch.float32 and torch.equal(ln, lp)
+        (ln * 0.75).backward()
+        (lp * 0.75).backward()
+        assert xn.grad.dtype == dtype and xn.grad.shape == (b, 9) and torch.equal(xn.grad, xp.grad)
+    # both arguments of the loss want their gradient; a (2,b/2..)-shaped head input; a non-contiguous upstream gradient of the head
+    a = rr.symmetric_orthogonalization(x.float()).clone().requires_grad_(True)
+    c = t.clone().requires_grad_(True)
+    (rr.loss_frobenius(a, c) * 2.0).backward()
+    a2, c2 = a.detach().clone().requires_grad_(True), c.detach().clone().requires_grad_(True)
+    (rr._LossFrobenius.apply(a2, c2) * 2.0).backward()
+    assert torch.equal(a.grad, a2.grad) and torch.equal(c.grad, c2.grad) and torch.equal(c.grad, -a.grad)
+    xs = x.float().clone().requires_grad_(True)
+    w = torch.randn(3, 3, b, device=DEV, generator=gen).permute(2, 0, 1)                                   # strided cotangent
+    rr.symmetric_orthogonalization(xs).backward(w)
+    xs2 = x.float().clone().requires_grad_(True)
+    rr._SymmetricOrthogonalization.apply(xs2).backward(w)
+    assert torch.equal(xs.grad, xs2.grad)
+    # declined: float16 / float64 / strided input, no gradient wanted, double backward refused
+    assert "ProjectNode" not in rr.symmetric_orthogonalization(x.half().requires_grad_(True)).grad_fn.name()
+    assert rr.symmetric_orthogonalization(x).grad_fn is None
+    xd = x.float().clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="differentiate twice"):
+        torch.autograd.grad(rr.symmetric_orthogonalization(xd).sum(), xd, create_graph=True)
+    with pytest.raises(RuntimeError, match="differentiate twice"):
+        torch.autograd.grad(rr.loss_frobenius(t, a), a, create_graph=True)
+
+
 @pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1000), (torch.bfloat16, 3000)])
 def test_recorded_training_step_matches_the_autograd_spelling(rr, dtype, b):
     """FrobeniusHeadStep (one hipGraph replay: config #4's launch-bound step) against frobenius_head + backward; sizes on

@@ -4,6 +4,7 @@
   floor+c    the same with one ctypes call (so3_version) in forward and backward through CDLL (releases the GIL),
   floor+p    the same through PyDLL (keeps the GIL),
   mirror     frobenius_head(x, t)[0].backward()
+  two calls  loss_frobenius(t, symmetric_orthogonalization(x)).backward(), the reference's own spelling
 as median / p10 / p90 of 20 blocks of 200 steps each (the cost is bimodal with where the autograd engine's device thread runs)."""
 import ctypes, os, sys, time
 import torch
@@ -50,6 +51,11 @@ def mirror():
     x.grad = None
 
 
+def two_calls():                                   # the reference's own spelling (3D-Pose/main.py:60,85,90)
+    rr.loss_frobenius(t, rr.symmetric_orthogonalization(x)).backward()
+    x.grad = None
+
+
 def blocks(fn, nblocks=20, n=200):
     for _ in range(300):
         fn()
@@ -67,9 +73,14 @@ def blocks(fn, nblocks=20, n=200):
 
 for name, fn in (("floor", stepper(make(None))), ("floor + CDLL call", stepper(make(lib.so3_version))),
                  ("floor + PyDLL call", stepper(make(plib.so3_version))), ("mirror", mirror), ("floor (again)", stepper(make(None))),
-                 ("mirror (again)", mirror)):
+                 ("mirror (again)", mirror), ("two calls (head, loss)", two_calls)):
     b = blocks(fn)
     print("%-22s median %6.1f  p10 %6.1f  p90 %6.1f  min %6.1f us/step" % (name, 0.5 * (b[9] + b[10]), b[2], b[17], b[0]), flush=True)
+node, rr._so3node = rr._so3node, None              # the same spellings through the Python autograd.Functions
+for name, fn in (("mirror, Python class", mirror), ("two calls, Python classes", two_calls)):
+    b = blocks(fn)
+    print("%-26s median %6.1f  p10 %6.1f  p90 %6.1f  min %6.1f us/step" % (name, 0.5 * (b[9] + b[10]), b[2], b[17], b[0]), flush=True)
+rr._so3node = node
 if len(sys.argv) > 1:
     os.sched_setaffinity(0, {0, 1})
     print("-- pinned to cores 0-1")
