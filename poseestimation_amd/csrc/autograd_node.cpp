@@ -8,10 +8,12 @@
 //
 // frobenius_head handles: x float32 / bfloat16, contiguous, (B,9) or (B,3,3), B >= 1; R_true float32, contiguous, same device, not
 // requiring grad.  symmetric_orthogonalization: x float32 / bfloat16, contiguous, numel a multiple of 9, requiring grad.
-// loss_frobenius: two float32 contiguous tensors of B x 9 elements on one device, at least one requiring grad.  Anything else:
-// the caller uses the Python class.
+// loss_frobenius: two float32 contiguous tensors of B x 9 elements on one device, at least one requiring grad.  row_head (the 6D
+// head and the other row-operation heads): float32, contiguous, requiring grad.  Anything else: the caller uses the Python class.
 #include <torch/extension.h>
 #include <c10/core/DeviceGuard.h>
+
+#include <vector>
 
 namespace {
 
@@ -175,6 +177,45 @@ struct FrobLossNode : public torch::autograd::Function<FrobLossNode> {
     }
 };
 
+// The heads that are plain row operations -- (..., width) float32 -> (..., 3, 3): the 6D Gram-Schmidt head (rotation_representation.py:21-36)
+// and the quaternion / Euler / 5D / exponential-map heads of the reference's dispatch tables -- share one node; the entry points
+// so3_<head>_fwd_f32(X, R, B, stream) / so3_<head>_bwd_f32(X, G, dX, B, stream) travel as addresses.
+typedef int (*RowFwdFn)(const float *X, float *R, int64_t B, void *stream);
+typedef int (*RowBwdFn)(const float *X, const float *G, float *dX, int64_t B, void *stream);
+struct RowHeadNode : public torch::autograd::Function<RowHeadNode> {
+    static at::Tensor forward(AutogradContext *ctx, const at::Tensor &x, int64_t width, int64_t fwd, int64_t bwd, int64_t stream) {
+        const int64_t b = x.numel() / width;
+        std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end() - 1);
+        shape.push_back(3);
+        shape.push_back(3);
+        at::Tensor r = at::empty(shape, x.options());
+        {
+            c10::DeviceGuard guard(x.device());
+            check(reinterpret_cast<RowFwdFn>(fwd)(static_cast<const float *>(x.data_ptr()), static_cast<float *>(r.data_ptr()), b, reinterpret_cast<void *>(stream)),
+                  "row head forward");
+        }
+        ctx->save_for_backward({x});
+        ctx->saved_data["bwd"] = bwd;
+        ctx->saved_data["width"] = width;
+        ctx->saved_data["stream"] = stream;
+        return r;
+    }
+    static variable_list backward(AutogradContext *ctx, variable_list grads) {
+        no_double_backward();
+        const at::Tensor x = ctx->get_saved_variables()[0];
+        at::Tensor g = grads[0];
+        if (!g.defined()) return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        if (g.scalar_type() != at::kFloat) g = g.to(at::kFloat);
+        g = g.contiguous();
+        at::Tensor dx = at::empty_like(x);
+        check(reinterpret_cast<RowBwdFn>(ctx->saved_data["bwd"].toInt())(static_cast<const float *>(x.data_ptr()), static_cast<const float *>(g.data_ptr()),
+                                                                        static_cast<float *>(dx.data_ptr()), x.numel() / ctx->saved_data["width"].toInt(),
+                                                                        reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+              "row head backward");
+        return {dx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    }
+};
+
 void bind(const py::dict &addresses, int64_t small_batch) {
     auto at_ = [&](const char *name) -> int64_t { return addresses[name].cast<int64_t>(); };
     g_entry.frob_f32 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_ws_f32"));
@@ -221,6 +262,14 @@ py::object loss_frobenius(const at::Tensor &a, const at::Tensor &b, int64_t stre
     return py::cast(FrobLossNode::apply(a, b, stream, workspace));
 }
 
+// None unless x is the node's case: float32, contiguous, last dimension `width`, at least one row, requiring grad.
+py::object row_head(const at::Tensor &x, int64_t width, int64_t fwd, int64_t bwd, int64_t stream) {
+    if (fwd == 0 || bwd == 0 || !x.is_cuda() || x.scalar_type() != at::kFloat || !x.is_contiguous() || x.dim() < 1 || x.size(-1) != width ||
+        x.numel() < width || !x.requires_grad() || !at::GradMode::is_enabled())
+        return py::none();
+    return py::cast(RowHeadNode::apply(x, width, fwd, bwd, stream));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -228,4 +277,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("frobenius_head", &frobenius_head);
     m.def("symmetric_orthogonalization", &symmetric_orthogonalization);
     m.def("loss_frobenius", &loss_frobenius);
+    m.def("row_head", &row_head);
 }

@@ -89,6 +89,23 @@ def _node():
     return _so3node
 
 
+_ROW_HEADS = {}
+
+
+def _row_head(symbol: str, width: int, x):
+    """(..., width) -> (..., 3, 3) through the C++ node of the row-operation heads, or None when it (or its case) is not there."""
+    node = _node()
+    if node is None or type(x) is not torch.Tensor or not x.is_cuda:
+        return None
+    fns = _ROW_HEADS.get(symbol)
+    if fns is None:
+        import ctypes
+        lib = _libh()
+        fns = tuple(ctypes.cast(getattr(lib, "so3_%s_%s_f32" % (symbol, d)), ctypes.c_void_p).value for d in ("fwd", "bwd"))
+        _ROW_HEADS[symbol] = fns
+    return node.row_head(x, width, fns[0], fns[1], _stream(x.device))
+
+
 def _require_device(*tensors: torch.Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -947,7 +964,8 @@ class _Ortho6d(torch.autograd.Function):
 def compute_rotation_matrix_from_ortho6d(poses: torch.Tensor) -> torch.Tensor:
     """6D (two 3-vectors) -> rotation by Gram-Schmidt, columns (x, y, z); rotation_representation.py:21-36.
     poses: (..., 6); returns (..., 3, 3) float32, differentiable."""
-    return _Ortho6d.apply(poses)
+    r = _row_head("ortho6d", 6, poses)
+    return r if r is not None else _Ortho6d.apply(poses)
 
 
 # --------------------------------------------------------------------------------------------
@@ -995,21 +1013,24 @@ def _batch_of(x: torch.Tensor, width: int, name: str) -> None:
 def compute_rotation_matrix_from_quaternion(quaternion: torch.Tensor) -> torch.Tensor:
     """(B,4) quaternion (w,x,y,z), normalised with max(|q|, 1e-8) -> (B,3,3); rotation_representation.py:137-171."""
     _batch_of(quaternion, 4, "compute_rotation_matrix_from_quaternion")
-    return _Quat.apply(quaternion)
+    r = _row_head("quat", 4, quaternion)
+    return r if r is not None else _Quat.apply(quaternion)
 
 
 def compute_rotation_matrix_from_euler(euler: torch.Tensor) -> torch.Tensor:
     """(B,3) Euler angles -> (B,3,3) in the reference's convention (c2,s2 from column 2, c3,s3 from column 1);
     rotation_representation.py:92-113."""
     _batch_of(euler, 3, "compute_rotation_matrix_from_euler")
-    return _Euler.apply(euler)
+    r = _row_head("euler", 3, euler)
+    return r if r is not None else _Euler.apply(euler)
 
 
 def compute_rotation_matrix_from_ortho5d(a: torch.Tensor) -> torch.Tensor:
     """(B,5) -> (B,3,3): stereographic un-projection of a[:,2:5] to a unit 4-vector, then the 6D head;
     rotation_representation.py:118-134."""
     _batch_of(a, 5, "compute_rotation_matrix_from_ortho5d")
-    return _Ortho5d.apply(a)
+    r = _row_head("ortho5d", 5, a)
+    return r if r is not None else _Ortho5d.apply(a)
 
 
 def so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001) -> torch.Tensor:
@@ -1018,7 +1039,8 @@ def so3_exp_map(log_rot: torch.Tensor, eps: float = 0.0001) -> torch.Tensor:
         raise ValueError("Input tensor shape has to be Nx3.")                   # reference: :255-256
     if eps != 0.0001:
         raise NotImplementedError("so3_exp_map: the kernel is built for the reference's only eps, 1e-4")
-    return _ExpMap.apply(log_rot)
+    r = _row_head("expmap", 3, log_rot)
+    return r if r is not None else _ExpMap.apply(log_rot)
 
 
 def vec_3d_to_SO3(x: torch.Tensor) -> torch.Tensor:

@@ -809,6 +809,33 @@ def test_cpp_nodes_of_the_two_call_spelling_equal_the_python_functions(rr, dtype
         torch.autograd.grad(rr.loss_frobenius(t, a), a, create_graph=True)
 
 
+@pytest.mark.parametrize("name,width,cls", [("compute_rotation_matrix_from_ortho6d", 6, "_Ortho6d"), ("compute_rotation_matrix_from_quaternion", 4, "_Quat"),
+                                            ("compute_rotation_matrix_from_euler", 3, "_Euler"), ("compute_rotation_matrix_from_ortho5d", 5, "_Ortho5d"),
+                                            ("so3_exp_map", 3, "_ExpMap")])
+def test_cpp_node_of_the_row_heads_equals_the_python_functions(rr, name, width, cls):
+    """The heads that are plain row operations share csrc/autograd_node.cpp's RowHeadNode; the Python classes are what it replaces
+    (and still serve float16 / strided / no-grad input).  Same launches: rotation and gradient bit for bit."""
+    if rr._node() is None:
+        pytest.skip("_so3node not built")
+    gen = torch.Generator(device=DEV).manual_seed(width)
+    x = torch.randn(777, width, device=DEV, generator=gen)
+    w = torch.randn(777, 3, 3, device=DEV, generator=gen)
+    xn, xp = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    rn, rp = getattr(rr, name)(xn), getattr(rr, cls).apply(xp)
+    assert "RowHeadNode" in rn.grad_fn.name() and rn.shape == (777, 3, 3) and torch.equal(rn, rp)
+    (rn * w).sum().backward()
+    (rp * w).sum().backward()
+    assert torch.equal(xn.grad, xp.grad)
+    assert "RowHeadNode" not in getattr(rr, name)(x.half().requires_grad_(True)).grad_fn.name()
+    assert getattr(rr, name)(x).grad_fn is None
+    if width == 6:                                                          # the 6D head takes (..., 6)
+        x3 = x[:776].reshape(2, 388, 6).clone().requires_grad_(True)
+        r3 = rr.compute_rotation_matrix_from_ortho6d(x3)
+        assert r3.shape == (2, 388, 3, 3) and torch.equal(r3.reshape(-1, 3, 3), rp[:776])
+        r3.sum().backward()
+        assert x3.grad.shape == (2, 388, 6)
+
+
 @pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 1000), (torch.bfloat16, 3000)])
 def test_recorded_training_step_matches_the_autograd_spelling(rr, dtype, b):
     """FrobeniusHeadStep (one hipGraph replay: config #4's launch-bound step) against frobenius_head + backward; sizes on
