@@ -233,6 +233,8 @@ template <int NPL> struct RowCtx {
     double acc;             // per-lane float64 partial of the operation's reduction
     bool flag;              // per-lane sticky flag (K4: cosine out of range)
     const char *img1;       // LDS image of the second input's block (operations with kLateIn1 read their rows from it themselves)
+    char *scratch;          // the wave's Op::kWaveScratch bytes of LDS, kept across its rounds (K1: the queue of hard rows)
+    int pending;            // wave-uniform state that goes with it (K1: how many rows the queue holds)
 };
 
 #ifndef SO3_HOST_MODEL
@@ -279,6 +281,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     constexpr int kOutBytes = kOut0B + kOut1B;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     __shared__ __attribute__((aligned(16))) char lds[kWaves][kSlot];
+    __shared__ __attribute__((aligned(16))) char scratch[kWaves][Op::kWaveScratch > 0 ? Op::kWaveScratch : 4];
     __shared__ double red[Op::kReduce ? kWaves : 1];
     __shared__ int red_flag[Op::kReduce ? kWaves : 1];
 
@@ -295,6 +298,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.acc = 0.0;
     ctx.flag = false;
     ctx.img1 = nullptr;
+    ctx.scratch = scratch[wave_in_block];
+    ctx.pending = 0;
     if (t < nrounds) {
         auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
             const int64_t left = nunits - tr * NPL;
@@ -380,6 +385,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 issue(held);
             }
         }
+        if constexpr (Op::kWaveScratch > 0) op.template drain<T, NPL>(ctx);
     }
     if (Op::kReduce) {
         double v = ctx.acc;
@@ -439,6 +445,9 @@ struct OpBase {
     // kLateIn1: the operation reads the second input's rows out of LDS itself (late_in1), where it first needs them -- for K2 / K3 /
     // K1+K4 that is AFTER the projection, whose ~110 live registers the 18 of a second input's rows would otherwise sit beside
     static constexpr bool kLateIn1 = false;
+    // kWaveScratch: bytes of LDS per wave that live across the wave's rounds (ctx.scratch); an operation that asks for them also
+    // provides drain(ctx), called once when the wave has done its last round
+    static constexpr int kWaveScratch = 0;
 #ifndef SO3_HOST_MODEL
     ReduceWs *ws = nullptr;        // reduction workspace (nullptr: atomics onto host-initialised accumulators)
     unsigned ws_slot0 = 0;         // slots below this one were filled by the remainder kernel launched before the engine
@@ -450,15 +459,25 @@ struct OpBase {
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
 // K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path, the Jacobi path for
 // the rows it declares hard (project_rotation).
+// Hard rows are DEFERRED when they are few: a round that holds up to 16 NPL of them queues their matrices (and row numbers) in the
+// wave's scratch LDS and goes on; the Jacobi path runs once, when the wave has done its last round, on what the queue holds (64 NPL
+// rows at most), and its rotations overwrite what the rounds' block stores wrote for those rows.  A batch with 1 % or 10 % of hard
+// rows then pays for one Jacobi pass per wave instead of one per round that holds a hard row (72 % / 100 % of the rounds).  A round
+// dense in hard rows (or one the queue has no room for) takes the Jacobi path on the spot, as every such round did before.
+// A row's bits do not depend on where it waited: signed_svd executes the same IEEE operations per matrix in every lane and half.
 template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kQueueWords = 11;                                  // 9 entries + the row number (two dwords)
+    static constexpr int kWaveScratch = kQueueWords * 128 * 4;              // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
     uint8_t *flip = nullptr;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
         const T (&m)[9] = rows.a;
         T (&r)[9] = rows.o0;
-        project_rotation<T, !FLIP>(m, r);
+        const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
+        if (__builtin_expect(wave_any(R::any(hard)), 0)) defer<T, NPL>(ctx, m, r, hard);
         if (FLIP) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
@@ -469,6 +488,79 @@ struct OpProject : OpBase {
                 __builtin_amdgcn_raw_buffer_store_b8(bit, row_rsrc<1>(flip, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane, 0, 0);
             }
         }
+    }
+    // queue the round's hard rows (the block store writes whatever the fast path left for them; flush() overwrites it)
+    template <class T, int NPL>
+    __device__ __forceinline__ void defer(RowCtx<NPL> &ctx, const T (&m)[9], T (&r)[9], typename Tr<T>::mask hard) const {
+        unsigned long long votes[NPL];
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            votes[k] = __builtin_amdgcn_ballot_w64(Tr<T>::lane_of(hard, k) && ctx.exists[k]);
+            n += __builtin_popcountll(votes[k]);
+        }
+        if (n > 16 * NPL || ctx.pending + n > 64 * NPL) {
+            // a round dense in hard rows (or a full queue): the Jacobi path here, on the round itself, as before round 3's queue --
+            // queued, such rows would be stored twice, the second time 4 bytes per lane and store
+            T rj[9];
+            rotation_from(signed_svd<false, T>(m), rj);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) r[j] = Tr<T>::sel(hard, rj[j], r[j]);
+            return;
+        }
+        float *q = reinterpret_cast<float *>(ctx.scratch);
+        int at = ctx.pending;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            if (Tr<T>::lane_of(hard, k) && ctx.exists[k]) {
+                const unsigned lo = static_cast<unsigned>(votes[k]), hi = static_cast<unsigned>(votes[k] >> 32);
+                const int e = at + static_cast<int>(__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)));
+#pragma unroll
+                for (int i = 0; i < 9; ++i) q[128 * i + e] = Tr<T>::get(m[i], k);
+                const long long row = ctx.unit[k] * kUnitRows + ctx.lane;
+                q[128 * 9 + e] = __int_as_float(static_cast<int>(row & 0xffffffffll));
+                q[128 * 10 + e] = __int_as_float(static_cast<int>(row >> 32));
+            }
+            at += __builtin_popcountll(votes[k]);
+        }
+        ctx.pending = at;
+    }
+    // the Jacobi path on everything the queue holds; lane l takes entries l and (NPL = 2) 64 + l
+    template <class T, int NPL>
+    __device__ __forceinline__ void flush(RowCtx<NPL> &ctx) const {
+        wave_lds_fence();
+        const float *q = reinterpret_cast<const float *>(ctx.scratch);
+        const int count = ctx.pending;
+        T m[9];
+        long long row[NPL];
+        bool valid[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int e = 64 * k + ctx.lane;
+            valid[k] = e < count;
+            const int src = valid[k] ? e : 0;                   // an empty slot works on entry 0 (there is one); its result is dropped
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Tr<T>::set(m[i], k, q[128 * i + src]);
+            row[k] = static_cast<long long>(static_cast<unsigned>(__float_as_int(q[128 * 9 + src])))
+                     | (static_cast<long long>(__float_as_int(q[128 * 10 + src])) << 32);
+        }
+        wave_lds_fence();
+        T r[9];
+        rotation_from(signed_svd<false, T>(m), r);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the block stores that wrote these rows first have been performed
+        float *out = static_cast<float *>(out0);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            if (valid[k]) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __builtin_nontemporal_store(Tr<T>::get(r[i], k), out + row[k] * 9 + i);
+            }
+        }
+        ctx.pending = 0;
+    }
+    template <class T, int NPL>
+    __device__ __forceinline__ void drain(RowCtx<NPL> &ctx) const {
+        if (ctx.pending > 0) flush<T, NPL>(ctx);
     }
 };
 

@@ -285,6 +285,60 @@ def test_a_row_does_not_depend_on_its_neighbours(rr):
     assert torch.equal(rr.symmetric_orthogonalization(x[shuffled]), full.detach()[shuffled])
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_deferred_hard_rows_are_the_rows_the_tile_kernel_gives(rr, bf16):
+    """K1's engine queues the hard rows of a round that holds few of them and runs the Jacobi path once per wave, patching the
+    rows it had already stored; a round dense in hard rows takes it on the spot; a full queue too.  Every row, bit for bit,
+    against the one-row-per-thread kernel (same arithmetic, no queue), on a batch whose share of hard rows runs from none to
+    all by region, with and without flip flags, 16-byte aligned and not, and against the float64 oracle's verdict per family."""
+    from poseestimation_amd import _lib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
+    hr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hr)
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(123)
+    d = torch.device(DEV)
+    n = 64 * 6000 + 37                                                       # 6000 whole units for the engine + a remainder for the tile kernel
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    families = ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one", "all zero")
+    region = n // 6
+    for j, share in enumerate((0.0, 0.003, 0.03, 0.2, 0.6, 1.0)):         # sparse (queued), mixed, dense (on the spot)
+        lo, hi = j * region, (j + 1) * region
+        pick = torch.nonzero(torch.rand(hi - lo, device=DEV, generator=gen) < share).flatten() + lo
+        for f, name in enumerate(families):
+            idx = pick[f::len(families)]
+            if idx.numel():
+                x[idx] = hr.family(name, idx.numel(), d, gen).reshape(-1, 9)
+    if bf16:
+        x = x.bfloat16().float()                                              # values a bfloat16 tensor can hold
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(n, 9, device=DEV)
+    hard = torch.empty(n, dtype=torch.uint8, device=DEV)
+    assert lib.so3_project_fwd_diag_f32(x.data_ptr(), ref.data_ptr(), hard.data_ptr(), n, st) == 0
+    assert 0.1 * n < int(hard.sum().item()) < 0.45 * n                     # the mixture really is hard where it is meant to be (bfloat16 rounding breaks some ties)
+    fn = lib.so3_project_fwd_bf16 if bf16 else lib.so3_project_fwd_f32
+    for offset in (0, 1, 2):                                               # rows 36 B apart: 16-, 4- and 8-byte aligned starts
+        src = torch.empty((n + 1) * 9, device=DEV, dtype=torch.bfloat16 if bf16 else torch.float32)
+        xin = src[(2 * offset if bf16 else offset):][:n * 9].view(n, 9)     # bfloat16: even element offsets keep dword alignment
+        xin.copy_(x)
+        for want_flip in (False, True):
+            out = torch.full((n * 9 + 8,), 7.0, device=DEV)
+            r = out[offset:offset + n * 9].view(n, 9)
+            flip = torch.empty(n, dtype=torch.uint8, device=DEV) if want_flip else None
+            assert fn(xin.data_ptr(), r.data_ptr(), flip.data_ptr() if want_flip else None, n, st) == 0
+            assert torch.equal(r, ref), (offset, want_flip, int((r != ref).any(dim=1).sum().item()))
+            assert (out[:offset] == 7).all() and (out[offset + n * 9:] == 7).all()
+            if want_flip:
+                det = torch.linalg.det(x.double().view(n, 3, 3))
+                sure = det.abs() > 1e-6
+                assert torch.equal(flip.bool()[sure], (det < 0)[sure])
+    # orthogonal, det +1, and optimal wherever the answer is unique (the float64 oracle's conditioned error)
+    r3 = ref.view(n, 3, 3).double()
+    assert (r3.transpose(1, 2) @ r3 - torch.eye(3, device=DEV, dtype=torch.float64)).abs().amax() < 1e-5
+    assert (torch.linalg.det(r3) - 1).abs().max() < 1e-5
+
+
 def test_device_rows_match_the_host_model_of_the_same_templates(rr):
     """csrc/so3_device.h compiled for the host (oracle/kernel_model.cpp) against the device: same algorithm, the only
     difference being 1-ulp v_rsq/v_sqrt/v_rcp versus correctly rounded libm."""
@@ -994,8 +1048,8 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
 def test_hard_rows_cost_is_bounded(rr):
     """The worst case of K1 / K3 is on record and bounded (tools/k1_hard_rows.py, profiles/r03_k1_hard_rows.txt): a batch whose
     rows are HARD for the fast path (ties, near-reflections, rank deficiency: the packed Jacobi body runs on top of the fast
-    path for every wave that holds one) costs at most 2.4 x a Gaussian batch for K1 and 1.7 x for K3 (measured: 1.7-2.1 and
-    1.35-1.5; round 2: 1.9-2.0 already at 1 % hard rows), and rows that are merely far from unit scale cost nothing extra (they
+    path for every round dense in them) costs at most 2.2 x a Gaussian batch for K1 and 1.7 x for K3 (measured: 1.5-1.9 and
+    1.3-1.45; round 2: 1.9-2.0 already at 1 % hard rows), and rows that are merely far from unit scale cost nothing extra (they
     were hard in round 2: 1.6 x)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
@@ -1034,12 +1088,25 @@ def test_hard_rows_cost_is_bounded(rr):
 
     g1, g3 = both([torch.randn(n, 9, device=DEV, generator=gen) for _ in range(nb)])
     report = {}
-    for name, cap1, cap3 in (("near-reflection", 2.4, 1.7), ("entries in {-1,0,1}", 2.4, 1.7), ("generic ties", 2.4, 1.7), ("rank one", 2.4, 1.7),
+    for name, cap1, cap3 in (("near-reflection", 2.2, 1.7), ("entries in {-1,0,1}", 2.2, 1.7), ("generic ties", 2.2, 1.7), ("rank one", 2.2, 1.7),
                              ("1e5 * Gaussian", 1.15, 1.15), ("rank two", 1.15, 1.15)):
         xs = [hr.family(name, n, torch.device(DEV), gen).reshape(n, 9).contiguous() for _ in range(nb)]
         k1, k3 = both(xs)
         report[name] = (round(k1 / g1, 2), round(k3 / g3, 2))
         assert k1 <= cap1 * g1 and k3 <= cap3 * g3, (name, k1, g1, k3, g3, report)
+        del xs
+    # a batch with SOME hard rows (10 %) stays under the review's 1.6 x for K1: the engine queues them and runs the Jacobi path once
+    # per wave instead of once per round that holds one (measured 1.29-1.46; 1.6-1.9 before the queue)
+    for name in ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one"):
+        xs = []
+        for _ in range(nb):
+            x = torch.randn(n, 9, device=DEV, generator=gen)
+            idx = torch.nonzero(torch.rand(n, device=DEV, generator=gen) < 0.10).flatten()
+            x[idx] = hr.family(name, idx.numel(), torch.device(DEV), gen).reshape(-1, 9)
+            xs.append(x)
+        k1 = timed(lambda i: lib.so3_project_fwd_f32(xs[i % nb].data_ptr(), out[i % nb].data_ptr(), None, n, st))
+        report[name + " 10 %"] = round(k1 / g1, 2)
+        assert k1 <= 1.6 * g1, (name, k1, g1, report)
         del xs
 
 
