@@ -578,6 +578,52 @@ template <class T> struct Prescale {
 };
 // The fast path on a matrix whose |M|_F^2 = f is known; in_window: the rows whose f lies inside the scale window (the others are
 // declared hard at the end -- after the prescale these are zero, infinite and NaN rows).
+// The head of the fast path: cofactors, det, |adj M|_F^2 and the cubic of the squared singular values in units of f = |M|_F^2
+// (mu / f in [0, 1]: no power of the entries beyond f^2 is formed).  Shared by quat_rotation_core and by invariant_hard_rows, so
+// that both judge a row by the same bits.
+template <class T> struct CubicHead {
+    T det, cf;      // det M, |adj M|_F^2 = s1^2 s2^2 + s1^2 s3^2 + s2^2 s3^2
+    T cfn, dn;      // cf / f^2,  det^2 / f^3
+    T p, x;         // p = (1 - 3 cfn)/9 (floored at 1e-12),  x = cos(theta) = q / p^(3/2) clamped to [-1, 1]
+};
+template <class T> __device__ __forceinline__ CubicHead<T> cubic_head(const T (&m)[9], T f) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    CubicHead<T> h;
+    const T g00 = R::fma(m[4], m[8], -(m[5] * m[7])), g01 = R::fma(m[5], m[6], -(m[3] * m[8])), g02 = R::fma(m[3], m[7], -(m[4] * m[6]));
+    const T g10 = R::fma(m[2], m[7], -(m[1] * m[8])), g11 = R::fma(m[0], m[8], -(m[2] * m[6])), g12 = R::fma(m[1], m[6], -(m[0] * m[7]));
+    const T g20 = R::fma(m[1], m[5], -(m[2] * m[4])), g21 = R::fma(m[2], m[3], -(m[0] * m[5])), g22 = R::fma(m[0], m[4], -(m[1] * m[3]));
+    h.det = R::fma(m[2], g02, R::fma(m[1], g01, m[0] * g00));
+    T cf = g00 * g00;
+    cf = R::fma(g01, g01, cf); cf = R::fma(g02, g02, cf); cf = R::fma(g10, g10, cf); cf = R::fma(g11, g11, cf);
+    cf = R::fma(g12, g12, cf); cf = R::fma(g20, g20, cf); cf = R::fma(g21, g21, cf); cf = R::fma(g22, g22, cf);
+    h.cf = cf;
+    const T inv_f = R::rcp(f);
+    const T di = h.det * inv_f;
+    h.cfn = (cf * inv_f) * inv_f;
+    h.dn = (di * di) * inv_f;
+    h.p = R::max(R::fma(h.cfn, R::splat(S(-1.0 / 3.0)), R::splat(S(1.0 / 9.0))), R::splat(S(1e-12)));
+    const T q = R::fma(h.dn, R::splat(S(0.5)), R::fma(h.cfn, R::splat(S(-1.0 / 6.0)), R::splat(S(1.0 / 27.0))));
+    h.x = R::clamp(q * R::rsq((h.p * h.p) * h.p), R::splat(S(-1)), R::splat(S(1)));
+    return h;
+}
+// Rows that are hard by their invariants alone: no eigenvalue is needed to see that the three singular values coincide with
+// det < 0 (a near-reflection: 27 det^2 = |M|^6 is the equality case of the AM-GM inequality) or that the rank is one
+// (|adj M| = 0).  Each bar lies well inside what steps 4b-6 call hard anyway (none in 2e7 Gaussian rows); the point is that EVERY
+// row of such a family is caught -- Newton's lambda, on which 4b judges, is still far from a multiple root on 2-7 % of them -- so
+// that a round made of them can be recognised before the fast path is run (OpProject's dense-round shortcut).  A per-row rule
+// like every other: it is folded into the verdict below.  (Ties s2 = s3 with det < 0 show as x = +1, the cubic's two smaller
+// roots coinciding, but float32 resolves x to 1e-7, i.e. the tie to 5e-4: a bar loose enough to catch every row of a batch of
+// ties -- x >= 1 - 1e-5 did not -- already takes 1e-4 of the Gaussian rows, and one queued row per 30 waves lengthens the
+// launch's tail by a Jacobi pass: K1 8 % slower on Gaussian input.  No rule for ties.)
+template <class T> __device__ __forceinline__ typename Tr<T>::mask invariant_hard(const CubicHead<T> &h) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    const typename R::mask refl = R::gt(R::splat(S(0)), h.det) & R::ge(h.dn * R::splat(S(27)), R::splat(S(1.0 - 1e-4)));
+    const typename R::mask rank1 = R::le(h.cfn, R::splat(S(1e-12)));
+    return refl | rank1;
+}
+
 template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::mask quat_rotation_core(const T (&m)[9], T f, typename Tr<T>::mask in_window, T (&r)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
@@ -589,13 +635,9 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     k.a01 = m[7] - m[5]; k.a02 = m[2] - m[6]; k.a03 = m[3] - m[1];
     k.a12 = m[1] + m[3]; k.a13 = m[2] + m[6]; k.a23 = m[5] + m[7];
     // 3. the characteristic quartic  l^4 + c2 l^2 + c1 l + c0
-    const T g00 = R::fma(m[4], m[8], -(m[5] * m[7])), g01 = R::fma(m[5], m[6], -(m[3] * m[8])), g02 = R::fma(m[3], m[7], -(m[4] * m[6]));
-    const T g10 = R::fma(m[2], m[7], -(m[1] * m[8])), g11 = R::fma(m[0], m[8], -(m[2] * m[6])), g12 = R::fma(m[1], m[6], -(m[0] * m[7]));
-    const T g20 = R::fma(m[1], m[5], -(m[2] * m[4])), g21 = R::fma(m[2], m[3], -(m[0] * m[5])), g22 = R::fma(m[0], m[4], -(m[1] * m[3]));
-    const T det = R::fma(m[2], g02, R::fma(m[1], g01, m[0] * g00));
-    T cf = g00 * g00;
-    cf = R::fma(g01, g01, cf); cf = R::fma(g02, g02, cf); cf = R::fma(g10, g10, cf); cf = R::fma(g11, g11, cf);
-    cf = R::fma(g12, g12, cf); cf = R::fma(g20, g20, cf); cf = R::fma(g21, g21, cf); cf = R::fma(g22, g22, cf);
+    const CubicHead<T> head = cubic_head<T>(m, f);
+    const T det = head.det, cf = head.cf;
+    const typename R::mask usable = in_window & R::mnot(invariant_hard<T>(head));   // judged here and folded into the window's mask: nothing more stays alive
     const T c2 = f * R::splat(S(-2)), c1 = det * R::splat(S(-8)), c0 = R::fma(f, f, cf * R::splat(S(-4)));
     const T twoc2 = c2 + c2;
     // 4. lambda_max = s1 + s2 + s3'.  Start: the squared singular values are the roots of  mu^3 - f mu^2 + cf mu - det^2,
@@ -607,13 +649,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // step for the same roots: 68 packed instructions and 20 transcendentals against 40 and 26.)
     T lam;
     {
-        // in units of f (mu / f in [0, 1]): no power of the entries beyond f^2 is formed
-        const T inv_f = R::rcp(f);
-        const T di = det * inv_f;
-        const T cfn = (cf * inv_f) * inv_f, dn = (di * di) * inv_f;                               // cf / f^2,  det^2 / f^3
-        const T p = R::max(R::fma(cfn, R::splat(S(-1.0 / 3.0)), R::splat(S(1.0 / 9.0))), R::splat(S(1e-12)));
-        const T q = R::fma(dn, R::splat(S(0.5)), R::fma(cfn, R::splat(S(-1.0 / 6.0)), R::splat(S(1.0 / 27.0))));
-        const T x = R::clamp(q * R::rsq((p * p) * p), R::splat(S(-1)), R::splat(S(1)));
+        const T p = head.p, x = head.x;
         const T ax = R::abs(x);
         T poly = R::fma(ax, R::splat(S(-0.0187293)), R::splat(S(0.0742610)));
         poly = R::fma(poly, ax, R::splat(S(-0.2121144)));
@@ -650,7 +686,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
         const T l2 = lam * lam;
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
         early_hard = R::mnot(R::gt(dp, (l2 * lam) * R::splat(S(0.25f * kQuatTau2)))
-                             & R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(0.25f * kQuatCurv))) & in_window);
+                             & R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(0.25f * kQuatCurv))) & usable);
         if (SKIP && __builtin_expect(!wave_any(R::any(R::mnot(early_hard))), 0)) return early_hard;      // r is not used for hard rows
     }
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
@@ -712,7 +748,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
     r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    return R::mnot(settled & finite & in_window) | early_hard;
+    return R::mnot(settled & finite) | early_hard;                  // (early_hard holds the rows outside the window and the invariant-hard ones)
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
@@ -749,6 +785,19 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     for (int i = 1; i < 9; ++i) f2 = R::fma(m[i], m[i], f2);
     const typename R::mask inside2 = R::ge(f2, R::splat(S(kQuatWindowLo))) & R::le(f2, R::splat(S(kQuatWindowHi)));
     return quat_rotation_core<T, SKIP>(m, f2, inside2, r);
+}
+
+// Does the wave hold nothing but rows that are hard by their invariants (and inside the scale window, where the core would
+// judge them on the same bits)?  Wave-uniform; 60 instructions instead of the fast path's 420.
+template <class T> __device__ __forceinline__ bool all_rows_invariant_hard(const T (&m)[9]) {
+    typedef Tr<T> R;
+    typedef typename R::scalar S;
+    T f = m[0] * m[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
+    const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
+    const typename R::mask sure = inside & invariant_hard<T>(cubic_head<T>(m, f));
+    return !wave_any(R::any(R::mnot(sure)));
 }
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.

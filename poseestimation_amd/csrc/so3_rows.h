@@ -49,6 +49,15 @@ constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data
 constexpr int kLoadCpol = SO3_LOAD_CPOL, kStoreCpol = SO3_STORE_CPOL;
 constexpr int kStreamNt = 2;                     // the cloud kernels' once-read points
 
+// The lane number, recomputed (v_mbcnt in a volatile asm, which is not hoisted): for the rare paths of the engine's operations.  Their address
+// arithmetic is loop-invariant; built on the loop's own lane register it was hoisted out of the loop and occupied registers of
+// the hot path (K1 at three waves per SIMD: spills).
+__device__ __forceinline__ int lane_id_now() {
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
+
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -233,8 +242,10 @@ template <int NPL> struct RowCtx {
     double acc;             // per-lane float64 partial of the operation's reduction
     bool flag;              // per-lane sticky flag (K4: cosine out of range)
     const char *img1;       // LDS image of the second input's block (operations with kLateIn1 read their rows from it themselves)
+    char *slot;             // the wave's LDS slot: free between take_rows and put_rows (the inputs have left, the outputs are not staged yet)
     char *scratch;          // the wave's Op::kWaveScratch bytes of LDS, kept across its rounds (K1: the queue of hard rows)
     int pending;            // wave-uniform state that goes with it (K1: how many rows the queue holds)
+    int dense;              // wave-uniform (K1): 1 = the wave's last round was dense in hard rows, 2 = so were earlier ones and the shortcut was refused
 };
 
 #ifndef SO3_HOST_MODEL
@@ -298,8 +309,10 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.acc = 0.0;
     ctx.flag = false;
     ctx.img1 = nullptr;
+    ctx.slot = nullptr;
     ctx.scratch = scratch[wave_in_block];
     ctx.pending = 0;
+    ctx.dense = 0;
     if (t < nrounds) {
         auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
             const int64_t left = nunits - tr * NPL;
@@ -348,6 +361,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         {
             char *slot = lds[wave_in_block];
             ctx.img1 = slot + kIn0B;
+            ctx.slot = slot;
             // One round is in flight in registers behind the round that sits in LDS.
             f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
             auto issue = [&](int64_t tr) {                  // past the last round the descriptors are empty: the loads
@@ -469,16 +483,16 @@ template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     static constexpr int kQueueWords = 11;                                  // 9 entries + the row number (two dwords)
-    static constexpr int kWaveScratch = kQueueWords * 128 * 4;              // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
+    // (the instantiation that also writes flip flags has no registers to spare for any of this at three waves per SIMD: every round that
+    // holds a hard row takes the Jacobi path on the spot there, as in round 2)
+    static constexpr int kWaveScratch = FLIP ? 0 : kQueueWords * 128 * 4;   // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
     uint8_t *flip = nullptr;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
         const T (&m)[9] = rows.a;
         T (&r)[9] = rows.o0;
-        const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
-        if (__builtin_expect(wave_any(R::any(hard)), 0)) defer<T, NPL>(ctx, m, r, hard);
-        if (FLIP) {
+        if (FLIP) {                                          // the flags first: their temporaries are gone before the projection's peak
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 float mk_[9];
@@ -488,10 +502,40 @@ struct OpProject : OpBase {
                 __builtin_amdgcn_raw_buffer_store_b8(bit, row_rsrc<1>(flip, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane, 0, 0);
             }
         }
+        // After a round dense in hard rows the next one is asked first whether ALL its rows are hard by their invariants alone
+        // (a batch of reflections, ties or rank-one rows): then it takes the Jacobi path without running the fast path at all.
+        if constexpr (FLIP) {
+            project_rotation<T, false>(m, r);
+        } else if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
+            rotation_from(signed_svd<false, T>(m), r);
+        } else {
+            const int asked = ctx.dense;                 // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
+            const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
+            ctx.dense = 0;
+            if (__builtin_expect(wave_any(R::any(hard)), 0) && defer<T, NPL>(ctx, m, hard, asked)) {
+                // a round dense in hard rows (or a full queue): the Jacobi path here, on the round itself, as before round 3's queue --
+                // queued, such rows would be stored twice, the second time 4 bytes per lane and store.  The fast path's rotations wait
+                // in the wave's LDS slot meanwhile (the round's inputs have left it, its outputs are not staged yet): 18 registers
+                // that the Jacobi path's peak would otherwise sit on top of.
+                typedef UnitIO<4, 9, NPL> Stash;
+                const int lane = lane_id_now();
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) Stash::write_row(ctx.slot, k, lane, k, r);
+                wave_lds_fence();                                // (also keeps the compiler from forwarding the stores to the loads below)
+                T rj[9];
+                rotation_from(signed_svd<false, T>(m), rj);
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) Stash::read_row(ctx.slot, k, lane, k, r);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) r[j] = R::sel(hard, rj[j], r[j]);
+            }
+        }
     }
-    // queue the round's hard rows (the block store writes whatever the fast path left for them; flush() overwrites it)
+    // queue the round's hard rows (the block store writes whatever the fast path left for them; flush() overwrites it); true if
+    // the round has to take the Jacobi path on the spot instead
     template <class T, int NPL>
-    __device__ __forceinline__ void defer(RowCtx<NPL> &ctx, const T (&m)[9], T (&r)[9], typename Tr<T>::mask hard) const {
+    __device__ __forceinline__ bool defer(RowCtx<NPL> &ctx, const T (&m)[9], typename Tr<T>::mask hard, int asked) const {
         unsigned long long votes[NPL];
         int n = 0;
 #pragma unroll
@@ -499,15 +543,9 @@ struct OpProject : OpBase {
             votes[k] = __builtin_amdgcn_ballot_w64(Tr<T>::lane_of(hard, k) && ctx.exists[k]);
             n += __builtin_popcountll(votes[k]);
         }
-        if (n > 16 * NPL || ctx.pending + n > 64 * NPL) {
-            // a round dense in hard rows (or a full queue): the Jacobi path here, on the round itself, as before round 3's queue --
-            // queued, such rows would be stored twice, the second time 4 bytes per lane and store
-            T rj[9];
-            rotation_from(signed_svd<false, T>(m), rj);
-#pragma unroll
-            for (int j = 0; j < 9; ++j) r[j] = Tr<T>::sel(hard, rj[j], r[j]);
-            return;
-        }
+        ctx.dense = n > 16 * NPL ? (asked != 0 ? 2 : 1) : 0;
+        if (n > 16 * NPL || ctx.pending + n > 64 * NPL) return true;
+        const int lane = lane_id_now();
         float *q = reinterpret_cast<float *>(ctx.scratch);
         int at = ctx.pending;
 #pragma unroll
@@ -517,18 +555,20 @@ struct OpProject : OpBase {
                 const int e = at + static_cast<int>(__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)));
 #pragma unroll
                 for (int i = 0; i < 9; ++i) q[128 * i + e] = Tr<T>::get(m[i], k);
-                const long long row = ctx.unit[k] * kUnitRows + ctx.lane;
+                const long long row = ctx.unit[k] * kUnitRows + lane;
                 q[128 * 9 + e] = __int_as_float(static_cast<int>(row & 0xffffffffll));
                 q[128 * 10 + e] = __int_as_float(static_cast<int>(row >> 32));
             }
             at += __builtin_popcountll(votes[k]);
         }
         ctx.pending = at;
+        return false;
     }
     // the Jacobi path on everything the queue holds; lane l takes entries l and (NPL = 2) 64 + l
     template <class T, int NPL>
     __device__ __forceinline__ void flush(RowCtx<NPL> &ctx) const {
         wave_lds_fence();
+        const int lane = lane_id_now();
         const float *q = reinterpret_cast<const float *>(ctx.scratch);
         const int count = ctx.pending;
         T m[9];
@@ -536,7 +576,7 @@ struct OpProject : OpBase {
         bool valid[NPL];
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            const int e = 64 * k + ctx.lane;
+            const int e = 64 * k + lane;
             valid[k] = e < count;
             const int src = valid[k] ? e : 0;                   // an empty slot works on entry 0 (there is one); its result is dropped
 #pragma unroll
