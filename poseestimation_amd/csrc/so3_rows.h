@@ -40,13 +40,8 @@ constexpr int kUnitRows = 64;
 constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data format
 // Cache policy of the streamed accesses (each byte is touched once): aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1.
 // A plain 36 MB -> 36 MB copy: 14.8 us with the default policy, 13.1 us nt (tools/ubench/copy_ceiling.hip).
-#ifndef SO3_LOAD_CPOL
-#define SO3_LOAD_CPOL 2
-#endif
-#ifndef SO3_STORE_CPOL
-#define SO3_STORE_CPOL 2
-#endif
-constexpr int kLoadCpol = SO3_LOAD_CPOL, kStoreCpol = SO3_STORE_CPOL;
+// (default, sc0, sc1 and their combinations were swept on one device in round 3: nt / nt stays, profiles/r03_k1_engine_experiments.txt)
+constexpr int kLoadCpol = 2, kStoreCpol = 2;
 constexpr int kStreamNt = 2;                     // the cloud kernels' once-read points
 
 // The lane number, recomputed (v_mbcnt in a volatile asm, which is not hoisted): for the rare paths of the engine's operations.  Their address
