@@ -339,6 +339,64 @@ def test_deferred_hard_rows_are_the_rows_the_tile_kernel_gives(rr, bf16):
     assert (torch.linalg.det(r3) - 1).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("plan", [("sparse", "reflection", "reflection", "ties", "sparse"), ("rank one", "rank one", "sparse", "sparse", "reflection"),
+                                  ("crowded", "crowded", "crowded", "crowded", "crowded"), ("ties", "ties", "reflection", "reflection", "zero"),
+                                  ("zero", "zero", "rank one", "mixed", "mixed")])
+def test_hard_row_queue_over_the_rounds_of_a_wave(rr, plan):
+    """What K1's engine does with hard rows depends on what the WAVE met before: its queue fills over its rounds (and a round it
+    has no room for takes the Jacobi path on the spot), a round after a dense one is asked whether all its rows are hard by their
+    invariants (reflections, rank one: yes, no fast path; ties: no, and the wave does not ask again).  The result may not: five
+    passes of the grid (wave w takes rounds w, w + 3072, ...), each pass of its own kind, every row bit for bit against the
+    one-row-per-thread kernel."""
+    from poseestimation_amd import _lib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
+    hr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hr)
+    lib = _lib.load()
+    d = torch.device(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(sum(len(k) * (i + 1) for i, k in enumerate(plan)))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    waves = cus * 4 * 3                                                     # K1: three waves per SIMD, 128 rows per wave and round
+    per_pass = waves * 128
+    n = per_pass * len(plan) + 64 * 3 + 11                                # + an odd tail of units + a remainder for the tile kernel
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    families = ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one", "all zero")
+
+    def fill(lo, hi, kind):
+        if kind in ("sparse", "crowded", "mixed"):
+            share = {"sparse": 0.05, "crowded": 0.22, "mixed": 0.5}[kind]   # 0.22: ~28 of a round's 128 rows -- queued, until the queue is full
+            pick = torch.nonzero(torch.rand(hi - lo, device=DEV, generator=gen) < share).flatten() + lo
+            for f, name in enumerate(families):
+                idx = pick[f::len(families)]
+                if idx.numel():
+                    x[idx] = hr.family(name, idx.numel(), d, gen).reshape(-1, 9)
+        else:
+            name = {"reflection": "near-reflection", "ties": "generic ties", "rank one": "rank one", "zero": "all zero"}[kind]
+            x[lo:hi] = hr.family(name, hi - lo, d, gen).reshape(-1, 9)
+
+    for p_, kind in enumerate(plan):
+        fill(p_ * per_pass, (p_ + 1) * per_pass, kind)
+    fill(per_pass * len(plan), n, "mixed")
+    st = torch.cuda.current_stream().cuda_stream
+    ref = torch.empty(n, 9, device=DEV)
+    hard = torch.empty(n, dtype=torch.uint8, device=DEV)
+    assert lib.so3_project_fwd_diag_f32(x.data_ptr(), ref.data_ptr(), hard.data_ptr(), n, st) == 0
+    out = torch.full((n * 9 + 8,), 7.0, device=DEV)
+    r = out[4:4 + n * 9].view(n, 9)
+    assert lib.so3_project_fwd_f32(x.data_ptr(), r.data_ptr(), None, n, st) == 0
+    bad = (r != ref).any(dim=1)
+    assert not bool(bad.any()), (plan, int(bad.sum().item()), torch.nonzero(bad).flatten()[:8].tolist(), int(hard.sum().item()))
+    assert (out[:4] == 7).all() and (out[4 + n * 9:] == 7).all()
+    # the passes are what they are meant to be: every row of a reflection / rank-one / zero pass is hard, a sparse one has a few per cent
+    for p_, kind in enumerate(plan):
+        share = hard[p_ * per_pass:(p_ + 1) * per_pass].float().mean().item()
+        if kind in ("reflection", "rank one", "zero", "ties"):
+            assert share > 0.999, (kind, share)
+        elif kind == "sparse":
+            assert 0.01 < share < 0.06, (kind, share)
+
+
 def test_device_rows_match_the_host_model_of_the_same_templates(rr):
     """csrc/so3_device.h compiled for the host (oracle/kernel_model.cpp) against the device: same algorithm, the only
     difference being 1-ulp v_rsq/v_sqrt/v_rcp versus correctly rounded libm."""
