@@ -637,7 +637,13 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // 3. the characteristic quartic  l^4 + c2 l^2 + c1 l + c0
     const CubicHead<T> head = cubic_head<T>(m, f);
     const T det = head.det, cf = head.cf;
-    const typename R::mask usable = in_window & R::mnot(invariant_hard<T>(head));   // judged here and folded into the window's mask: nothing more stays alive
+    // Rows that are hard whatever the steps below would say -- outside the scale window (zero, Inf, NaN) or hard by their invariants --
+    // are judged here and folded into one mask: a per-row rule, so a row's result does not depend on its wave-mates.  A wave in which
+    // EVERY row is such a row (SKIP) leaves for the Jacobi path at once: a batch of zeros (a dead head) costs K3 1.05 x a Gaussian
+    // one instead of 1.34 x.  (K1's engine kernel asks the same question in front of the fast path, OpProject; inside it, the second
+    // way out costs 20 registers that kernel does not have at three waves per SIMD.)
+    const typename R::mask usable = in_window & R::mnot(invariant_hard<T>(head));
+    if (SKIP && __builtin_expect(!wave_any(R::any(usable)), 0)) return R::mnot(usable);      // r is not used for hard rows
     const T c2 = f * R::splat(S(-2)), c1 = det * R::splat(S(-8)), c0 = R::fma(f, f, cf * R::splat(S(-4)));
     const T twoc2 = c2 + c2;
     // 4. lambda_max = s1 + s2 + s3'.  Start: the squared singular values are the roots of  mu^3 - f mu^2 + cf mu - det^2,
@@ -671,23 +677,6 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
         const T p = R::fma(R::fma(l2 + c2, lam, c1), lam, c0);
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
         lam = R::fma(-p, R::rcp(dp), lam);
-    }
-    // 4b. Rows that no eigenvector will settle, known from the quartic alone: P'(lambda) = (l1 - l2)(l1 - l3)(l1 - l4) is the gap
-    // product the adjugate's trace measures in step 6, P''(lambda) the curvature criterion (4) asks for.  A row that misses a
-    // quarter of either bar at Newton's lambda (half of what `hopeless` asks below at the Rayleigh quotient), or lies outside the
-    // scale window (zero, Inf, NaN), is HARD whatever steps 5-7 would say -- a per-row rule, so its result does not depend on its
-    // wave-mates; none in 2e7 Gaussian rows -- and a wave in which EVERY row is leaves here for the Jacobi path without paying
-    // for eigenvectors it would discard: a batch of zeros (a dead head) 15.3 us per 1M rows instead of 19.7.  (Batches of
-    // near-reflections or rank-one rows do not profit: Newton's lambda is still far from a multiple root on 2-7 % of such rows,
-    // so some row of nearly every wave only shows its hand in step 6.  SKIP: the instantiation that also writes flip flags has no
-    // registers to spare for the second way out.)
-    typename R::mask early_hard;
-    {
-        const T l2 = lam * lam;
-        const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
-        early_hard = R::mnot(R::gt(dp, (l2 * lam) * R::splat(S(0.25f * kQuatTau2)))
-                             & R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(0.25f * kQuatCurv))) & usable);
-        if (SKIP && __builtin_expect(!wave_any(R::any(R::mnot(early_hard))), 0)) return early_hard;      // r is not used for hard rows
     }
     // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
     // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
@@ -748,7 +737,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
     r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
-    return R::mnot(settled & finite) | early_hard;                  // (early_hard holds the rows outside the window and the invariant-hard ones)
+    return R::mnot(settled & finite & usable);
 }
 
 // r = the rotation nearest to m_in (fast path); returns the mask of HARD rows, whose r must not be used.
