@@ -478,9 +478,7 @@ template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
     static constexpr int kQueueWords = 11;                                  // 9 entries + the row number (two dwords)
-    // (the instantiation that also writes flip flags has no registers to spare for any of this at three waves per SIMD: every round that
-    // holds a hard row takes the Jacobi path on the spot there, as in round 2)
-    static constexpr int kWaveScratch = FLIP ? 0 : kQueueWords * 128 * 4;   // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
+    static constexpr int kWaveScratch = kQueueWords * 128 * 4;   // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
     uint8_t *flip = nullptr;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
@@ -499,9 +497,7 @@ struct OpProject : OpBase {
         }
         // After a round dense in hard rows the next one is asked first whether ALL its rows are hard by their invariants alone
         // (a batch of reflections, ties or rank-one rows): then it takes the Jacobi path without running the fast path at all.
-        if constexpr (FLIP) {
-            project_rotation<T, false>(m, r);
-        } else if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
+        if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
             rotation_from(signed_svd<false, T>(m), r);
         } else {
             const int asked = ctx.dense;                 // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
