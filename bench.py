@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the SVD -> SO(3) hot path on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1: starts its N ranks itself, one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -23,8 +23,115 @@ import argparse
 import ctypes
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
+
+
+# ---- `python bench.py --gpus N` without an outer launcher ----------------------------------------------------------------
+# The reference's only multi-process script starts its ranks itself (3D-Pose/main_DDP.py:112-116, mp.spawn(world_size=2)); so does
+# this one.  With N > 1 and no WORLD_SIZE in the environment the process that was started is only a LAUNCHER: it starts N fresh
+# children of this very script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what
+# torch.distributed.run would have set), relays rank 0's one JSON line, and exits non-zero as soon as any child does (ending the
+# others).  It runs BEFORE torch is even imported: the launcher makes no HIP call of any kind, and children are started with
+# subprocess (fork + exec of a process that never touched the GPU), never by replacing a process that did.
+def _child_dies_with_parent():
+    """preexec hook: SIGKILL to the child when the launcher dies (prctl(PR_SET_PDEATHSIG)), so that not even a SIGKILLed
+    launcher leaves ranks behind."""
+    try:
+        import ctypes as ct
+        ct.CDLL(None, use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)
+    except Exception:
+        pass
+
+
+def launch_ranks(n: int, argv, child_cmd=None, grace_s: float = 5.0, out=None) -> int:
+    """Start n ranks of `child_cmd + argv` (default: this script under the same interpreter), wait for them, relay rank 0's
+    stdout to `out` (default: this process' stdout) when all have ended well.  Returns the exit code: 0, or the first failing
+    child's (negative signals as 128 + signal); on a failure -- or on SIGTERM / SIGINT to the launcher -- the remaining children
+    get SIGTERM and, `grace_s` later, SIGKILL.  SO3_BENCH_SHARE_DEVICE=1 gives every child LOCAL_RANK 0 (the one-GPU test box)."""
+    cmd = list(child_cmd) if child_cmd is not None else [sys.executable, os.path.abspath(__file__)]
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    share = os.environ.get("SO3_BENCH_SHARE_DEVICE") == "1"
+    procs = []
+
+    def end_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):
+        end_all(signal.SIGTERM)
+        raise SystemExit(128 + signum)
+
+    old = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT)}
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SO3_BENCH_LAUNCHED="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # rank 0's stdout is the job's one line; the other ranks print nothing there (whatever a library writes goes to stderr)
+            procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                                          stderr=None, preexec_fn=_child_dies_with_parent))
+        line = b""
+        import select
+        fd0 = procs[0].stdout
+        while True:
+            if fd0 is not None:                                  # drain rank 0's pipe while waiting (never block on a full pipe)
+                ready, _, _ = select.select([fd0], [], [], 0.05)
+                if ready:
+                    chunk = os.read(fd0.fileno(), 65536)
+                    if chunk:
+                        line += chunk
+                    else:
+                        fd0 = None
+            else:
+                time.sleep(0.05)
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 128 - bad[0]
+                break
+            if all(c == 0 for c in codes) and fd0 is None:
+                break
+        if rc != 0:
+            end_all(signal.SIGTERM)
+            deadline = time.time() + grace_s
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.05)
+            end_all(signal.SIGKILL)
+            for p in procs:
+                p.wait()
+            print("[bench] a rank ended with exit code %d; the others were stopped" % rc, file=sys.stderr)
+        else:
+            dst = out if out is not None else sys.stdout
+            dst.write(line.decode())
+            dst.flush()
+    finally:
+        end_all(signal.SIGKILL)
+        for s, h in old.items():
+            signal.signal(s, h)
+    return rc
+
+
+def _self_launch_if_needed(argv) -> None:
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--gpus", type=int, default=1)
+    known, _ = ap.parse_known_args(argv)
+    if known.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(known.gpus, argv))
+
+
+if __name__ == "__main__":
+    _self_launch_if_needed(sys.argv[1:])          # before torch is imported: the launcher never touches HIP
 
 import numpy as np
 import torch
@@ -306,10 +413,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched through torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    if world != args.gpus:                  # under an outer launcher the environment is authoritative (python bench.py --gpus N with
+        args.gpus = world                   # no WORLD_SIZE never gets here: _self_launch_if_needed started N ranks of its own)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)

@@ -95,6 +95,25 @@ def test_bench_with_two_ranks_sharing_the_device():
     assert "cpu_baseline" not in d and "secondary" not in d         # rank 0 at N = 1 only
 
 
+def test_bench_gpus_2_starts_its_own_ranks():
+    """Exactly the driver's spelling -- `python bench.py --gpus 2 --steps 30 --warmup 3 --rows 500000` -- with NO rank variables in
+    the environment: the entry is a launcher that starts two fresh ranks of itself before it touches HIP (bench.launch_ranks;
+    3D-Pose/main_DDP.py:112-116 spawns its ranks the same way), relays rank 0's one line and returns 0.  On this one-GPU box both
+    ranks are mapped onto cuda:0 (SO3_BENCH_SHARE_DEVICE) and the process group is gloo (RCCL refuses two ranks on one device)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SO3_BENCH_BACKEND="gloo", SO3_BENCH_SHARE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--rows", "500000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["rows_per_gpu"] == 500_000 and d["config"]["global_rows"] == 1_000_000
+    assert abs(d["value"] - 1_000_000 * 30 / (d["ms_per_step"] * 30 * 1e-3)) / d["value"] < 1e-9
+    assert 120.0 < d["mean_angle_error_deg"] < 133.0
+
+
 def test_bench_config5_shape_on_one_rank():
     """--config 5 = BASELINE configs[4]: 2M rows per GPU (16M over 8), rank r seeded with r; one rank of it fits here."""
     d = _run_bench("--config", "5", "--no-cpu-baseline", "--no-secondary")

@@ -1,0 +1,131 @@
+"""`python bench.py --gpus N` without an outer launcher (bench.launch_ranks), on the CPU: the launcher starts N fresh children
+with the rank variables set, relays rank 0's one line, and when a child dies it ends the others and returns non-zero -- no
+orphans.  Replaces 3D-Pose/main_DDP.py:112-116 (mp.spawn(world_size=2)).  The GPU half is in tests/test_bench_contract.py."""
+import json
+import os
+import signal
+import subprocess
+import sys
+import time
+
+from conftest import ROOT
+
+_CHILD_OK = r"""
+import json, os, sys
+d = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+open(os.path.join(sys.argv[1], "rank%s.json" % d["RANK"]), "w").write(json.dumps(d))
+if d["RANK"] == "0":
+    print(json.dumps({"n_gpus": int(d["WORLD_SIZE"]), "argv": sys.argv[2:]}))
+else:
+    print("noise from rank", d["RANK"])          # must not reach the launcher's stdout
+"""
+
+_CHILD_SLEEP = r"""
+import os, sys, time
+open(os.path.join(sys.argv[1], "rank%s.pid" % os.environ["RANK"]), "w").write(str(os.getpid()))
+time.sleep(120)
+"""
+
+
+def _launcher(n, child, argv, env=None):
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.launch_ranks(%d, %r, child_cmd=[sys.executable, '-c', %r], grace_s=1.0))" % (ROOT, n, list(argv), child))
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                            env=env if env is not None else {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+
+
+def _alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                            # a zombie still answers kill(0): look at its state
+        with open("/proc/%d/stat" % pid) as fh:
+            return fh.read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_launcher_sets_the_rank_variables_and_relays_rank0_only(tmp_path):
+    p = _launcher(3, _CHILD_OK, [str(tmp_path), "--steps", "7"])
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                                        # rank 0's line, nothing from the others
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["argv"] == ["--steps", "7"]
+    envs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert all(e["WORLD_SIZE"] == "3" and e["MASTER_ADDR"] == "127.0.0.1" for e in envs)
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and int(envs[0]["MASTER_PORT"]) > 0
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for e in envs)      # dmabuf IPC only on this pool
+
+
+def test_share_device_knob_maps_every_rank_to_local_rank_zero(tmp_path):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["SO3_BENCH_SHARE_DEVICE"] = "1"
+    p = _launcher(2, _CHILD_OK, [str(tmp_path)], env=env)
+    out, err = p.communicate(timeout=120)
+    assert p.returncode == 0, err[-2000:]
+    assert [json.load(open(tmp_path / ("rank%d.json" % r)))["LOCAL_RANK"] for r in range(2)] == ["0", "0"]
+
+
+def _wait_for(paths, timeout=60.0):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        if all(os.path.exists(p) and os.path.getsize(p) > 0 for p in paths):
+            return
+        time.sleep(0.05)
+    raise AssertionError("children did not start: %s" % (paths,))
+
+
+def test_a_dead_rank_ends_the_job_nonzero_and_leaves_no_orphan(tmp_path):
+    p = _launcher(2, _CHILD_SLEEP, [str(tmp_path)])
+    pidfiles = [str(tmp_path / ("rank%d.pid" % r)) for r in range(2)]
+    _wait_for(pidfiles)
+    pids = [int(open(f).read()) for f in pidfiles]
+    os.kill(pids[1], signal.SIGKILL)                                     # rank 1 dies
+    out, err = p.communicate(timeout=60)
+    assert p.returncode != 0 and out.strip() == "", (p.returncode, out)
+    assert "exit code" in err
+    time.sleep(0.2)
+    assert not _alive(pids[0]) and not _alive(pids[1])                    # rank 0 was stopped: nothing left behind
+
+
+def test_a_killed_launcher_takes_its_ranks_with_it(tmp_path):
+    p = _launcher(2, _CHILD_SLEEP, [str(tmp_path)])
+    pidfiles = [str(tmp_path / ("rank%d.pid" % r)) for r in range(2)]
+    _wait_for(pidfiles)
+    pids = [int(open(f).read()) for f in pidfiles]
+    p.send_signal(signal.SIGTERM)
+    p.communicate(timeout=60)
+    assert p.returncode != 0
+    time.sleep(0.5)
+    assert not any(_alive(q) for q in pids)
+
+
+def test_a_sigkilled_launcher_still_leaves_no_ranks(tmp_path):
+    """A launcher that cannot run any handler: its children carry PR_SET_PDEATHSIG."""
+    p = _launcher(2, _CHILD_SLEEP, [str(tmp_path)])
+    pidfiles = [str(tmp_path / ("rank%d.pid" % r)) for r in range(2)]
+    _wait_for(pidfiles)
+    pids = [int(open(f).read()) for f in pidfiles]
+    p.kill()
+    p.communicate(timeout=60)
+    time.sleep(0.5)
+    assert not any(_alive(q) for q in pids)
+
+
+def test_bench_entry_with_gpus_2_and_no_rank_variables_starts_ranks_itself():
+    """The driver's own spelling, `python bench.py --gpus 2 ...`, with no rank variables: here (no GPU) both ranks stop at the
+    'needs an MI355X' check -- which proves the entry started ranks (RANK 0 and 1 each say so) instead of refusing, and that a
+    failing rank makes the job's exit code non-zero."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the entry (the GPU run is tests/test_bench_contract.py)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "needs an MI355X" in out.stderr and "must be launched through" not in out.stderr
