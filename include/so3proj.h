@@ -76,86 +76,82 @@ int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, voi
 int so3_project_fwd_f64(const double *M, double *R, uint8_t *flip, int64_t B, void *stream);
 int so3_project_bwd_f64(const double *M, const double *G, double *dM, int64_t B, void *stream);
 
+/* ---- the reducing entry points: K3, K3', K4, K1+K4 ----------------------------------------------------------------
+ * Each reduces over the batch (loss_sum; sum_count, range_flag) and exists ONCE; how the reduction is finished is chosen by
+ * `workspace` and `flags` (round 3 exported three spellings of each -- plain, _ws, _acc; they are inline wrappers at the end of
+ * this header now):
+ *   workspace  NULL, or so3_reduce_workspace_bytes() bytes of device memory owned by the caller, ZERO-FILLED ONCE before its
+ *              first use (every call leaves it zeroed), used by ONE stream at a time.  With it every workgroup parks its
+ *              partial in a slot of its own and the last one to finish (a ticket) sums the slots in a fixed order and writes
+ *              the results with plain stores: one launch, and the same input gives the same bits whatever order the
+ *              workgroups retire in.  Without it the accumulators are zeroed by a memset / 1-thread launch in front of the
+ *              kernel (unless SO3_PREZEROED) and every workgroup adds to them with one atomic.  (Batches of <= 1024 rows run
+ *              as one workgroup and never touch it; input that cannot take the streaming engine -- e.g. a bfloat16 view
+ *              starting at an odd row -- falls back to the atomics path.)
+ *   flags      SO3_RADIANS    angles in radians (default: degrees)                                        [K4, K1+K4]
+ *              SO3_PREZEROED  the caller guarantees loss_sum[0] / sum_count[0] / *range_flag are 0 on entry (e.g. fresh slots
+ *                             of a zero-filled pool): no init launch, the kernels add to them as they are and one workgroup
+ *                             stores the row count into sum_count[1]
+ *              SO3_EXACT_F64  K1+K4's sum without per-row angles: the reference's float64 arithmetic on EVERY row (default:
+ *                             float32 trace and acos for rows whose cosine is at least 5e-7 away from +-1, float64 inside
+ *                             that band; see so3_project_angle_error_v2_f32)
+ */
+#define SO3_RADIANS 0x1u
+#define SO3_PREZEROED 0x2u
+#define SO3_EXACT_F64 0x4u
+size_t so3_reduce_workspace_bytes(void);
+
 /* ---- K3: fused head forward + Frobenius loss + backward (config #4) ------------------------------
  * loss = mean_b ||Rtrue_b - R_b||_F  (3D-Pose/loss.py:7-11; NOT squared),  dM = dloss/dM.
  * Replaces the chain 3D-Pose/main.py:60 (head), :85 (loss), :90 (backward) in one launch.
- *   M        in   B*9 (f32 / bf16)
- *   Rtrue    in   B*9 float32
- *   R        out  optional B*9 float32
- *   dM       out  optional B*9 (f32 / bf16): d(mean loss)/dM, i.e. already divided by B
- *   loss_sum out  1 double: sum_b ||Rtrue_b - R_b||_F (the caller divides by B).  Zeroed by the
- *                 call itself (hipMemsetAsync on `stream`) before the kernel accumulates into it.
+ *   M         in   B*9 (f32 / bf16)
+ *   Rtrue     in   B*9 float32
+ *   R         out  optional B*9 float32
+ *   dM        out  optional B*9 (f32 / bf16): d(mean loss)/dM, i.e. already divided by B
+ *   loss_sum  out  1 double: sum_b ||Rtrue_b - R_b||_F (may be NULL for B <= 1024 when loss_mean is given)
+ *   loss_mean out  optional 1 float: (float)(loss_sum / B) -- what loss_frobenius returns (3D-Pose/loss.py:11), so the host
+ *                  side needs no launch of its own to turn the float64 sum into the float32 mean
  * A row whose difference is exactly zero contributes zero gradient (the reference gives NaN).
  */
-int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum,
-                         int64_t B, void *stream);
-int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum,
-                          int64_t B, void *stream);
+int so3_frob_fwd_bwd_v2_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
+                            void *workspace, unsigned flags, int64_t B, void *stream);
+int so3_frob_fwd_bwd_v2_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean,
+                             void *workspace, unsigned flags, int64_t B, void *stream);
 
-/* Stand-alone Frobenius loss for a caller that already holds R_pred (3D-Pose/loss.py:7-11; copies at
+/* K3': stand-alone Frobenius loss for a caller that already holds R_pred (3D-Pose/loss.py:7-11; copies at
  * Comparison/main.py:12-16, UPNA/main.py:27-31, Iterative/loss.py:4-7):
- *   loss_sum out 1 double: sum_b ||Rtrue_b - Rpred_b||_F (zeroed by the call; the caller divides by B)
+ *   loss_sum out 1 double: sum_b ||Rtrue_b - Rpred_b||_F;  loss_mean out optional 1 float, as above
  *   dRpred   out optional B*9 float32: d(mean loss)/dRpred = (Rpred - Rtrue)/(B ||.||_F); d/dRtrue is its negative.
  */
-int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B,
-                      void *stream);
+int so3_frob_loss_v2_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean,
+                         void *workspace, unsigned flags, int64_t B, void *stream);
 
 /* ---- K4: geodesic angle error ----------------------------------------------------------------------
  * theta_b = acos(clamp((tr(R1_b^T R2_b) - 1)/2, -1, 1)) evaluated in float64 on float32 data.
  * Replaces rotation_representation.py:230-242 (angle_error; copies at Comparison/main.py:19-31,
  * Iterative/utility.py:35-47, ...).
- *   deg        out optional B doubles: angle in degrees (radians if `radians` != 0)
- *   sum_count  out optional 2 doubles: (sum_b theta_b, B), accumulated on the device; zeroed by the
- *                  call itself before the kernel runs.  This pair is what one RCCL all-reduce sums
- *                  across GPUs.
+ *   deg        out optional B doubles: angle in degrees (radians with SO3_RADIANS)
+ *   sum_count  out optional 2 doubles: (sum_b theta_b, B), accumulated on the device.  This pair is what one RCCL
+ *                  all-reduce sums across GPUs.
  *   range_flag out optional 1 int32: set to 1 if any cos is outside [-1.1, 1.1] -- the condition
- *                  on which the reference raises ValueError (:237-239); zeroed by the call itself.
+ *                  on which the reference raises ValueError (:237-239); 0 otherwise.
  */
-int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count,
-                    int32_t *range_flag, int radians, int64_t B, void *stream);
+int so3_angle_error_v2(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
+                       void *workspace, unsigned flags, int64_t B, void *stream);
 
 /* K1 + K4 fused: theta_b = angle(proj(M_b), Rtrue_b), R not materialised unless requested -- the evaluation step
  * `angle_error(func[rot_rep](out), R).mean()` of 3D-Pose/main.py:60-62,110-112 and UPNA/main.py:54-57 in one
- * launch reading 72 B per row.  deg / sum_count / range_flag / radians as in so3_angle_error; R optional
- * (required only when B is not a multiple of 64 or a pointer is not 16-byte aligned: the tail then runs as
- * K1 followed by K4 and needs the buffer). */
-int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                int32_t *range_flag, int radians, int64_t B, void *stream);
-
-/* ---- the same reductions with a caller-owned WORKSPACE and the mean written by the kernel ---------------------------
- * K3, K3', K4 and K1+K4 reduce over the batch (loss_sum, sum_count, range_flag).  The entry points above zero those
- * accumulators with a memset / 1-thread launch in front of the kernel and add to them with one atomic per workgroup.
- * With a workspace every workgroup parks its partial in a slot of its own, and the last one to finish (a ticket) sums the
- * slots in a fixed order and writes the results with plain stores: one launch less per call (1.5-2 us of a 15-30 us call at
- * 1M rows), and the same input gives the same bits whatever order the workgroups retire in.
- *   workspace  so3_reduce_workspace_bytes() bytes of device memory owned by the caller, ZERO-FILLED ONCE before its first
- *              use (every call leaves it zeroed), used by ONE stream at a time.  NULL selects the behaviour of the entry
- *              points above.  (Batches of <= 1024 rows run as one workgroup and never touch it; input that cannot take the
- *              streaming engine -- e.g. a bfloat16 view starting at an odd row -- falls back to the memset + atomics path.)
- *   loss_mean  out optional 1 float: (float)(loss_sum / B) -- what loss_frobenius returns (3D-Pose/loss.py:11), so the host
- *              side needs no launch of its own to turn the float64 sum into the float32 mean.  (so3_frob_fwd_bwd_ws_*: with it,
- *              loss_sum may be NULL for batches of <= 1024 rows.)
- * Everything else as in so3_frob_fwd_bwd_* / so3_frob_loss_f32 / so3_angle_error / so3_project_angle_error_f32. */
-size_t so3_reduce_workspace_bytes(void);
-int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
-                            void *workspace, int64_t B, void *stream);
-int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean,
-                             void *workspace, int64_t B, void *stream);
-int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean,
-                         void *workspace, int64_t B, void *stream);
-int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                       void *workspace, int64_t B, void *stream);
-int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                   int32_t *range_flag, int radians, void *workspace, int64_t B, void *stream);
-
-/* K4 / K1+K4 with accumulators the CALLER has zeroed: sum_count[0] and *range_flag must be 0 on entry (e.g. fresh slots of a
- * zero-filled pool -- one memset per few hundred calls instead of an init launch in front of every kernel); the kernels add to
- * them with one atomic per workgroup and one workgroup stores the row count into sum_count[1].  One launch per call: at 1M rows
- * 14.8 us instead of 16.3.  Everything else as in so3_angle_error / so3_project_angle_error_f32. */
-int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                        int64_t B, void *stream);
-int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                    int32_t *range_flag, int radians, int64_t B, void *stream);
+ * launch reading 72 B per row.  deg / sum_count / range_flag as in so3_angle_error_v2; R optional (required only when B is
+ * not a multiple of 64 or a pointer is not 16-byte aligned: the tail then runs as K1 followed by K4 and needs the buffer).
+ * Arithmetic of the metric: with `deg` every row's angle is the reference's float64 expression on the float32 rotation
+ * (1e-9 degrees against so3_angle_error_v2 on the materialised R).  The SUM ALONE (deg == NULL, batches above 1024 rows on the
+ * streaming engine) evaluates the same expression in float32 -- trace, cosine, acos -- for every row whose cosine is at least
+ * 5e-7 away from +-1, accumulates in float64, and runs the float64 expression for the rows inside that band (angles within
+ * 0.057 degrees of 0 or 180, where acos would amplify the float32 trace's round-off): a row then differs from its float64 angle
+ * by at most 2e-7 / sin(theta) rad, without bias; measured |difference of the means| 3e-8 degrees over 1M and 16M Haar pairs and
+ * <= 2e-6 degrees when every angle is 0.3 degrees (tests/test_gpu_parity.py).  SO3_EXACT_F64 selects float64 for every row. */
+int so3_project_angle_error_v2_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                   int32_t *range_flag, void *workspace, unsigned flags, int64_t B, void *stream);
 
 /* Diagnostic: K1 one row per thread (the same arithmetic, bit for bit, as so3_project_fwd_f32) plus, per row, the device's own
  * verdict: hard[b] = 1 where the quaternion fast path did not certify its result and the row was redone by the Jacobi path.
@@ -303,6 +299,60 @@ int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B
 int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream);
 int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t seed, float *R, float *H,
                          int64_t B, int32_t N, void *stream);
+
+/* ---- round-3 spellings of the reducing entry points, kept for one round as inline wrappers (not exported) -----------------
+ * plain: the call zeroes the accumulators itself; _ws: caller-owned workspace and the kernel-written mean; _acc: accumulators the
+ * caller has zeroed.  New code calls the *_v2 functions above. */
+#ifndef SO3_NO_LEGACY_WRAPPERS
+static inline int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
+    return so3_frob_fwd_bwd_v2_f32(M, Rtrue, R, dM, loss_sum, NULL, NULL, 0u, B, stream);
+}
+static inline int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
+    return so3_frob_fwd_bwd_v2_bf16(M, Rtrue, R, dM, loss_sum, NULL, NULL, 0u, B, stream);
+}
+static inline int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
+                                          void *workspace, int64_t B, void *stream) {
+    return so3_frob_fwd_bwd_v2_f32(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, 0u, B, stream);
+}
+static inline int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean,
+                                           void *workspace, int64_t B, void *stream) {
+    return so3_frob_fwd_bwd_v2_bf16(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, 0u, B, stream);
+}
+static inline int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
+    return so3_frob_loss_v2_f32(Rpred, Rtrue, dRpred, loss_sum, NULL, NULL, 0u, B, stream);
+}
+static inline int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean,
+                                       void *workspace, int64_t B, void *stream) {
+    return so3_frob_loss_v2_f32(Rpred, Rtrue, dRpred, loss_sum, loss_mean, workspace, 0u, B, stream);
+}
+static inline int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                                  int64_t B, void *stream) {
+    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, NULL, radians ? SO3_RADIANS : 0u, B, stream);
+}
+static inline int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                                     void *workspace, int64_t B, void *stream) {
+    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, workspace, radians ? SO3_RADIANS : 0u, B, stream);
+}
+static inline int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
+                                      int64_t B, void *stream) {
+    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, NULL, (radians ? SO3_RADIANS : 0u) | SO3_PREZEROED, B, stream);
+}
+/* (the round-3 fused evaluation was float64 on every row: the wrappers keep that) */
+static inline int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                              int32_t *range_flag, int radians, int64_t B, void *stream) {
+    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, NULL, (radians ? SO3_RADIANS : 0u) | SO3_EXACT_F64, B, stream);
+}
+static inline int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                                 int32_t *range_flag, int radians, void *workspace, int64_t B, void *stream) {
+    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, workspace, (radians ? SO3_RADIANS : 0u) | SO3_EXACT_F64, B,
+                                          stream);
+}
+static inline int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
+                                                  int32_t *range_flag, int radians, int64_t B, void *stream) {
+    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, NULL,
+                                          (radians ? SO3_RADIANS : 0u) | SO3_PREZEROED | SO3_EXACT_F64, B, stream);
+}
+#endif /* SO3_NO_LEGACY_WRAPPERS */
 
 #ifdef __cplusplus
 }

@@ -75,10 +75,11 @@ def build_autograd_node(force: bool = False, verbose: bool = False):
         return None
     incs = [i for i in cpp_extension.include_paths() if os.path.isdir(i)] + [sysconfig.get_paths()["include"]]
     libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm_inc = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "include")     # c10/hip/HIPStream.h needs hip_runtime_api.h (host API only)
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=_so3node", "-DTORCH_API_INCLUDE_EXTENSION_H",
-           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-Wno-deprecated-declarations",
-           *["-isystem" + i for i in incs], "-o", out + ".tmp", src,
-           "-L" + libdir, "-Wl,-rpath," + libdir, "-lc10", "-ltorch_cpu", "-ltorch", "-ltorch_python"]
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-Wno-deprecated-declarations",
+           *["-isystem" + i for i in incs], "-isystem" + rocm_inc, "-o", out + ".tmp", src,
+           "-L" + libdir, "-Wl,-rpath," + libdir, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", "-ltorch_python"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:

@@ -3,8 +3,11 @@
 // _SymmetricOrthogonalization and _LossFrobenius in rotation_representation.py are their twins and serve every case these decline.  Config #4 (B = 512, bfloat16: 3D-Pose/main.py:60,85,90) is launch-bound: the kernels take 4 us,
 // a Python autograd.Function costs 30 us of interpreter and engine bookkeeping before it launches anything.  A C++ node takes the
 // interpreter out of forward and backward; what it launches is the same C ABI (include/so3proj.h), reached through function
-// addresses the Python side hands over once (no link-time dependency on libso3proj.so, no HIP headers here: the stream is an
-// integer from torch's accessor, the device guard is c10's generic one).
+// addresses the Python side hands over once (no link-time dependency on libso3proj.so, no device code here).
+// STREAMS: forward launches on the stream the caller passes (the Python side's torch._C._cuda_getCurrentRawStream); backward
+// launches on the stream that is CURRENT when the engine runs the node (c10::hip::getCurrentHIPStream) -- the rule of the Python
+// classes, which ask for the current stream in both places.  (Round 3 kept the forward's raw handle as an integer for backward:
+// the engine makes the forward's stream current for the node anyway, but a handle must not outlive what it names.)
 //
 // frobenius_head handles: x float32 / bfloat16, contiguous, (B,9) or (B,3,3), B >= 1; R_true float32, contiguous, same device, not
 // requiring grad.  symmetric_orthogonalization: x float32 / bfloat16, contiguous, numel a multiple of 9, requiring grad.
@@ -12,19 +15,20 @@
 // head and the other row-operation heads): float32, contiguous, requiring grad.  Anything else: the caller uses the Python class.
 #include <torch/extension.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
 
 #include <vector>
 
 namespace {
 
 typedef int (*FrobFn)(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace,
-                      int64_t B, void *stream);                                      // so3_frob_fwd_bwd_ws_{f32,bf16}
+                      unsigned flags, int64_t B, void *stream);                      // so3_frob_fwd_bwd_v2_{f32,bf16}
 typedef int (*ScaleFn)(const void *src, const float *factor, void *dst, int64_t n, void *stream);   // so3_scale_{f32,bf16}
 typedef const char *(*ErrFn)();                                                      // so3_last_error
 typedef int (*FwdFn)(const void *M, float *R, uint8_t *flip, int64_t B, void *stream);             // so3_project_fwd_{f32,bf16}
 typedef int (*BwdFn)(const void *M, const float *G, void *dM, int64_t B, void *stream);            // so3_project_bwd_{f32,bf16}
 typedef int (*LossFn)(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace,
-                      int64_t B, void *stream);                                      // so3_frob_loss_ws_f32
+                      unsigned flags, int64_t B, void *stream);                      // so3_frob_loss_v2_f32
 
 struct Entry {
     FrobFn frob_f32 = nullptr, frob_bf16 = nullptr;
@@ -36,18 +40,26 @@ struct Entry {
     int64_t small_batch = 0;
 } g_entry;
 
-void no_double_backward() {
-    TORCH_CHECK(!at::GradMode::is_enabled(),
-                "trying to differentiate twice a function that was marked with @once_differentiable "
-                "(poseestimation_amd kernels do not support double backward; the reference never uses it)");
-}
-
 void check(int code, const char *what) {
     TORCH_CHECK(code == 0, what, " failed with code ", code, ": ", g_entry.last_error ? g_entry.last_error() : "");
 }
 
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
+
+// once_differentiable's own condition: only a backward whose result would have to be differentiated AGAIN fails -- grad mode on
+// (create_graph=True) AND an incoming gradient that requires grad.  create_graph=True alone (e.g. a gradient penalty on another
+// branch of the graph) runs the kernels as always: nothing is recorded, the result is a constant.
+void no_double_backward(const variable_list &grads) {
+    if (!at::GradMode::is_enabled()) return;
+    for (const at::Tensor &g : grads)
+        TORCH_CHECK(!(g.defined() && g.requires_grad()),
+                    "trying to differentiate twice a function that was marked with @once_differentiable "
+                    "(poseestimation_amd kernels do not support double backward; the reference never uses it)");
+}
+
+// the stream the engine made current for this node, as the C ABI takes it
+void *current_stream(const at::Tensor &t) { return static_cast<void *>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
 
 struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
     // returns {loss} or {loss, R}; R carries no gradient
@@ -66,13 +78,12 @@ struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
             check((bf16 ? g_entry.frob_bf16 : g_entry.frob_f32)(
                       x.data_ptr(), static_cast<const float *>(r_true.data_ptr()), r.defined() ? static_cast<float *>(r.data_ptr()) : nullptr,
                       dm.defined() ? dm.data_ptr() : nullptr, loss_sum.defined() ? static_cast<double *>(loss_sum.data_ptr()) : nullptr,
-                      static_cast<float *>(loss.data_ptr()), reinterpret_cast<void *>(workspace), b, reinterpret_cast<void *>(stream)),
+                      static_cast<float *>(loss.data_ptr()), reinterpret_cast<void *>(workspace), 0u, b, reinterpret_cast<void *>(stream)),
                   "so3_frob_fwd_bwd");
         }
         if (need_grad) {
             ctx->saved_data["dm"] = dm;                         // ours, not an input or output: no version-counter bookkeeping needed
             ctx->saved_data["shape"] = x.sizes().vec();
-            ctx->saved_data["stream"] = stream;                 // the engine runs backward on the forward's stream
         }
         if (!r.defined()) return {loss};
         ctx->mark_non_differentiable({r});
@@ -80,7 +91,7 @@ struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grads) {
-        no_double_backward();
+        no_double_backward(grads);
         const at::Tensor dm = ctx->saved_data["dm"].toTensor();
         const at::Tensor &g = grads[0];
         at::Tensor gx;
@@ -89,7 +100,7 @@ struct FrobeniusHeadNode : public torch::autograd::Function<FrobeniusHeadNode> {
             gx = at::empty_like(dm);
             const bool bf16 = dm.scalar_type() == at::kBFloat16;
             check((bf16 ? g_entry.scale_bf16 : g_entry.scale_f32)(dm.data_ptr(), static_cast<const float *>(g.data_ptr()), gx.data_ptr(), dm.numel(),
-                                                                    reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+                                                                    current_stream(dm)),
                   "so3_scale");
         } else if (g.defined()) {
             gx = (dm.to(at::kFloat) * g).to(dm.scalar_type());
@@ -111,11 +122,10 @@ struct ProjectNode : public torch::autograd::Function<ProjectNode> {
                   "so3_project_fwd");
         }
         ctx->save_for_backward({x});
-        ctx->saved_data["stream"] = stream;
         return r;
     }
     static variable_list backward(AutogradContext *ctx, variable_list grads) {
-        no_double_backward();
+        no_double_backward(grads);
         const at::Tensor x = ctx->get_saved_variables()[0];
         at::Tensor g = grads[0];
         if (!g.defined()) return {at::Tensor(), at::Tensor()};
@@ -123,7 +133,7 @@ struct ProjectNode : public torch::autograd::Function<ProjectNode> {
         g = g.contiguous();
         at::Tensor dm = at::empty_like(x);
         check((x.scalar_type() == at::kBFloat16 ? g_entry.bwd_bf16 : g_entry.bwd_f32)(x.data_ptr(), static_cast<const float *>(g.data_ptr()), dm.data_ptr(),
-                                                                                     x.numel() / 9, reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+                                                                                     x.numel() / 9, current_stream(x)),
               "so3_project_bwd");
         return {dm, at::Tensor()};
     }
@@ -145,19 +155,18 @@ struct FrobLossNode : public torch::autograd::Function<FrobLossNode> {
             c10::DeviceGuard guard(a.device());
             check(g_entry.loss_f32(static_cast<const float *>(p.data_ptr()), static_cast<const float *>(t.data_ptr()),
                                    g.defined() ? static_cast<float *>(g.data_ptr()) : nullptr, static_cast<double *>(loss_sum.data_ptr()),
-                                   static_cast<float *>(loss.data_ptr()), reinterpret_cast<void *>(workspace), b, reinterpret_cast<void *>(stream)),
+                                   static_cast<float *>(loss.data_ptr()), reinterpret_cast<void *>(workspace), 0u, b, reinterpret_cast<void *>(stream)),
                   "so3_frob_loss_f32");
         }
         if (need_grad) {
             ctx->saved_data["g"] = g;
             ctx->saved_data["first"] = first;
             ctx->saved_data["other_shape"] = t.sizes().vec();
-            ctx->saved_data["stream"] = stream;
         }
         return loss;
     }
     static variable_list backward(AutogradContext *ctx, variable_list grads) {
-        no_double_backward();
+        no_double_backward(grads);
         const at::Tensor g = ctx->saved_data["g"].toTensor();
         const bool first = ctx->saved_data["first"].toBool();
         const at::Tensor &gl = grads[0];
@@ -165,8 +174,7 @@ struct FrobLossNode : public torch::autograd::Function<FrobLossNode> {
         if (gl.defined()) {
             if (gl.scalar_type() == at::kFloat && gl.is_cuda() && gl.numel() == 1) {
                 mine = at::empty_like(g);
-                check(g_entry.scale_f32(g.data_ptr(), static_cast<const float *>(gl.data_ptr()), mine.data_ptr(), g.numel(),
-                                        reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+                check(g_entry.scale_f32(g.data_ptr(), static_cast<const float *>(gl.data_ptr()), mine.data_ptr(), g.numel(), current_stream(g)),
                       "so3_scale");
             } else {
                 mine = g * gl;
@@ -197,11 +205,10 @@ struct RowHeadNode : public torch::autograd::Function<RowHeadNode> {
         ctx->save_for_backward({x});
         ctx->saved_data["bwd"] = bwd;
         ctx->saved_data["width"] = width;
-        ctx->saved_data["stream"] = stream;
         return r;
     }
     static variable_list backward(AutogradContext *ctx, variable_list grads) {
-        no_double_backward();
+        no_double_backward(grads);
         const at::Tensor x = ctx->get_saved_variables()[0];
         at::Tensor g = grads[0];
         if (!g.defined()) return {at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
@@ -210,7 +217,7 @@ struct RowHeadNode : public torch::autograd::Function<RowHeadNode> {
         at::Tensor dx = at::empty_like(x);
         check(reinterpret_cast<RowBwdFn>(ctx->saved_data["bwd"].toInt())(static_cast<const float *>(x.data_ptr()), static_cast<const float *>(g.data_ptr()),
                                                                         static_cast<float *>(dx.data_ptr()), x.numel() / ctx->saved_data["width"].toInt(),
-                                                                        reinterpret_cast<void *>(ctx->saved_data["stream"].toInt())),
+                                                                        current_stream(x)),
               "row head backward");
         return {dx, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
     }
@@ -218,15 +225,15 @@ struct RowHeadNode : public torch::autograd::Function<RowHeadNode> {
 
 void bind(const py::dict &addresses, int64_t small_batch) {
     auto at_ = [&](const char *name) -> int64_t { return addresses[name].cast<int64_t>(); };
-    g_entry.frob_f32 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_ws_f32"));
-    g_entry.frob_bf16 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_ws_bf16"));
+    g_entry.frob_f32 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_v2_f32"));
+    g_entry.frob_bf16 = reinterpret_cast<FrobFn>(at_("so3_frob_fwd_bwd_v2_bf16"));
     g_entry.scale_f32 = reinterpret_cast<ScaleFn>(at_("so3_scale_f32"));
     g_entry.scale_bf16 = reinterpret_cast<ScaleFn>(at_("so3_scale_bf16"));
     g_entry.fwd_f32 = reinterpret_cast<FwdFn>(at_("so3_project_fwd_f32"));
     g_entry.fwd_bf16 = reinterpret_cast<FwdFn>(at_("so3_project_fwd_bf16"));
     g_entry.bwd_f32 = reinterpret_cast<BwdFn>(at_("so3_project_bwd_f32"));
     g_entry.bwd_bf16 = reinterpret_cast<BwdFn>(at_("so3_project_bwd_bf16"));
-    g_entry.loss_f32 = reinterpret_cast<LossFn>(at_("so3_frob_loss_ws_f32"));
+    g_entry.loss_f32 = reinterpret_cast<LossFn>(at_("so3_frob_loss_v2_f32"));
     g_entry.last_error = reinterpret_cast<ErrFn>(at_("so3_last_error"));
     g_entry.small_batch = small_batch;
 }

@@ -241,6 +241,7 @@ template <int NPL> struct RowCtx {
     char *scratch;          // the wave's Op::kWaveScratch bytes of LDS, kept across its rounds (K1: the queue of hard rows)
     int pending;            // wave-uniform state that goes with it (K1: how many rows the queue holds)
     int dense;              // wave-uniform (K1): 1 = the wave's last round was dense in hard rows, 2 = so were earlier ones and the shortcut was refused
+    int n_half, n_pi;       // wave-uniform (the float32 angle sum, angle_sum_f32): rows of this wave whose angle is pi/2 - r, pi - 2r
 };
 
 #ifndef SO3_HOST_MODEL
@@ -308,6 +309,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.scratch = scratch[wave_in_block];
     ctx.pending = 0;
     ctx.dense = 0;
+    ctx.n_half = 0;
+    ctx.n_pi = 0;
     if (t < nrounds) {
         auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
             const int64_t left = nunits - tr * NPL;
@@ -398,6 +401,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     }
     if (Op::kReduce) {
         double v = ctx.acc;
+        if constexpr (Op::kAngleConstants)        // angle_sum_f32: the multiples of pi/2 the wave's rows carry, counted on the scalar unit
+            if (lane == 0) v += 1.57079632679489661923 * static_cast<double>(ctx.n_half) + 3.14159265358979323846 * static_cast<double>(ctx.n_pi);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
         const bool any_flag = __any(ctx.flag);
@@ -408,6 +413,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int w = 0; w < kWaves; ++w) { total += red[w]; f |= red_flag[w]; }
+            total = op.scale_partial(total);
         }
         if (op.ws == nullptr) {                             // no workspace: atomics onto accumulators the host initialised
             if (threadIdx.x == 0) op.finish(total, f != 0);
@@ -451,6 +457,7 @@ struct OpBase {
     const void *in0 = nullptr, *in1 = nullptr, *in2 = nullptr;
     void *out0 = nullptr, *out1 = nullptr;
     static constexpr bool kReduce = false;
+    static constexpr bool kAngleConstants = false;      // the operation sums angles through angle_sum_f32 (RowCtx::n_half, n_pi)
     // kLateIn1: the operation reads the second input's rows out of LDS itself (late_in1), where it first needs them -- for K2 / K3 /
     // K1+K4 that is AFTER the projection, whose ~110 live registers the 18 of a second input's rows would otherwise sit beside
     static constexpr bool kLateIn1 = false;
@@ -463,6 +470,7 @@ struct OpBase {
 #endif
     __device__ __forceinline__ void finish(double, bool) const {}
     __device__ __forceinline__ void finish_total(double, bool) const {}
+    __device__ __forceinline__ double scale_partial(double t) const { return t; }      // a workgroup's partial -> the unit of the result
 };
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
@@ -756,14 +764,80 @@ struct OpAngle : OpBase {
     }
 };
 
+// The REDUCED forms of the metric -- sum_b acos(clamp((tr(R1_b^T R2_b) - 1)/2)), what `angle_error(...).mean()` (3D-Pose/main.py:62) and
+// the (sum, count) pair of the multi-GPU layer need -- without float64 arithmetic on every row.  The reference casts both
+// rotations to float64 before the product (rotation_representation.py:232-233); reproducing that costs 18 v_cvt_f64_f32, 9 float64
+// FMAs and a 35-instruction float64 acos per row, 560 cycles per pair of rows on top of K1's 1 750 (profiles/r03_valu_rates_f64.txt),
+// for a sum whose INPUTS are float32 rotations carrying 1e-7 of orthonormality defect.  Here the same formula runs in packed
+// float32 -- trace, cosine, acos as pi/2 - asin(c) for |c| <= 1/2 and through asin(sqrt((1 - |c|)/2)) beyond, a degree-5 polynomial
+// (1.2e-9 rad, fitted for float32 evaluation: mean error -3e-10 rad) -- and only the asin part r travels to the float64
+// accumulator per row (one v_cvt, one v_add_f64); the multiples of pi/2 are counted on the scalar unit from the lane masks
+// (RowCtx::n_half, n_pi) and added once per wave, so no float32 constant's rounding enters the sum.
+// Where the cosine is within 5e-7 of +-1 (angles within 1e-3 rad = 0.057 degrees of 0 or 180: acos amplifies the float32 trace's
+// 1e-7 of round-off beyond 1e-4 rad there) the row takes the reference's float64 arithmetic as before, under a wave-uniform
+// branch (Haar-distributed pairs: one round of 128 rows in twelve) and per row: a row's contribution does not depend on its
+// wave-mates.  Outside that band a row's angle differs from the float64 one by at most 2e-7 / sin(theta) rad, without bias
+// (round-to-nearest), 3e-8 degrees in the mean of 1M Haar pairs.  The range test (cos outside [-1.1, 1.1]) runs on the float32 cosine.
+template <class T, int NPL>
+__device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], RowCtx<NPL> &ctx) {
+    typedef Tr<T> R;
+    T tr = a[0] * b[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) tr = R::fma(a[i], b[i], tr);
+    const T c = (tr - R::splat(1.f)) * R::splat(0.5f);
+    const T ac = R::abs(c);
+    // every comparison is false for NaN: a NaN cosine takes the sqrt branch and stays NaN (torch.clamp keeps NaN, acos returns it)
+    const typename R::mask small = R::le(ac, R::splat(0.5f));
+    const T zb = R::sel(R::gt(ac, R::splat(1.f)), R::splat(0.f), R::fma(ac, R::splat(-0.5f), R::splat(0.5f)));    // clamp: |c| > 1 -> angle 0 or pi
+    const T z = R::sel(small, c * c, zb);
+    const T x = R::sel(small, c, R::sqrt(zb));
+    T g = R::fma(z, R::splat(3.392098099e-02f), R::splat(1.700584404e-02f));
+    g = R::fma(g, z, R::splat(3.113190830e-02f));
+    g = R::fma(g, z, R::splat(4.459662735e-02f));
+    g = R::fma(g, z, R::splat(7.500103116e-02f));
+    g = R::fma(g, z, R::splat(1.666666567e-01f));
+    const T r = R::fma(x * z, g, x);                                   // asin(x)
+    // theta = pi/2 - r (small) | 2 r (c > 1/2) | pi - 2 r (c < -1/2): r times -1 / 2 / -2 here, the constants by count
+    const typename R::mask neg = R::gt(R::splat(0.f), c);
+    const T rm = r * R::sel(small, R::splat(-1.f), R::sel(neg, R::splat(-2.f), R::splat(2.f)));
+    const typename R::mask out = R::gt(ac, R::splat(1.1f));            // the reference's range test (rotation_representation.py:236-239)
+    const typename R::mask band = R::gt(ac, R::splat(0.9999995f));     // cosine within 5e-7 of +-1 (or clamped): float64 for this row
+    bool any_band = false;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        if (!ctx.exists[k]) continue;                                   // wave-uniform: the phantom unit of an odd tail
+        ctx.acc += static_cast<double>(R::get(rm, k));
+        ctx.flag |= R::lane_of(out, k);
+        ctx.n_half += __builtin_popcountll(__builtin_amdgcn_ballot_w64(R::lane_of(small, k)));
+        ctx.n_pi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(!R::lane_of(small, k) && R::lane_of(neg, k)));
+        any_band |= wave_any(R::lane_of(band, k));
+    }
+    if (__builtin_expect(any_band, 0)) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            double t64 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) t64 = fma(static_cast<double>(R::get(a[i], k)), static_cast<double>(R::get(b[i], k)), t64);
+            const double c64 = fmin(fmax((t64 - 1.0) * 0.5, -1.0), 1.0);       // (a band row's cosine is finite)
+            // what the row has contributed above is K + rm with K = 0 or pi: replace it by the float64 angle
+            const double base = R::lane_of(neg, k) ? 3.14159265358979323846 : 0.0;
+            const double corr = acos_f64(c64) - base - static_cast<double>(R::get(rm, k));
+            if (ctx.exists[k] && R::lane_of(band, k)) ctx.acc += corr;
+        }
+    }
+}
+
 // K1 + K4 fused: theta_b = angle(proj(M_b), T_b) without materialising R (72 B read per row, nothing written
 // unless the per-row angles or R are requested).  The evaluation step of the reference,
 // `angle_error(func[rot_rep](out), R).mean()` (3D-Pose/main.py:60-62,110-112), in one launch.
-template <int M_BYTES, bool WANT_R, bool WANT_DEG, bool WANT_SUM>
+// F32SUM (only without per-row angles): the sum through angle_sum_f32 above; otherwise every row in the reference's float64.
+template <int M_BYTES, bool WANT_R, bool WANT_DEG, bool WANT_SUM, bool F32SUM = false>
 struct OpProjectAngle : OpBase {
+    static_assert(!F32SUM || (!WANT_DEG && WANT_SUM), "the float32 angle sum is a reduced form");
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_R ? 4 : 0, kOut1 = 0;
     static constexpr bool kReduce = true;
     static constexpr bool kLateIn1 = true;
+    static constexpr bool kAngleConstants = F32SUM;
     double *deg = nullptr, *sum_count = nullptr;
     int32_t *range_flag = nullptr;
     double unit_scale = 1.0;
@@ -775,6 +849,10 @@ struct OpProjectAngle : OpBase {
         if (WANT_R) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];
+        }
+        if constexpr (F32SUM) {
+            angle_sum_f32<T, NPL>(r, rows.b, ctx);           // radians; finish() scales the workgroup's total
+            return;
         }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
@@ -795,6 +873,7 @@ struct OpProjectAngle : OpBase {
     }
     double count = 0.0;
     bool store_count = false;      // accumulators pre-zeroed by the caller (so3_*_acc): nobody else writes the row count
+    __device__ __forceinline__ double scale_partial(double t) const { return F32SUM ? t * unit_scale : t; }   // angle_sum_f32 sums radians
     __device__ __forceinline__ void finish(double total, bool any_flag) const {
         if (WANT_SUM) atomicAdd(sum_count, total);
         if (WANT_SUM && store_count && blockIdx.x == 0) sum_count[1] = count;

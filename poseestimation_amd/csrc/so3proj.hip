@@ -1499,7 +1499,10 @@ inline bool use_workspace(void *workspace, int64_t nunits, unsigned tile_wgs) {
 }
 
 template <bool BF16>
-int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace, int64_t B, void *stream) {
+int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace, unsigned flags, int64_t B,
+         void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_PREZEROED)) == 0, "so3_frob_fwd_bwd: unknown flag");
+    const bool prezeroed = (flags & SO3_PREZEROED) != 0;
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_fwd_bwd: B");
     SO3_CHECK_ARGS(loss_sum != nullptr || (loss_mean != nullptr && B > 0 && B <= kSmallBatch), "so3_frob_fwd_bwd: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1517,7 +1520,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     const unsigned tile_wgs = rest > 0 ? persistent_grid(rest) : 0u;
     so3::ReduceWs *ws = use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
-    if (ws == nullptr) {
+    if (ws == nullptr && !prezeroed) {
         hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
         if (e != hipSuccess) return fail((int)e, "so3_frob_fwd_bwd: memset");
     }
@@ -1598,24 +1601,20 @@ int so3_project_bwd_f32(const float *M, const float *G, float *dM, int64_t B, vo
 int so3_project_bwd_bf16(const void *M, const float *G, void *dM, int64_t B, void *stream) {
     return project_bwd<true>(M, G, dM, B, stream);
 }
-int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
-    return frob<false>(M, Rtrue, R, dM, loss_sum, nullptr, nullptr, B, stream);
-}
-int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
-    return frob<true>(M, Rtrue, R, dM, loss_sum, nullptr, nullptr, B, stream);
-}
 size_t so3_reduce_workspace_bytes(void) { return sizeof(so3::ReduceWs); }
-int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean, void *workspace,
-                            int64_t B, void *stream) {
-    return frob<false>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, B, stream);
+int so3_frob_fwd_bwd_v2_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean, void *workspace,
+                            unsigned flags, int64_t B, void *stream) {
+    return frob<false>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, flags, B, stream);
 }
-int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace,
-                             int64_t B, void *stream) {
-    return frob<true>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, B, stream);
+int so3_frob_fwd_bwd_v2_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean, void *workspace,
+                             unsigned flags, int64_t B, void *stream) {
+    return frob<true>(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, flags, B, stream);
 }
 
-static int frob_loss(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace, int64_t B,
-                     void *stream) {
+int so3_frob_loss_v2_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace,
+                         unsigned flags, int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_PREZEROED)) == 0, "so3_frob_loss_f32: unknown flag");
+    const bool prezeroed = (flags & SO3_PREZEROED) != 0;
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f32: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f32: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1631,7 +1630,7 @@ static int frob_loss(const float *Rpred, const float *Rtrue, float *dRpred, doub
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     const unsigned tile_wgs = rest > 0 ? persistent_grid(rest) : 0u;
     so3::ReduceWs *ws = use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
-    if (ws == nullptr) {
+    if (ws == nullptr && !prezeroed) {
         hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
         if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f32: memset");
     }
@@ -1661,18 +1660,12 @@ static int frob_loss(const float *Rpred, const float *Rtrue, float *dRpred, doub
     if (ws == nullptr && loss_mean != nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(loss_sum, loss_mean, 1.0 / static_cast<double>(B));
     return check_launch("so3_frob_loss_f32");
 }
-int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
-    return frob_loss(Rpred, Rtrue, dRpred, loss_sum, nullptr, nullptr, B, stream);
-}
-int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean, void *workspace,
-                         int64_t B, void *stream) {
-    return frob_loss(Rpred, Rtrue, dRpred, loss_sum, loss_mean, workspace, B, stream);
-}
-
 // `prezeroed`: sum_count[0] and *range_flag are zero on entry (the caller hands out fresh slots of a zero-filled pool): no
 // init launch, the kernels add to them as they are and one workgroup stores the row count.
-static int angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag,
-                       int radians, void *workspace, bool prezeroed, int64_t B, void *stream) {
+int so3_angle_error_v2(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, void *workspace, unsigned flags,
+                       int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_RADIANS | SO3_PREZEROED | SO3_EXACT_F64)) == 0, "so3_angle_error: unknown flag");
+    const bool radians = (flags & SO3_RADIANS) != 0, prezeroed = (flags & SO3_PREZEROED) != 0;      // (K4 alone is float64 on every row: SO3_EXACT_F64 changes nothing)
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;   // 180/pi
@@ -1714,19 +1707,10 @@ static int angle_error(const float *R1, const float *R2, double *deg, double *su
     }
     return check_launch("so3_angle_error");
 }
-int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B, void *stream) {
-    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, false, B, stream);
-}
-int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, void *workspace,
-                       int64_t B, void *stream) {
-    return angle_error(R1, R2, deg, sum_count, range_flag, radians, workspace, false, B, stream);
-}
-int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B, void *stream) {
-    return angle_error(R1, R2, deg, sum_count, range_flag, radians, nullptr, true, B, stream);
-}
-
-static int project_angle_error(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                               int radians, void *workspace, bool prezeroed, int64_t B, void *stream) {
+int so3_project_angle_error_v2_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
+                                   void *workspace, unsigned flags, int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_RADIANS | SO3_PREZEROED | SO3_EXACT_F64)) == 0, "so3_project_angle_error_f32: unknown flag");
+    const bool radians = (flags & SO3_RADIANS) != 0, prezeroed = (flags & SO3_PREZEROED) != 0, exact = (flags & SO3_EXACT_F64) != 0;
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_angle_error_f32: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
@@ -1761,29 +1745,19 @@ static int project_angle_error(const float *M, const float *Rtrue, float *R, dou
 #undef LAUNCH
     }
     if (nunits > 0) {
-#define SLAUNCH(WR, WD, WS) do { so3::OpProjectAngle<4, WR, WD, WS> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
+#define SLAUNCH(WR, WD, WS, F32) do { so3::OpProjectAngle<4, WR, WD, WS, F32> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
                                  op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
                                  op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
-#define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true); else if (deg) SLAUNCH(WR, true, false); else if (sum_count) SLAUNCH(WR, false, true); else SLAUNCH(WR, false, false); } while (0)
+        // the sum without per-row angles: float32 trace and acos outside the band around +-1 (so3::angle_sum_f32) unless SO3_EXACT_F64
+#define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true, false); else if (deg) SLAUNCH(WR, true, false, false); \
+                       else if (sum_count && !exact) SLAUNCH(WR, false, true, true); else if (sum_count) SLAUNCH(WR, false, true, false); \
+                       else SLAUNCH(WR, false, false, false); } while (0)
         if (R) PICKR(true); else PICKR(false);
 #undef PICKR
 #undef SLAUNCH
     }
     return check_launch("so3_project_angle_error_f32");
 }
-int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                                int radians, int64_t B, void *stream) {
-    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, false, B, stream);
-}
-int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                                    int radians, int64_t B, void *stream) {
-    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, nullptr, true, B, stream);
-}
-int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count, int32_t *range_flag,
-                                   int radians, void *workspace, int64_t B, void *stream) {
-    return project_angle_error(M, Rtrue, R, deg, sum_count, range_flag, radians, workspace, false, B, stream);
-}
-
 int so3_project_fwd_diag_f32(const float *M, float *R, uint8_t *hard, int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_project_fwd_diag_f32: B");
     if (B == 0) return 0;

@@ -45,10 +45,23 @@ def _libh():
     return _L
 
 
-try:                                  # csrc/fastcall.c: METH_FASTCALL entry for the enqueue-only calls (ctypes: ~2.5 us per call)
-    from . import _so3fast
-except ImportError:                   # not built (no C compiler / Python.h): every call goes through ctypes
-    _so3fast = None
+def _optional_helper(name: str, without: str):
+    """An optional host-side helper module of this package, or None -- with ONE warning on stderr saying what is lost: both
+    helpers only remove host overhead (results are the same bits either way), so a missing one must not fail the import, but it
+    must not go unnoticed either (_so3node is compiled against the build machine's torch; another torch on the box where it
+    runs silently moved config #4's step from the C++ nodes to the Python classes in round 3)."""
+    import importlib
+    try:
+        return importlib.import_module("." + name, __package__)
+    except ImportError as exc:
+        import sys
+        print("[poseestimation_amd] optional helper %s is not available (%s): %s.  "
+              "`python -m poseestimation_amd.build --force` rebuilds it." % (name, exc, without), file=sys.stderr)
+        return None
+
+
+# csrc/fastcall.c: METH_FASTCALL entry for the enqueue-only calls (ctypes: ~2.5 us per call)
+_so3fast = _optional_helper("_so3fast", "every C-ABI call goes through ctypes, ~2.5 us per call slower")
 _FAST = {}
 
 
@@ -68,10 +81,8 @@ def _fn(name: str):
     return f
 
 
-try:                                  # csrc/autograd_node.cpp: frobenius_head's autograd node without the interpreter in forward / backward
-    from . import _so3node
-except ImportError:                   # not built: the Python autograd.Function below serves every case
-    _so3node = None
+# csrc/autograd_node.cpp: the autograd nodes without the interpreter in forward / backward
+_so3node = _optional_helper("_so3node", "the Python autograd.Function classes serve every case, ~10-25 us per training step slower at batch 512")
 _NODE_BOUND = False
 
 
@@ -83,8 +94,8 @@ def _node():
         lib = _libh()
         addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
         _so3node.bind({name: addr(name) for name in (
-            "so3_frob_fwd_bwd_ws_f32", "so3_frob_fwd_bwd_ws_bf16", "so3_scale_f32", "so3_scale_bf16", "so3_project_fwd_f32", "so3_project_fwd_bf16",
-            "so3_project_bwd_f32", "so3_project_bwd_bf16", "so3_frob_loss_ws_f32", "so3_last_error")}, _SMALL_BATCH)
+            "so3_frob_fwd_bwd_v2_f32", "so3_frob_fwd_bwd_v2_bf16", "so3_scale_f32", "so3_scale_bf16", "so3_project_fwd_f32", "so3_project_fwd_bf16",
+            "so3_project_bwd_f32", "so3_project_bwd_bf16", "so3_frob_loss_v2_f32", "so3_last_error")}, _SMALL_BATCH)
         _NODE_BOUND = True
     return _so3node
 
@@ -166,7 +177,7 @@ _WORKSPACES = {}
 def _workspace(dev: torch.device, stream: int):
     """The reduction workspace of (device, stream) -- include/so3proj.h: zero-filled once, then owned by that stream's calls.
     None while the stream is being captured into a graph (a replay may run beside eager calls: the no-workspace path then)."""
-    if torch.cuda.is_current_stream_capturing():
+    if _capturing(dev):
         return None
     key = (dev.index, stream)
     ws = _WORKSPACES.get(key)
@@ -176,23 +187,37 @@ def _workspace(dev: torch.device, stream: int):
     return ws
 
 
+def _capturing(dev: torch.device) -> bool:
+    """Is the current stream OF `dev` being captured into a graph?  (torch's query looks at the current device.)"""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return torch.cuda.is_current_stream_capturing()
+    with torch.cuda.device(dev):
+        return torch.cuda.is_current_stream_capturing()
+
+
 class _ZeroPool:
-    """Zero-filled accumulator slots for the metric kernels (so3_*_acc: sum_count[0] and the range flag must be 0 on entry):
+    """Zero-filled accumulator slots for the metric kernels (SO3_PREZEROED: sum_count[0] and the range flag must be 0 on entry):
     one torch.zeros per 256 calls instead of an init launch in front of every kernel.  A slot is handed out once; the tensors
-    returned to the caller are views of it and keep their pool alive."""
+    returned to the caller are views of it and keep their pool alive.
+    One pool per (device, STREAM), like the reduction workspaces: the zero-fill is enqueued on the stream that was current when
+    the pool was made, and a kernel on another stream could otherwise add into a slot before it has been zeroed -- or into a
+    retired pool's block after the allocator handed it to someone else on the filling stream."""
     SLOTS = 256
 
     def __init__(self):
         self.pools = {}
 
-    def take(self, dev: torch.device):
-        """(sum_count: 2 float64, flag: 1 int32), both zero."""
-        entry = self.pools.get(dev.index)
-        if entry is None or entry[1] >= self.SLOTS or torch.cuda.is_current_stream_capturing():
-            entry = [torch.zeros((self.SLOTS, 4), dtype=torch.float64, device=dev), 0]
-            if torch.cuda.is_current_stream_capturing():
-                return entry[0][0, :2], entry[0][0, 2:3].view(torch.int32)[:1]     # a graph keeps its own (captured) zero-fill
-            self.pools[dev.index] = entry
+    def take(self, dev: torch.device, stream: int):
+        """(sum_count: 2 float64, flag: 1 int32), both zero, for a kernel enqueued on `stream` (the current stream of dev)."""
+        if _capturing(dev):
+            z = torch.zeros((1, 4), dtype=torch.float64, device=dev)               # a graph keeps its own (captured) zero-fill
+            return z[0, :2], z[0, 2:3].view(torch.int32)[:1]
+        key = (dev.index, stream)
+        entry = self.pools.get(key)
+        if entry is None or entry[1] >= self.SLOTS:
+            with _on_device(dev):
+                entry = [torch.zeros((self.SLOTS, 4), dtype=torch.float64, device=dev), 0]     # filled on `stream`: it is current
+            self.pools[key] = entry
         row = entry[0][entry[1]]
         entry[1] += 1
         return row[:2], row[2:3].view(torch.int32)[:1]
@@ -246,10 +271,13 @@ def _head_fns(dtype):
     return fns
 
 
-def _no_double_backward() -> None:
-    """What torch's once_differentiable decorator guards against, at a fraction of its price (a no_grad context per call): these
-    backward functions launch kernels autograd cannot see, so backward-of-backward (create_graph=True) must fail loudly."""
-    if torch.is_grad_enabled():
+def _no_double_backward(*grads) -> None:
+    """torch's once_differentiable, at a fraction of its price (a no_grad context per call): these backward functions launch
+    kernels autograd cannot see, so a backward whose result would have to be differentiated AGAIN must fail loudly.  That is
+    once_differentiable's own condition -- grad mode on (create_graph=True) AND an incoming gradient that requires grad.
+    create_graph=True alone (a gradient penalty on another branch of the graph) runs the kernels as always; nothing is recorded,
+    the result is a constant."""
+    if torch.is_grad_enabled() and any(g is not None and g.requires_grad for g in grads):
         raise RuntimeError("trying to differentiate twice a function that was marked with @once_differentiable "
                            "(poseestimation_amd kernels do not support double backward; the reference never uses it)")
 
@@ -279,7 +307,7 @@ class _SymmetricOrthogonalization(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_r):
-        _no_double_backward()
+        _no_double_backward(grad_r)
         (m,) = ctx.saved_tensors
         dev = m.device
         _, fn, g_dtype = _head_fns(m.dtype)
@@ -346,10 +374,11 @@ def _angle_call(r1, r2, want_deg, want_sum, radians=False):
         raise RuntimeError(f"angle_error: shape mismatch {tuple(r1.shape)} vs {tuple(r2.shape)}")
     n = a.shape[0]
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
-    sc, flag = _ZERO_POOL.take(dev)                 # zero-filled slots: the kernel needs no init launch in front of it
     with _on_device(dev):
-        _check(_fn("so3_angle_error_acc")(a.data_ptr(), b_.data_ptr(), _ptr(deg), sc.data_ptr() if want_sum else None, flag.data_ptr(),
-                                           1 if radians else 0, n, _stream(dev)), "so3_angle_error")
+        st = _stream(dev)
+        sc, flag = _ZERO_POOL.take(dev, st)         # zero-filled slots: the kernel needs no init launch in front of it
+        _check(_fn("so3_angle_error_v2")(a.data_ptr(), b_.data_ptr(), _ptr(deg), sc.data_ptr() if want_sum else None, flag.data_ptr(), None,
+                                          _lib.PREZEROED | (_lib.RADIANS if radians else 0), n, st), "so3_angle_error")
     return deg, (sc if want_sum else None), flag
 
 
@@ -412,12 +441,22 @@ def angle_error_sum_count(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = 
     return sc
 
 
-def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none", check: bool = True, return_rotation: bool = False):
+def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none", check: bool = True, return_rotation: bool = False,
+                     exact: bool = False):
     """Fused `angle_error(symmetric_orthogonalization(x), R_true)` (3D-Pose/main.py:60-62): one launch that reads
     x and R_true (72 B per row) and writes only what is asked for.
 
     reduce="none": (B,) float64 degrees;  reduce="mean": 0-dim float64 mean;  reduce="sum_count": the (sum, count)
-    pair for a multi-GPU all-reduce.  return_rotation=True also returns R.  Not differentiable (evaluation path)."""
+    pair for a multi-GPU all-reduce.  return_rotation=True also returns R.  Not differentiable (evaluation path).
+
+    Arithmetic.  reduce="none" gives, row for row, what `angle_error` gives on the materialised rotation (the reference's
+    float64 expression, rotation_representation.py:232-241; equal to 1e-9 degrees).  The reduced forms of a batch above 1024
+    rows evaluate the same expression -- trace, cosine, clamp, acos -- in float32 for every row whose cosine is at least
+    5e-7 away from +-1 and in float64 for the rows inside that band (angles within 0.057 degrees of 0 or 180), and sum in
+    float64: the result differs from `angle_error(...).mean()` by the float32 trace's round-off, at most 2e-7 / sin(theta) rad
+    per row and without bias -- 3e-8 degrees on the mean of 1M Haar-distributed pairs, below 2e-6 degrees when every pair is
+    0.3 degrees apart (the reference's own sensitivity to the 1e-7 of orthonormality defect its float32 inputs carry is larger).
+    exact=True runs the float64 expression on every row (20 % slower at 1M rows).  The range check is the reference's."""
     if reduce not in ("none", "mean", "sum_count"):
         raise ValueError("reduce must be 'none', 'mean' or 'sum_count'")
     dev = _require_device(x, R_true)
@@ -433,12 +472,13 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     need_r = return_rotation or (n % 64 != 0) or (m.data_ptr() % 16 != 0) or (t.data_ptr() % 16 != 0)
     r = torch.empty((n, 3, 3), dtype=torch.float32, device=dev) if need_r else None
     deg = torch.empty((n,), dtype=torch.float64, device=dev) if want_deg else None
-    sc, flag = _ZERO_POOL.take(dev)                 # zero-filled slots: the kernel needs no init launch in front of it
-    if want_deg:
-        sc = None
     with _on_device(dev):
-        _check(_fn("so3_project_angle_error_acc_f32")(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), 0, n, _stream(dev)),
-               "so3_project_angle_error_f32")
+        st = _stream(dev)
+        sc, flag = _ZERO_POOL.take(dev, st)         # zero-filled slots: the kernel needs no init launch in front of it
+        if want_deg:
+            sc = None
+        _check(_fn("so3_project_angle_error_v2_f32")(_ptr(m), _ptr(t), _ptr(r), _ptr(deg), _ptr(sc), _ptr(flag), None,
+                                                      _lib.PREZEROED | (_lib.EXACT_F64 if exact else 0), n, st), "so3_project_angle_error_f32")
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
     out = deg if want_deg else (sc if reduce == "sum_count" else sc[0] / sc[1])
@@ -485,7 +525,7 @@ class _LossFrobenius(torch.autograd.Function):
                        "so3_frob_loss_f64")
             else:
                 ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-                _check(_fn("so3_frob_loss_ws_f32")(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
+                _check(_fn("so3_frob_loss_v2_f32")(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), 0, b, st),
                        "so3_frob_loss_f32")
         ctx.g = g
         ctx.shapes = (r_pred.shape, r_true.shape, r_pred.dtype, r_true.dtype)
@@ -544,27 +584,32 @@ class _FrobeniusHead(torch.autograd.Function):
         # d loss / d R_true = -(R - R_true) / (B ||R - R_true||_F), the loss being differentiable in both arguments
         # (3D-Pose/loss.py:7-11): it is rebuilt in backward from R and R_true (K3'), so R is kept whenever it is asked for
         ctx.true_grad = r_true.requires_grad
+        want_r_user = want_r                      # the caller gets R (and may write into it)
         want_r = want_r or ctx.true_grad
         r = torch.empty((b, 3, 3), dtype=torch.float32, device=dev) if want_r else None
         dm = torch.empty_like(m) if need_grad else None
         loss_sum = torch.empty((1,), dtype=torch.float64, device=dev) if b > _SMALL_BATCH or b == 0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)      # the kernel writes the float32 mean itself: no launch of ours
-        fn = _fn("so3_frob_fwd_bwd_ws_bf16" if m.dtype is torch.bfloat16 else "so3_frob_fwd_bwd_ws_f32")
+        fn = _fn("so3_frob_fwd_bwd_v2_bf16" if m.dtype is torch.bfloat16 else "so3_frob_fwd_bwd_v2_f32")
         with _on_device(dev):
             st = _stream(dev)
             ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-            _check(fn(m.data_ptr(), t.data_ptr(), _ptr(r), _ptr(dm), _ptr(loss_sum), loss.data_ptr(), _ptr(ws), b, st), "so3_frob_fwd_bwd")
+            _check(fn(m.data_ptr(), t.data_ptr(), _ptr(r), _ptr(dm), _ptr(loss_sum), loss.data_ptr(), _ptr(ws), 0, b, st), "so3_frob_fwd_bwd")
         ctx.dm = dm
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
         if ctx.true_grad:
-            ctx.rt = (r, t, r_true.shape, r_true.dtype)
+            # the target goes through save_for_backward (an in-place edit between forward and backward then raises instead of
+            # yielding a silently wrong gradient); the rotation handed to the caller leaves autograd through `box`, so backward
+            # keeps a private copy of it
+            ctx.save_for_backward(t)
+            ctx.rt = (r.clone() if want_r_user else r, r_true.shape, r_true.dtype)
         box.append(r)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
-        _no_double_backward()
+        _no_double_backward(grad_loss)
         dm = ctx.dm
         gx = gt = None
         if dm is not None and ctx.needs_input_grad[0]:
@@ -583,13 +628,14 @@ class _FrobeniusHead(torch.autograd.Function):
             else:
                 gx = (dm.float() * grad_loss).to(ctx.in_dtype).view(ctx.in_shape)
         if ctx.true_grad and ctx.needs_input_grad[1]:
-            r, t, shape, dtype = ctx.rt
+            r, shape, dtype = ctx.rt
+            (t,) = ctx.saved_tensors
             dev = t.device
             b = t.shape[0]
             g = torch.empty_like(t)                              # d(mean loss)/dR_pred; the target's gradient is its negative
             scratch = torch.empty((1,), dtype=torch.float64, device=dev)
             with _on_device(dev):
-                _check(_libh().so3_frob_loss_f32(_ptr(r), _ptr(t), _ptr(g), _ptr(scratch), b, _stream(dev)), "so3_frob_loss_f32")
+                _check(_libh().so3_frob_loss_v2_f32(_ptr(r), _ptr(t), _ptr(g), _ptr(scratch), None, None, 0, b, _stream(dev)), "so3_frob_loss_f32")
             gt = (g * (-grad_loss)).to(dtype).view(shape)
         return gx, gt, None, None
 
@@ -652,12 +698,12 @@ class FrobeniusHeadStep:
         self._sum = torch.empty((1,), dtype=torch.float64, device=dev)
         self.loss = torch.empty((), dtype=torch.float32, device=dev)
         lib = _libh()
-        fn = lib.so3_frob_fwd_bwd_ws_bf16 if dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_ws_f32
+        fn = lib.so3_frob_fwd_bwd_v2_bf16 if dtype == torch.bfloat16 else lib.so3_frob_fwd_bwd_v2_f32
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
 
         def record():                 # the float32 mean is written by the kernel(s); no workspace inside a graph
-            _check(fn(_ptr(self.x), _ptr(self.r_true), _ptr(self.r), _ptr(self.dx), _ptr(self._sum), _ptr(self.loss), None, self.batch,
+            _check(fn(_ptr(self.x), _ptr(self.r_true), _ptr(self.r), _ptr(self.dx), _ptr(self._sum), _ptr(self.loss), None, 0, self.batch,
                       side.cuda_stream), "so3_frob_fwd_bwd")
 
         with torch.cuda.device(dev), torch.cuda.stream(side):

@@ -10,10 +10,20 @@ import torch
 from conftest import ROOT
 
 
-def header_symbols():
+def _header_parts():
+    """(declarations, legacy block): the exported prototypes, and the `static inline` wrappers kept for one round."""
     text = open(os.path.join(ROOT, "include", "so3proj.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(so3_[a-z0-9_]+)\s*\(", text)))
+    a, b = text.index("#ifndef SO3_NO_LEGACY_WRAPPERS"), text.index("#endif", text.index("#ifndef SO3_NO_LEGACY_WRAPPERS"))
+    return text[:a] + text[b:], text[a:b]
+
+
+def header_symbols():
+    return sorted(set(re.findall(r"\b(so3_[a-z0-9_]+)\s*\(", _header_parts()[0])))
+
+
+def legacy_wrappers():
+    return sorted(set(re.findall(r"static inline int (so3_[a-z0-9_]+)\s*\(", _header_parts()[1])))
 
 
 def test_library_exports_every_declared_symbol(built_library):
@@ -22,6 +32,23 @@ def test_library_exports_every_declared_symbol(built_library):
     assert len(names) >= 11
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/so3proj.h but not exported"
+
+
+def test_reducing_entry_points_exist_once(built_library):
+    """Round 3 exported every reducing entry three times (plain, _ws, _acc); now one export each (workspace nullable, a flags
+    word) and the old names are inline wrappers in the header -- present there, absent from the library."""
+    import subprocess
+    from poseestimation_amd import _lib
+    wrappers = legacy_wrappers()
+    assert wrappers == sorted(_lib.LEGACY_INLINE) and len(wrappers) == 12
+    exported = subprocess.run(["nm", "-D", "--defined-only", built_library], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(so3_[a-z0-9_]+)\b", exported))
+    assert not (exported & set(wrappers)), exported & set(wrappers)
+    assert exported == set(header_symbols())                      # nothing undeclared is exported either
+    for name in ("so3_frob_fwd_bwd_v2_f32", "so3_frob_fwd_bwd_v2_bf16", "so3_frob_loss_v2_f32", "so3_angle_error_v2", "so3_project_angle_error_v2_f32"):
+        assert name in exported
+    lib = _lib.load()                                             # the Python side mirrors the header's wrappers for this round
+    assert all(callable(getattr(lib, w)) for w in wrappers)
 
 
 def test_binding_table_matches_header(built_library):

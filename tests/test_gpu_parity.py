@@ -869,11 +869,16 @@ def test_cpp_autograd_node_equals_the_python_function(rr, dtype, b):
     assert "FrobeniusHeadNode" not in lg.grad_fn.name()
     lg.backward()
     assert tg.grad is not None and xg.grad is not None
-    # double backward is refused, as by the Python class
-    xd = x.clone().requires_grad_(True)
-    ld, _ = rr.frobenius_head(xd, t)
-    with pytest.raises(RuntimeError, match="differentiate twice"):
-        torch.autograd.grad(ld, xd, create_graph=True)
+    # double backward is refused under once_differentiable's own condition -- grad mode on AND a cotangent that requires grad;
+    # create_graph=True alone (a gradient penalty elsewhere in the graph) gives the ordinary gradient, as a constant
+    for head in (lambda xx: rr.frobenius_head(xx, t)[0], lambda xx: rr._FrobeniusHead.apply(xx, t, True, [])):
+        xd = x.clone().requires_grad_(True)
+        (g_plain,) = torch.autograd.grad(head(xd), xd)
+        (g_cg,) = torch.autograd.grad(head(xd), xd, create_graph=True)
+        assert torch.equal(g_cg, g_plain) and not g_cg.requires_grad
+        go = torch.ones((), device=DEV, requires_grad=True)
+        with pytest.raises(RuntimeError, match="differentiate twice"):
+            torch.autograd.grad(head(xd), xd, grad_outputs=go, create_graph=True)
 
 
 @pytest.mark.parametrize("dtype,b", [(torch.bfloat16, 512), (torch.float32, 512), (torch.float32, 3), (torch.float32, 70_000)])
@@ -915,10 +920,22 @@ def test_cpp_nodes_of_the_two_call_spelling_equal_the_python_functions(rr, dtype
     assert "ProjectNode" not in rr.symmetric_orthogonalization(x.half().requires_grad_(True)).grad_fn.name()
     assert rr.symmetric_orthogonalization(x).grad_fn is None
     xd = x.float().clone().requires_grad_(True)
+    (g_plain,) = torch.autograd.grad(rr.symmetric_orthogonalization(xd).sum(), xd)
+    (g_cg,) = torch.autograd.grad(rr.symmetric_orthogonalization(xd).sum(), xd, create_graph=True)      # .sum()'s backward hands over a constant
+    assert torch.equal(g_cg, g_plain) and not g_cg.requires_grad
+    go = torch.ones((), device=DEV, requires_grad=True)
     with pytest.raises(RuntimeError, match="differentiate twice"):
-        torch.autograd.grad(rr.symmetric_orthogonalization(xd).sum(), xd, create_graph=True)
+        torch.autograd.grad(rr.symmetric_orthogonalization(xd).sum(), xd, grad_outputs=go, create_graph=True)
     with pytest.raises(RuntimeError, match="differentiate twice"):
-        torch.autograd.grad(rr.loss_frobenius(t, a), a, create_graph=True)
+        torch.autograd.grad(rr.loss_frobenius(t, a), a, grad_outputs=go, create_graph=True)
+    # a gradient penalty on ANOTHER branch of the graph: the heads' backward runs under create_graph=True and must not object
+    w = torch.randn(9, device=DEV, generator=gen, requires_grad=True)
+    xd2 = x.float().clone().requires_grad_(True)
+    total = rr.loss_frobenius(t, rr.symmetric_orthogonalization(xd2)) + ((xd2 * w).sum()) ** 2
+    (gx,) = torch.autograd.grad(total, xd2, create_graph=True)
+    assert gx.requires_grad                                               # through the penalty branch only
+    gx.pow(2).sum().backward()
+    assert w.grad is not None and torch.isfinite(w.grad).all()
 
 
 @pytest.mark.parametrize("name,width,cls", [("compute_rotation_matrix_from_ortho6d", 6, "_Ortho6d"), ("compute_rotation_matrix_from_quaternion", 4, "_Quat"),
@@ -1650,6 +1667,115 @@ def test_fused_head_angle_error_matches_two_kernel_path(rr):
     assert (r - rr.symmetric_orthogonalization(x[:1000])).abs().max().item() == 0
     with pytest.raises(ValueError, match="angle out of range"):
         rr.head_angle_error(x[:128], 1.7 * t[:128])
+
+
+def _haar(n, gen):
+    q = torch.randn(n, 4, device=DEV, generator=gen)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+
+
+def test_fused_evaluation_sum_float32_outside_the_band_float64_inside(rr):
+    """The reduced forms of head_angle_error (3D-Pose/main.py:60-62: `angle_error(func[rot_rep](out), R).mean()`) run the
+    reference's expression in float32 for rows whose cosine is at least 5e-7 away from +-1 and in float64 inside that band
+    (so3::angle_sum_f32).  Against `angle_error(...).mean()` -- float64 on every row, pinned to the reference by G3 / G6:
+      * 1M Haar-like pairs (G6's rows) and 16M rows: |difference of the means| <= 1e-6 degrees;
+      * rows AT the ill-conditioned ends (G3's 0 / 180 degree pairs and its 1e-4 rad pair: inside the band): equal to 1e-9;
+      * G3 as a whole (it also holds a pair 3e-3 rad apart, outside the band, where one float32 ulp of the trace is worth
+        2e-3 degrees on that row): <= 2e-5 degrees on the mean;
+      * every pair 0.3 / 3 / 30 degrees apart (a trained network's regime): <= 5e-6 degrees;
+      * exact=True: 1e-9 everywhere;  the range check raises on G3's bad pairs, not on its nearly-proper ones;  NaN stays NaN."""
+    g6 = load_golden("g6_stats_1m.npz")
+    n = int(g6["n"])
+    torch.manual_seed(int(g6["seed_x"]))
+    x = torch.randn(n, 9).to(DEV)
+    torch.manual_seed(int(g6["seed_t"]))
+    t = rr.symmetric_orthogonalization(torch.randn(n, 9).to(DEV))
+    ref = rr.angle_error(rr.symmetric_orthogonalization(x), t).mean().item()
+    got = rr.head_angle_error(x, t, reduce="mean").item()
+    exact = rr.head_angle_error(x, t, reduce="mean", exact=True).item()
+    report = {"1M": got - ref}
+    assert abs(exact - ref) < 1e-9 and abs(got - ref) <= 1e-6, (got - ref, exact - ref)
+    assert abs(got - float(g6["mean_angle_deg"])) < 1e-4                        # and the BASELINE parity metric against the reference's number
+    # 16M rows (config #5's size on one device), in four slices for the float64 reference's per-row vector
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    n16 = 16_000_000
+    x16 = torch.randn(n16, 9, device=DEV, generator=gen)
+    t16 = _haar(n16, gen)
+    sc = rr.head_angle_error(x16, t16, reduce="sum_count")
+    ref_sum = 0.0
+    for lo in range(0, n16, 4_000_000):
+        ref_sum += rr.angle_error(rr.symmetric_orthogonalization(x16[lo:lo + 4_000_000]), t16[lo:lo + 4_000_000]).sum().item()
+    report["16M"] = sc[0].item() / n16 - ref_sum / n16
+    assert sc[1].item() == n16 and abs(report["16M"]) <= 1e-6, report
+    del x16, t16
+    # G3's pairs on the engine (tiled to 2048 rows; M = r1, whose projection is the rotation itself up to round-off)
+    g3 = load_golden("g3_angles.npz")
+    r1, r2 = dev(g3["r1"]).reshape(-1, 9), dev(g3["r2"]).reshape(-1, 9)
+
+    def both(a, b_, reps):
+        a, b_ = a.repeat(reps, 1).contiguous(), b_.repeat(reps, 1).contiguous()
+        return (rr.head_angle_error(a, b_, reduce="mean").item(), rr.angle_error(rr.symmetric_orthogonalization(a), b_).mean().item(),
+                rr.head_angle_error(a, b_, reduce="mean", exact=True).item())
+    ends = both(r1[:4], r2[:4], 512)                    # 0, 180, 180 degrees and 1e-4 rad: all inside the band -> float64
+    assert abs(ends[0] - ends[1]) < 1e-9 and abs(ends[2] - ends[1]) < 1e-9, ends
+    whole = both(r1, r2, 8)
+    report["G3"] = whole[0] - whole[1]
+    assert abs(whole[0] - whole[1]) <= 2e-5 and abs(whole[2] - whole[1]) < 1e-9, whole
+    # a trained network's regime: every pair the same small angle apart
+    for deg_apart in (0.3, 3.0, 30.0):
+        m = 1 << 20
+        base = _haar(m, gen)
+        axis = torch.randn(m, 3, device=DEV, generator=gen)
+        axis = axis / axis.norm(dim=1, keepdim=True) * (deg_apart * torch.pi / 180.0)
+        tt = torch.bmm(base.view(m, 3, 3), rr.so3_exp_map(axis)).reshape(m, 9).contiguous()
+        f32 = rr.head_angle_error(base, tt, reduce="mean").item()
+        f64 = rr.angle_error(rr.symmetric_orthogonalization(base), tt).mean().item()
+        report["%g deg" % deg_apart] = f32 - f64
+        assert abs(f32 - f64) <= 5e-6 and abs(f64 - deg_apart) < 2e-2, (deg_apart, f32, f64, report)
+    # the reference's range check, on the float32 cosine
+    bad1, bad2 = dev(g3["bad1"]).reshape(-1, 9).repeat(700, 1).contiguous(), dev(g3["bad2"]).reshape(-1, 9).repeat(700, 1).contiguous()
+    with pytest.raises(ValueError, match="angle out of range, input probably not proper rotation matrices"):
+        rr.head_angle_error(bad1, bad2, reduce="mean")
+    near1, near2 = dev(g3["nearly1"]).reshape(-1, 9).repeat(1024, 1).contiguous(), dev(g3["nearly2"]).reshape(-1, 9).repeat(1024, 1).contiguous()
+    assert rr.head_angle_error(near1, near2, reduce="mean").item() == 0.0          # cos 1.075: inside the tolerance band, clamped
+    xn = x[:4096].clone()
+    xn[77, 3] = float("nan")
+    assert np.isnan(rr.head_angle_error(xn, t[:4096], reduce="mean").item())
+    # the caller-owned workspace finishes the float32 sum like the atomics do (same partials, a fixed order)
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    ws = torch.zeros(lib.so3_reduce_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    sc_ws = torch.empty(2, dtype=torch.float64, device=DEV)
+    fl = torch.empty(1, dtype=torch.int32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    for flags in (0, _lib.RADIANS):
+        assert lib.so3_project_angle_error_v2_f32(x.data_ptr(), t.data_ptr(), None, None, sc_ws.data_ptr(), fl.data_ptr(), ws.data_ptr(), flags, n, st) == 0
+        unit = 1.0 if flags else 180.0 / np.pi
+        assert sc_ws[1].item() == n and fl.item() == 0 and abs(sc_ws[0].item() / n - got / (180.0 / np.pi) * unit) < 1e-10
+    assert int(torch.count_nonzero(ws).item()) == 0
+    print("float32 angle sum minus float64, degrees:", report)
+
+
+def test_zero_pool_is_per_stream(rr):
+    """The metric kernels' pre-zeroed accumulator slots come from a pool per (device, stream): a kernel on a side stream must
+    never add into slots whose zero-fill was enqueued on another stream (the advisor's round-3 finding)."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    a, b_ = _haar(200_000, gen), _haar(200_000, gen)
+    ref = rr.angle_error_sum_count(a, b_)[0].item()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    torch.cuda.current_stream().synchronize()
+    outs = []
+    with torch.cuda.stream(side):
+        for _ in range(300):                                  # more than one pool's worth of slots, all on the side stream
+            outs.append(rr.angle_error_sum_count(a, b_, check=False))
+    side.synchronize()
+    pools = rr._ZERO_POOL.pools
+    assert any(k[1] == side.cuda_stream for k in pools) and any(k[1] == torch.cuda.current_stream().cuda_stream for k in pools)
+    assert all(abs(o[0].item() - ref) < 1e-6 and o[1].item() == 200_000 for o in outs)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -74,7 +74,10 @@ def main():
     pool = torch.zeros(4096, 4, dtype=torch.float64, device=dev)
     slot = lambda i: (P(pool[i % 4096].data_ptr()), P(pool[i % 4096].data_ptr() + 16))
     timeit("K4 so3_angle_error_acc (fused sum,count, zeroed slots)", lambda i: lib.so3_angle_error_acc(p(r[i % NB]), p(rt[i % NB]), None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
-    timeit("K1+K4 so3_project_angle_error_acc_f32 (sum,count, zeroed slots)", lambda i: lib.so3_project_angle_error_acc_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_acc_f32 (sum: float64 on every row, zeroed slots)", lambda i: lib.so3_project_angle_error_acc_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
+    f32sum = _lib.PREZEROED
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, zeroed slots)", lambda i: lib.so3_project_angle_error_v2_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], None, f32sum, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, workspace)", lambda i: lib.so3_project_angle_error_v2_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), p(ws), 0, n, st), 72 * n)
     timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
     timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
     timeit("K1+K4 so3_project_angle_error_f32 (fused sum,count)", lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st), 72 * n)
