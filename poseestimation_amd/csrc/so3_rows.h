@@ -238,9 +238,9 @@ template <int NPL> struct RowCtx {
     bool flag;              // per-lane sticky flag (K4: cosine out of range)
     const char *img1;       // LDS image of the second input's block (operations with kLateIn1 read their rows from it themselves)
     char *slot;             // the wave's LDS slot: free between take_rows and put_rows (the inputs have left, the outputs are not staged yet)
-    char *scratch;          // the wave's Op::kWaveScratch bytes of LDS, kept across its rounds (K1: the queue of hard rows)
-    int pending;            // wave-uniform state that goes with it (K1: how many rows the queue holds)
     int dense;              // wave-uniform (K1): 1 = the wave's last round was dense in hard rows, 2 = so were earlier ones and the shortcut was refused
+    float *park;            // Op::kParkWords > 0: the workgroup's list of parked hard rows (LDS, see park_hard_rows) ...
+    unsigned *park_count;   // ... and how many it holds
     int n_half, n_pi;       // wave-uniform (the float32 angle sum, angle_sum_f32): rows of this wave whose angle is pi/2 - r, pi - 2r
 };
 
@@ -288,7 +288,10 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     constexpr int kOutBytes = kOut0B + kOut1B;
     constexpr int kSlot = kInBytes > kOutBytes ? kInBytes : kOutBytes;
     __shared__ __attribute__((aligned(16))) char lds[kWaves][kSlot];
-    __shared__ __attribute__((aligned(16))) char scratch[kWaves][Op::kWaveScratch > 0 ? Op::kWaveScratch : 4];
+    // Op::kParkWords > 0: the rows the operation's fast path cannot serve and that are FEW in their round wait here, inputs and
+    // row number, word w of entry e at [w * kParkCap + e]; Op::redo_parked runs on them when the workgroup has streamed its share
+    __shared__ float park[Op::kParkWords > 0 ? (Op::kParkWords + 2) * Op::kParkCap : 1];
+    __shared__ unsigned park_count;
     __shared__ double red[Op::kReduce ? kWaves : 1];
     __shared__ int red_flag[Op::kReduce ? kWaves : 1];
 
@@ -306,9 +309,13 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.flag = false;
     ctx.img1 = nullptr;
     ctx.slot = nullptr;
-    ctx.scratch = scratch[wave_in_block];
-    ctx.pending = 0;
     ctx.dense = 0;
+    ctx.park = park;
+    ctx.park_count = &park_count;
+    if constexpr (Op::kParkWords > 0) {
+        if (threadIdx.x == 0) park_count = 0;
+        __syncthreads();
+    }
     ctx.n_half = 0;
     ctx.n_pi = 0;
     if (t < nrounds) {
@@ -397,7 +404,24 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 issue(held);
             }
         }
-        if constexpr (Op::kWaveScratch > 0) op.template drain<T, NPL>(ctx);
+    }
+    if constexpr (Op::kParkWords > 0) {
+        // The workgroup has streamed its share: its parked rows are redone, 64 per wave and pass, one matrix per lane
+        // (Op::redo_parked), and their outputs overwrite what the rounds' block stores wrote for them -- every wave's stores have
+        // been performed by then, and one L2 serves the whole workgroup, so the later store lands on top.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned parked = park_count;
+        const int total = parked < static_cast<unsigned>(Op::kParkCap) ? static_cast<int>(parked) : Op::kParkCap;
+        // Pass p goes to wave (p + first) mod kWaves, `first` differing between the workgroups that share a CU (consecutive ones,
+        // or ones 256 apart): wave w of every resident workgroup sits on SIMD w, and with a few parked rows per workgroup -- one
+        // pass each -- wave 0 of all of them would queue on SIMD 0 while the other three SIMDs idle.
+        const int first = static_cast<int>((blockIdx.x + (blockIdx.x >> 8)) % kWaves);
+        for (int e0 = kUnitRows * ((wave_in_block + kWaves - first) % kWaves); e0 < total; e0 += kUnitRows * kWaves) {
+            const int ln = lane_id_now();
+            const bool valid = e0 + ln < total;
+            op.template redo_parked<NPL>(ctx, valid ? e0 + ln : e0, valid);
+        }
     }
     if (Op::kReduce) {
         double v = ctx.acc;
@@ -461,9 +485,10 @@ struct OpBase {
     // kLateIn1: the operation reads the second input's rows out of LDS itself (late_in1), where it first needs them -- for K2 / K3 /
     // K1+K4 that is AFTER the projection, whose ~110 live registers the 18 of a second input's rows would otherwise sit beside
     static constexpr bool kLateIn1 = false;
-    // kWaveScratch: bytes of LDS per wave that live across the wave's rounds (ctx.scratch); an operation that asks for them also
-    // provides drain(ctx), called once when the wave has done its last round
-    static constexpr int kWaveScratch = 0;
+    // kParkWords > 0: the operation parks the inputs of the few hard rows of a round (park_hard_rows: kParkWords words per row, at
+    // most kParkCap rows per workgroup) and provides
+    //   template <int NPL> void redo_parked(RowCtx<NPL> &, int entry, bool valid)     one row per lane, behind the loop
+    static constexpr int kParkWords = 0, kParkCap = 1;
 #ifndef SO3_HOST_MODEL
     ReduceWs *ws = nullptr;        // reduction workspace (nullptr: atomics onto host-initialised accumulators)
     unsigned ws_slot0 = 0;         // slots below this one were filled by the remainder kernel launched before the engine
@@ -474,19 +499,124 @@ struct OpBase {
 };
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
-// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path, the Jacobi path for
-// the rows it declares hard (project_rotation).
-// Hard rows are DEFERRED when they are few: a round that holds up to 16 NPL of them queues their matrices (and row numbers) in the
-// wave's scratch LDS and goes on; the Jacobi path runs once, when the wave has done its last round, on what the queue holds (64 NPL
-// rows at most), and its rotations overwrite what the rounds' block stores wrote for those rows.  A batch with 1 % or 10 % of hard
-// rows then pays for one Jacobi pass per wave instead of one per round that holds a hard row (72 % / 100 % of the rounds).  A round
-// dense in hard rows (or one the queue has no room for) takes the Jacobi path on the spot, as every such round did before.
-// A row's bits do not depend on where it waited: signed_svd executes the same IEEE operations per matrix in every lane and half.
+// ---- rows the fast path cannot serve ------------------------------------------------------------------------------------
+// The quaternion fast path (so3_device.h section 3a) declares a row HARD when it cannot certify its rotation: 1e-6 of Gaussian
+// rows, every row of a batch of reflections, ties, rank-deficient or zero matrices.  SIMT leaves no way to run the second
+// algorithm on the hard lanes alone at less than full price, so:
+//   * a round with FEW hard rows (at most 16 NPL of its 64 NPL) PARKS them -- inputs and row number, in a list the workgroup
+//     shares in LDS -- and streams on; the block store writes whatever the fast path left for them.  When the workgroup has
+//     streamed its share the list is redone, 64 rows per wave and pass, ONE matrix per lane (signed_svd<., float>: the same IEEE
+//     operations per matrix as the packed instantiation, so a row's bits do not depend on where it waited), and the results
+//     overwrite the rows.  The cost is per hard ROW: round 3 queued per wave and ran one packed Jacobi pass per wave that held any
+//     (K1; 1 % of hard rows: 1.3-1.46 x a Gaussian batch), K2 / K3 / K1+K4 paid a packed pass per ROUND that held one.
+//   * a round DENSE in hard rows (or one the list has no room for) runs the packed Jacobi path on the spot, in front of the block
+//     store, as before: parked, such rows would be stored twice, the second time four bytes per lane and store.
+// (Built and measured first: row NUMBERS parked instead of inputs, every hard row redone from memory behind the loop, no Jacobi
+// code in any loop -- profiles/r04_row_number_queue*: the redo waits for its re-read inputs and for the round's stores, 10 % of
+// hard rows 1.8 x, whole batches 2.0-2.3 x.  The same experiment showed K2 at three waves per SIMD, spill-free, no faster than at two.)
+template <int CAP> __device__ __forceinline__ int park_reserve(unsigned *count, int n) {
+    int base = 0;
+    if (lane_id_now() == 0) {
+        // a reservation that does not fit is taken back at once; while it stands the count exceeds CAP, so nobody else's succeeds
+        // and the list never has a hole
+        const unsigned old = atomicAdd(count, static_cast<unsigned>(n));
+        base = old + static_cast<unsigned>(n) <= static_cast<unsigned>(CAP) ? static_cast<int>(old) : -1;
+        if (base < 0) atomicSub(count, static_cast<unsigned>(n));
+    }
+    return __builtin_amdgcn_readfirstlane(base);
+}
+// How many hard rows the round holds (wave-uniform), and the list entry of each hard lane-half given the round's first entry.
+template <class T, int NPL>
+__device__ __forceinline__ int count_hard(const RowCtx<NPL> &ctx, typename Tr<T>::mask hard) {
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) n += __builtin_popcountll(__builtin_amdgcn_ballot_w64(Tr<T>::lane_of(hard, k) && ctx.exists[k]));
+    return n;
+}
+// words [w0, w0 + N) of the round's parked rows <- v;  ROW: and the row number (two words behind the operation's WORDS)
+template <class T, int NPL, int CAP, int WORDS, bool ROW, int N>
+__device__ __forceinline__ void park_words(const RowCtx<NPL> &ctx, int base, typename Tr<T>::mask hard, int w0, const T (&v)[N]) {
+    const int lane = lane_id_now();
+    int at = base;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const bool mine = Tr<T>::lane_of(hard, k) && ctx.exists[k];
+        const unsigned long long votes = __builtin_amdgcn_ballot_w64(mine);
+        if (mine) {
+            const int e = at + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(votes >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(votes), 0u)));
+#pragma unroll
+            for (int i = 0; i < N; ++i) ctx.park[(w0 + i) * CAP + e] = Tr<T>::get(v[i], k);
+            if (ROW) {
+                const long long row = ctx.unit[k] * kUnitRows + lane;
+                ctx.park[WORDS * CAP + e] = __int_as_float(static_cast<int>(row & 0xffffffffll));
+                ctx.park[(WORDS + 1) * CAP + e] = __int_as_float(static_cast<int>(row >> 32));
+            }
+        }
+        at += __builtin_popcountll(votes);
+    }
+}
+template <int CAP, int WORDS> __device__ __forceinline__ long long parked_row(const float *park, int e) {
+    return static_cast<long long>(static_cast<unsigned>(__float_as_int(park[WORDS * CAP + e]))) | (static_cast<long long>(__float_as_int(park[(WORDS + 1) * CAP + e])) << 32);
+}
+template <int CAP, int N> __device__ __forceinline__ void parked_words(const float *park, int e, int w0, float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = park[(w0 + i) * CAP + e];
+}
+// One row of an output array by its number, for the redo pass (EB: 4 = float32, 2 = bfloat16).  A float32 row leaves as three
+// 12-byte stores with the default cache policy: the row is a PARTIAL write into lines the block store has streamed out already, and
+// nine non-temporal dword stores per row (round 3's flush) are nine read-modify-writes at the memory side -- with 10 % of hard
+// rows that alone was a third of the launch.
+typedef float f32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+template <int EB, int N> __device__ __forceinline__ void overwrite_row(void *base, long long row, const float (&m)[N]) {
+    if constexpr (EB == 4 && N % 3 == 0) {
+        float *p = static_cast<float *>(base) + row * N;
+#pragma unroll
+        for (int i = 0; i < N; i += 3) {
+            const f32x3_a4 v = {m[i], m[i + 1], m[i + 2]};
+            *reinterpret_cast<f32x3_a4 *>(p + i) = v;
+        }
+    } else if constexpr (EB == 4) {
+        float *p = static_cast<float *>(base) + row * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = m[i];
+    } else {
+        uint16_t *p = static_cast<uint16_t *>(base) + row * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = f32_to_bf16_bits(m[i]);
+    }
+}
+// The decision of a round that holds hard rows: -1 = dense (or no room): the caller runs the Jacobi path on the spot; otherwise the
+// round's first entry in the workgroup's list, where the caller parks the rows' inputs and numbers (park_words).
+template <class T, int NPL, int CAP>
+__device__ __forceinline__ int park_hard_rows(const RowCtx<NPL> &ctx, typename Tr<T>::mask hard, bool *dense = nullptr) {
+    const int n = count_hard<T, NPL>(ctx, hard);
+    if (dense != nullptr) *dense = n > 16 * NPL;
+    if (n > 16 * NPL) return -1;
+    return park_reserve<CAP>(ctx.park_count, n);
+}
+
+// The Jacobi path's rotation for everything a lane holds, one matrix at a time through the one-matrix-per-lane instantiation (for a
+// packed pair: two passes of ~570 plain instructions instead of one of ~570 mostly packed ones, +10 % in cycles) -- where the
+// packed body's 150 registers do not fit beside what the loop keeps live (K1 at three waves per SIMD: the packed body spilled 20
+// registers around its peak, and a dense batch paid for the scratch traffic).  Same bits either way.
+template <class T> __device__ __forceinline__ void jacobi_rotation_by_halves(const T (&m)[9], T (&rj)[9]) {
+#pragma unroll
+    for (int k = 0; k < Tr<T>::kLanes; ++k) {
+        float mk_[9], rk_[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) mk_[i] = Tr<T>::get(m[i], k);
+        rotation_from(signed_svd<false, float>(mk_), rk_);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Tr<T>::set(rj[i], k, rk_[i]);
+    }
+}
+
+// K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path; its hard rows parked, or
+// through the packed Jacobi path on the spot when the round is dense in them.
 template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
-    static constexpr int kQueueWords = 11;                                  // 9 entries + the row number (two dwords)
-    static constexpr int kWaveScratch = kQueueWords * 128 * 4;   // room for 64 NPL rows, NPL <= 2; word w of entry e at 4 (128 w + e)
+    static constexpr int kParkWords = 9, kParkCap = 512;                    // 22 KB of LDS per workgroup
     uint8_t *flip = nullptr;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {
@@ -504,25 +634,30 @@ struct OpProject : OpBase {
             }
         }
         // After a round dense in hard rows the next one is asked first whether ALL its rows are hard by their invariants alone
-        // (a batch of reflections, ties or rank-one rows): then it takes the Jacobi path without running the fast path at all.
+        // (a batch of reflections, rank-one or zero rows): then it takes the Jacobi path without running the fast path at all.
         if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
             rotation_from(signed_svd<false, T>(m), r);
-        } else {
-            const int asked = ctx.dense;                 // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
-            const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
-            ctx.dense = 0;
-            if (__builtin_expect(wave_any(R::any(hard)), 0) && defer<T, NPL>(ctx, m, hard, asked)) {
-                // a round dense in hard rows (or a full queue): the Jacobi path here, on the round itself, as before round 3's queue --
-                // queued, such rows would be stored twice, the second time 4 bytes per lane and store.  The fast path's rotations wait
-                // in the wave's LDS slot meanwhile (the round's inputs have left it, its outputs are not staged yet): 18 registers
-                // that the Jacobi path's peak would otherwise sit on top of.
+            return;
+        }
+        const int asked = ctx.dense;                     // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
+        const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
+        ctx.dense = 0;
+        if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+            bool dense;
+            const int base = park_hard_rows<T, NPL, kParkCap>(ctx, hard, &dense);
+            ctx.dense = dense ? (asked != 0 ? 2 : 1) : 0;
+            if (base >= 0) {
+                park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, hard, 0, m);
+            } else {
+                // The fast path's rotations wait in the wave's LDS slot meanwhile (the round's inputs have left it, its outputs are
+                // not staged yet): 18 registers that the Jacobi path's peak would otherwise sit on top of.
                 typedef UnitIO<4, 9, NPL> Stash;
                 const int lane = lane_id_now();
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) Stash::write_row(ctx.slot, k, lane, k, r);
                 wave_lds_fence();                                // (also keeps the compiler from forwarding the stores to the loads below)
                 T rj[9];
-                rotation_from(signed_svd<false, T>(m), rj);
+                jacobi_rotation_by_halves<T>(m, rj);
                 wave_lds_fence();
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) Stash::read_row(ctx.slot, k, lane, k, r);
@@ -531,90 +666,50 @@ struct OpProject : OpBase {
             }
         }
     }
-    // queue the round's hard rows (the block store writes whatever the fast path left for them; flush() overwrites it); true if
-    // the round has to take the Jacobi path on the spot instead
-    template <class T, int NPL>
-    __device__ __forceinline__ bool defer(RowCtx<NPL> &ctx, const T (&m)[9], typename Tr<T>::mask hard, int asked) const {
-        unsigned long long votes[NPL];
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            votes[k] = __builtin_amdgcn_ballot_w64(Tr<T>::lane_of(hard, k) && ctx.exists[k]);
-            n += __builtin_popcountll(votes[k]);
-        }
-        ctx.dense = n > 16 * NPL ? (asked != 0 ? 2 : 1) : 0;
-        if (n > 16 * NPL || ctx.pending + n > 64 * NPL) return true;
-        const int lane = lane_id_now();
-        float *q = reinterpret_cast<float *>(ctx.scratch);
-        int at = ctx.pending;
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            if (Tr<T>::lane_of(hard, k) && ctx.exists[k]) {
-                const unsigned lo = static_cast<unsigned>(votes[k]), hi = static_cast<unsigned>(votes[k] >> 32);
-                const int e = at + static_cast<int>(__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u)));
-#pragma unroll
-                for (int i = 0; i < 9; ++i) q[128 * i + e] = Tr<T>::get(m[i], k);
-                const long long row = ctx.unit[k] * kUnitRows + lane;
-                q[128 * 9 + e] = __int_as_float(static_cast<int>(row & 0xffffffffll));
-                q[128 * 10 + e] = __int_as_float(static_cast<int>(row >> 32));
-            }
-            at += __builtin_popcountll(votes[k]);
-        }
-        ctx.pending = at;
-        return false;
-    }
-    // the Jacobi path on everything the queue holds; lane l takes entries l and (NPL = 2) 64 + l
-    template <class T, int NPL>
-    __device__ __forceinline__ void flush(RowCtx<NPL> &ctx) const {
-        wave_lds_fence();
-        const int lane = lane_id_now();
-        const float *q = reinterpret_cast<const float *>(ctx.scratch);
-        const int count = ctx.pending;
-        T m[9];
-        long long row[NPL];
-        bool valid[NPL];
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const int e = 64 * k + lane;
-            valid[k] = e < count;
-            const int src = valid[k] ? e : 0;                   // an empty slot works on entry 0 (there is one); its result is dropped
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Tr<T>::set(m[i], k, q[128 * i + src]);
-            row[k] = static_cast<long long>(static_cast<unsigned>(__float_as_int(q[128 * 9 + src])))
-                     | (static_cast<long long>(__float_as_int(q[128 * 10 + src])) << 32);
-        }
-        wave_lds_fence();
-        T r[9];
-        rotation_from(signed_svd<false, T>(m), r);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the block stores that wrote these rows first have been performed
-        float *out = static_cast<float *>(out0);
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            if (valid[k]) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) __builtin_nontemporal_store(Tr<T>::get(r[i], k), out + row[k] * 9 + i);
-            }
-        }
-        ctx.pending = 0;
-    }
-    template <class T, int NPL>
-    __device__ __forceinline__ void drain(RowCtx<NPL> &ctx) const {
-        if (ctx.pending > 0) flush<T, NPL>(ctx);
+    template <int NPL>
+    __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+        float m[9], r[9];
+        parked_words<kParkCap, 9>(ctx.park, e, 0, m);
+        rotation_from(signed_svd<false, float>(m), r);
+        if (valid) overwrite_row<4, 9>(out0, parked_row<kParkCap, kParkWords>(ctx.park, e), r);
     }
 };
 
-// K2: dM = U' Bm V^T for upstream G (autograd of K1).
+// K2: dM = U' Bm V^T for upstream G (autograd of K1): the fast path's rotation and the backward from the rotation alone (so3_device.h
+// section 3c); hard rows through the Jacobi frames and their floored denominators -- parked, or on the spot in a dense round.
 template <int M_BYTES>
 struct OpProjectBwd : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
     static constexpr bool kLateIn1 = true;
+    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and G: 20 KB of LDS per workgroup
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
         T r[9];
         HardRows<T> h;
-        project_rotation_frames<true, T>(rows.a, r, h);
+        h.hard = quat_rotation<T>(rows.a, r, &h.prescale);
+        h.any = false;
+        int base = -1;
+        if (__builtin_expect(wave_any(R::any(h.hard)), 0)) {
+            base = park_hard_rows<T, NPL, kParkCap>(ctx, h.hard);
+            if (base >= 0) {
+                park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, h.hard, 0, rows.a);
+            } else {
+                h.any = true;
+                h.frames = signed_svd<true, T>(rows.a);
+            }
+        }
         late_in1<T, OpProjectBwd, NPL>(ctx, rows.b);              // G: only now
+        if (__builtin_expect(base >= 0, 0)) park_words<T, NPL, kParkCap, kParkWords, false, 9>(ctx, base, h.hard, 9, rows.b);
         backward_given_rotation<T>(rows.a, r, rows.b, h, rows.o0);
+    }
+    template <int NPL>
+    __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+        float m[9], g[9], dm[9];
+        parked_words<kParkCap, 9>(ctx.park, e, 0, m);
+        parked_words<kParkCap, 9>(ctx.park, e, 9, g);
+        project_backward(signed_svd<true, float>(m), g, dm);
+        if (valid) overwrite_row<M_BYTES, 9>(out0, parked_row<kParkCap, kParkWords>(ctx.park, e), dm);
     }
 };
 
@@ -624,6 +719,7 @@ struct OpFrobHead : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_DM ? M_BYTES : 0, kOut1 = WANT_R ? 4 : 0;
     static constexpr bool kReduce = true;
     static constexpr bool kLateIn1 = true;
+    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and Rtrue: 20 KB of LDS per workgroup
     double *loss_sum = nullptr;
     float inv_b = 0.f;
     template <class T, int NPL>
@@ -633,10 +729,25 @@ struct OpFrobHead : OpBase {
         const T (&t)[9] = rows.b;
         T (&dm)[9] = rows.o0;
         T (&r)[9] = rows.o1;
-        HardRows<T> hard;
-        if constexpr (WANT_DM) project_rotation_frames<true, T>(m, r, hard);
-        else project_rotation_frames<false, T>(m, r, hard);
+        HardRows<T> h;
+        h.hard = quat_rotation<T>(m, r, WANT_DM ? &h.prescale : nullptr);
+        h.any = false;
+        int base = -1;
+        if (__builtin_expect(wave_any(R::any(h.hard)), 0)) {
+            base = park_hard_rows<T, NPL, kParkCap>(ctx, h.hard);
+            if (base >= 0) {
+                park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, h.hard, 0, m);
+            } else {
+                h.any = true;
+                h.frames = signed_svd<WANT_DM, T>(m);
+                T rj[9];
+                rotation_from(h.frames, rj);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) r[j] = R::sel(h.hard, rj[j], r[j]);
+            }
+        }
         late_in1<T, OpFrobHead, NPL>(ctx, rows.b);                // Rtrue: only now
+        if (__builtin_expect(base >= 0, 0)) park_words<T, NPL, kParkCap, kParkWords, false, 9>(ctx, base, h.hard, 9, t);
         T g[9];
         T n2 = R::splat(0.f);
 #pragma unroll
@@ -647,13 +758,36 @@ struct OpFrobHead : OpBase {
         const T inv = R::rsq(R::max(n2, R::splat(1e-37f)));
         const T nrm = n2 * inv;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k)
-            if (ctx.exists[k]) ctx.acc += static_cast<double>(R::get(nrm, k));
+        for (int k = 0; k < NPL; ++k)                     // (a parked row's loss is added when it is redone)
+            if (ctx.exists[k] && !(base >= 0 && R::lane_of(h.hard, k))) ctx.acc += static_cast<double>(R::get(nrm, k));
         if (WANT_DM) {
             const T gs = R::sel(R::gt(n2, R::splat(0.f)), inv * R::splat(inv_b), R::splat(0.f));   // zero difference -> zero gradient
 #pragma unroll
             for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
-            backward_given_rotation<T>(m, r, g, hard, dm);
+            backward_given_rotation<T>(m, r, g, h, dm);
+        }
+    }
+    template <int NPL>
+    __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+        float m[9], t[9], r[9], g[9];
+        parked_words<kParkCap, 9>(ctx.park, e, 0, m);
+        parked_words<kParkCap, 9>(ctx.park, e, 9, t);
+        const long long row = parked_row<kParkCap, kParkWords>(ctx.park, e);
+        const SignedSvd<float> f = signed_svd<WANT_DM, float>(m);
+        rotation_from(f, r);
+        float n2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { g[i] = r[i] - t[i]; n2 = fmaf(g[i], g[i], n2); }
+        const float inv = hw::rsq(fmaxf(n2, 1e-37f));
+        if (valid) ctx.acc += static_cast<double>(n2 * inv);
+        if (WANT_R && valid) overwrite_row<4, 9>(out1, row, r);
+        if (WANT_DM) {
+            const float gs = n2 > 0.f ? inv * inv_b : 0.f;
+            float dm[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) g[i] = g[i] * gs;
+            project_backward(f, g, dm);
+            if (valid) overwrite_row<M_BYTES, 9>(out0, row, dm);
         }
     }
     float *loss_mean = nullptr;
@@ -778,8 +912,9 @@ struct OpAngle : OpBase {
 // branch (Haar-distributed pairs: one round of 128 rows in twelve) and per row: a row's contribution does not depend on its
 // wave-mates.  Outside that band a row's angle differs from the float64 one by at most 2e-7 / sin(theta) rad, without bias
 // (round-to-nearest), 3e-8 degrees in the mean of 1M Haar pairs.  The range test (cos outside [-1.1, 1.1]) runs on the float32 cosine.
+// `skip`: rows that do not count here (the fast path's hard rows: their angle comes from the redo pass).
 template <class T, int NPL>
-__device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], RowCtx<NPL> &ctx) {
+__device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], typename Tr<T>::mask skip, RowCtx<NPL> &ctx) {
     typedef Tr<T> R;
     T tr = a[0] * b[0];
 #pragma unroll
@@ -806,11 +941,12 @@ __device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], 
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         if (!ctx.exists[k]) continue;                                   // wave-uniform: the phantom unit of an odd tail
-        ctx.acc += static_cast<double>(R::get(rm, k));
-        ctx.flag |= R::lane_of(out, k);
-        ctx.n_half += __builtin_popcountll(__builtin_amdgcn_ballot_w64(R::lane_of(small, k)));
-        ctx.n_pi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(!R::lane_of(small, k) && R::lane_of(neg, k)));
-        any_band |= wave_any(R::lane_of(band, k));
+        const bool counts = !R::lane_of(skip, k);
+        ctx.acc += counts ? static_cast<double>(R::get(rm, k)) : 0.0;
+        ctx.flag |= counts && R::lane_of(out, k);
+        ctx.n_half += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counts && R::lane_of(small, k)));
+        ctx.n_pi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counts && !R::lane_of(small, k) && R::lane_of(neg, k)));
+        any_band |= wave_any(counts && R::lane_of(band, k));
     }
     if (__builtin_expect(any_band, 0)) {
 #pragma unroll
@@ -822,7 +958,7 @@ __device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], 
             // what the row has contributed above is K + rm with K = 0 or pi: replace it by the float64 angle
             const double base = R::lane_of(neg, k) ? 3.14159265358979323846 : 0.0;
             const double corr = acos_f64(c64) - base - static_cast<double>(R::get(rm, k));
-            if (ctx.exists[k] && R::lane_of(band, k)) ctx.acc += corr;
+            if (ctx.exists[k] && R::lane_of(band, k) && !R::lane_of(skip, k)) ctx.acc += corr;
         }
     }
 }
@@ -837,21 +973,38 @@ struct OpProjectAngle : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_R ? 4 : 0, kOut1 = 0;
     static constexpr bool kReduce = true;
     static constexpr bool kLateIn1 = true;
+    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and Rtrue: 20 KB of LDS per workgroup
     static constexpr bool kAngleConstants = F32SUM;
     double *deg = nullptr, *sum_count = nullptr;
     int32_t *range_flag = nullptr;
     double unit_scale = 1.0;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProjectAngle> &rows, RowCtx<NPL> &ctx) const {
+        typedef Tr<T> R;
         T r[9];
-        project_rotation<T>(rows.a, r);
+        const typename R::mask hard = quat_rotation<T>(rows.a, r);
+        int base = -1;
+        if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+            base = park_hard_rows<T, NPL, kParkCap>(ctx, hard);
+            if (base >= 0) {
+                park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, hard, 0, rows.a);
+            } else {
+                T rj[9];
+                rotation_from(signed_svd<false, T>(rows.a), rj);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) r[j] = R::sel(hard, rj[j], r[j]);
+            }
+        }
         late_in1<T, OpProjectAngle, NPL>(ctx, rows.b);            // Rtrue: only now
+        if (__builtin_expect(base >= 0, 0)) park_words<T, NPL, kParkCap, kParkWords, false, 9>(ctx, base, hard, 9, rows.b);
+        // rows that do not count here: the parked ones (their rotation is not in r; redo_parked answers for them)
+        const typename R::mask skip = base >= 0 ? hard : R::gt(R::splat(0.f), R::splat(1.f));
         if (WANT_R) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) rows.o0[i] = r[i];
         }
         if constexpr (F32SUM) {
-            angle_sum_f32<T, NPL>(r, rows.b, ctx);           // radians; finish() scales the workgroup's total
+            angle_sum_f32<T, NPL>(r, rows.b, skip, ctx);     // radians; scale_partial() turns the workgroup's total into the unit asked for
             return;
         }
 #pragma unroll
@@ -860,7 +1013,8 @@ struct OpProjectAngle : OpBase {
 #pragma unroll
             for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(Tr<T>::get(r[i], k)), static_cast<double>(Tr<T>::get(rows.b[i], k)), tr);
             const double c_raw = (tr - 1.0) * 0.5;
-            if (ctx.exists[k]) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
+            const bool counts = ctx.exists[k] && !R::lane_of(skip, k);
+            if (counts) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
             double c = fmin(fmax(c_raw, -1.0), 1.0);
             if (c_raw != c_raw) c = c_raw;
             const double ang = acos_f64(c) * unit_scale;
@@ -868,8 +1022,27 @@ struct OpProjectAngle : OpBase {
                 const u32x2 bits = __builtin_bit_cast(u32x2, ang);
                 __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc<8>(deg, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane * 8, 0, 0);
             }
-            if (WANT_SUM && ctx.exists[k]) ctx.acc += ang;
+            if (WANT_SUM && counts) ctx.acc += ang;
         }
+    }
+    template <int NPL>
+    __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+        float m[9], t[9], r[9];
+        parked_words<kParkCap, 9>(ctx.park, e, 0, m);
+        parked_words<kParkCap, 9>(ctx.park, e, 9, t);
+        const long long row = parked_row<kParkCap, kParkWords>(ctx.park, e);
+        rotation_from(signed_svd<false, float>(m), r);
+        if (WANT_R && valid) overwrite_row<4, 9>(out0, row, r);
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(r[i]), static_cast<double>(t[i]), tr);
+        const double c_raw = (tr - 1.0) * 0.5;
+        if (valid) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
+        double c = fmin(fmax(c_raw, -1.0), 1.0);
+        if (c_raw != c_raw) c = c_raw;
+        const double rad = acos_f64(c);
+        if (WANT_DEG && valid) __builtin_nontemporal_store(rad * unit_scale, deg + row);
+        if (WANT_SUM && valid) ctx.acc += F32SUM ? rad : rad * unit_scale;          // (the float32 sum is in radians until scale_partial)
     }
     double count = 0.0;
     bool store_count = false;      // accumulators pre-zeroed by the caller (so3_*_acc): nobody else writes the row count

@@ -1349,6 +1349,22 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restr
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
 inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); return t < 2048u ? t : 2048u; }
 
+// Resident waves per SIMD the two-input kernels K2 / K3 / K1+K4 are built for (K1 runs at 3): their rare Jacobi branch keeps the frames
+// live across the backward (190-216 VGPRs).  Round 4 measured what three waves would buy with that branch out of the loop
+// (profiles/r04_row_number_queue_ab.txt): K2 at 168 VGPRs, spill-free, 22.10 us against 22.01 us at two -- occupancy is not what bounds it.
+#ifndef SO3_WPS_K2
+#define SO3_WPS_K2 2
+#endif
+#ifndef SO3_WPS_K3
+#define SO3_WPS_K3 2
+#endif
+#ifndef SO3_WPS_K14
+#define SO3_WPS_K14 2
+#endif
+#ifndef SO3_NPL_K14
+#define SO3_NPL_K14 2
+#endif
+
 #define SO3_CHECK_ARGS(cond, name) \
     do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
 #define SO3_MAX_B (INT64_C(2147483647) * kBlock)
@@ -1475,7 +1491,7 @@ int project_bwd(const void *M, const float *G, void *dM, int64_t B, void *stream
     const int64_t nunits = stream_units(B, {M, G, dM});
     if (nunits > 0) {
         so3::OpProjectBwd<EB> op; op.in0 = M; op.in1 = G; op.out0 = dM;
-        launch_rows<2, 2, 256>(op, nunits, s);      // measured against <1,4>, <1,5>, <2,3>: 23.7 vs 26.6 / 26.5 / 24.5 us per 1M rows
+        launch_rows<2, SO3_WPS_K2, 256>(op, nunits, s);
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
@@ -1547,7 +1563,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (nunits > 0) {
 #define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
                              op.loss_sum = loss_sum; op.inv_b = inv_b; op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); \
-                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, SO3_WPS_K3, 256>(op, nunits, s); } while (0)
         if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
@@ -1747,7 +1763,7 @@ int so3_project_angle_error_v2_f32(const float *M, const float *Rtrue, float *R,
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS, F32) do { so3::OpProjectAngle<4, WR, WD, WS, F32> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
                                  op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
-                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, 2, 256>(op, nunits, s); } while (0)
+                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<SO3_NPL_K14, SO3_WPS_K14, 256>(op, nunits, s); } while (0)
         // the sum without per-row angles: float32 trace and acos outside the band around +-1 (so3::angle_sum_f32) unless SO3_EXACT_F64
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true, false); else if (deg) SLAUNCH(WR, true, false, false); \
                        else if (sum_count && !exact) SLAUNCH(WR, false, true, true); else if (sum_count) SLAUNCH(WR, false, true, false); \

@@ -1839,8 +1839,10 @@ def test_small_batch_metric_is_one_launch_with_the_same_angles(rr, b):
     assert sc[1].item() == b and abs(sc[0].item() - ref_deg[:b].sum().item()) < 1e-9 * max(b, 1)
     fused = rr.head_angle_error(x[:b], t[:b])
     assert (fused - ref_deg[:b]).abs().max().item() < 1e-9
-    fsc = rr.head_angle_error(x[:b], t[:b], reduce="sum_count")
+    fsc = rr.head_angle_error(x[:b], t[:b], reduce="sum_count", exact=True)
     assert fsc[1].item() == b and abs(fsc[0].item() - ref_deg[:b].sum().item()) < 1e-8 * max(b, 1)
+    fsc = rr.head_angle_error(x[:b], t[:b], reduce="sum_count")         # above 1024 rows: float32 trace outside the band around cos = +-1
+    assert fsc[1].item() == b and abs(fsc[0].item() - ref_deg[:b].sum().item()) < (1e-8 if b <= 1024 else 5e-6) * max(b, 1)
     d2, r2 = rr.head_angle_error(x[:b], t[:b], return_rotation=True)
     assert torch.equal(r2, r[:b]) and (d2 - ref_deg[:b]).abs().max().item() < 1e-9
     with pytest.raises(ValueError, match="angle out of range"):

@@ -23,11 +23,13 @@ def rr():
 
 
 def test_hard_rows_cost_is_bounded(rr):
-    """The worst case of K1 / K3 is on record and bounded (tools/k1_hard_rows.py, profiles/r03_k1_hard_rows.txt): a batch whose
-    rows are HARD for the fast path (ties, near-reflections, rank deficiency: the packed Jacobi body runs on top of the fast
-    path for every round dense in them) costs at most 2.2 x a Gaussian batch for K1 and 1.7 x for K3 (measured: 1.5-1.9 and
-    1.3-1.45; round 2: 1.9-2.0 already at 1 % hard rows), and rows that are merely far from unit scale cost nothing extra (they
-    were hard in round 2: 1.6 x)."""
+    """The worst case of K1 / K3 is on record and bounded (tools/ab_v2.py AB_HARD=1, profiles/r04_hard_rows_ab.txt): rows that are
+    HARD for the quaternion fast path (ties, near-reflections, rank deficiency) are parked -- inputs and row number, in a list the
+    workgroup shares in LDS -- when they are few in their round, and redone one matrix per lane when the workgroup has streamed
+    its share; a round dense in them runs the Jacobi path on the spot.  Caps = the worst ratio measured over round 4's devices
+    plus ~12 %: a batch with 1 % of hard rows K1 <= 1.35 x / K3 <= 1.2 x a Gaussian batch (round 3: 1.3-1.46 / 1.3-1.5), 10 %
+    K1 <= 1.7 x / K3 <= 1.45 x, whole batches K1 <= 1.8 x (ties: 2.15 x) / K3 <= 1.6 x; zero rows (dead heads) and rows that are
+    merely far from unit scale or of rank two cost nothing extra (<= 1.15 x)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
     hr = importlib.util.module_from_spec(spec)
@@ -59,29 +61,30 @@ def test_hard_rows_cost_is_bounded(rr):
 
     def both(xs):
         k1 = timed(lambda i: lib.so3_project_fwd_f32(xs[i % nb].data_ptr(), out[i % nb].data_ptr(), None, n, st))
-        k3 = timed(lambda i: lib.so3_frob_fwd_bwd_f32(xs[i % nb].data_ptr(), rt.data_ptr(), out[i % nb].data_ptr(), dm[i % nb].data_ptr(),
-                                                      ls.data_ptr(), n, st))
+        k3 = timed(lambda i: lib.so3_frob_fwd_bwd_v2_f32(xs[i % nb].data_ptr(), rt.data_ptr(), out[i % nb].data_ptr(), dm[i % nb].data_ptr(),
+                                                         ls.data_ptr(), None, None, 0, n, st))
         return k1, k3
 
     g1, g3 = both([torch.randn(n, 9, device=DEV, generator=gen) for _ in range(nb)])
     report = {}
-    for name, cap1, cap3 in (("near-reflection", 2.2, 1.7), ("entries in {-1,0,1}", 2.2, 1.7), ("generic ties", 2.2, 1.7), ("rank one", 2.2, 1.7),
-                             ("1e5 * Gaussian", 1.15, 1.15), ("rank two", 1.15, 1.15)):
-        xs = [hr.family(name, n, torch.device(DEV), gen).reshape(n, 9).contiguous() for _ in range(nb)]
-        k1, k3 = both(xs)
-        report[name] = (round(k1 / g1, 2), round(k3 / g3, 2))
-        assert k1 <= cap1 * g1 and k3 <= cap3 * g3, (name, k1, g1, k3, g3, report)
-        del xs
-    # a batch with SOME hard rows (10 %) stays near the review's 1.6 x for K1: the engine queues them and runs the Jacobi path once
-    # per wave instead of once per round that holds one (measured 1.29-1.61 over three devices; 1.6-1.9 before the queue)
-    for name in ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one"):
-        xs = []
-        for _ in range(nb):
-            x = torch.randn(n, 9, device=DEV, generator=gen)
-            idx = torch.nonzero(torch.rand(n, device=DEV, generator=gen) < 0.10).flatten()
-            x[idx] = hr.family(name, idx.numel(), torch.device(DEV), gen).reshape(-1, 9)
-            xs.append(x)
-        k1 = timed(lambda i: lib.so3_project_fwd_f32(xs[i % nb].data_ptr(), out[i % nb].data_ptr(), None, n, st))
-        report[name + " 10 %"] = round(k1 / g1, 2)
-        assert k1 <= 1.75 * g1, (name, k1, g1, report)
-        del xs
+    hard = ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one")
+    caps = {0.01: (1.35, 1.2), 0.10: (1.7, 1.45), 1.0: (1.8, 1.6)}
+    for name in hard + ("all zero", "1e5 * Gaussian", "rank two"):
+        for share in (0.01, 0.10, 1.0):
+            xs = []
+            for _ in range(nb):
+                if share < 1.0:
+                    x = torch.randn(n, 9, device=DEV, generator=gen)
+                    idx = torch.nonzero(torch.rand(n, device=DEV, generator=gen) < share).flatten()
+                    x[idx] = hr.family(name, idx.numel(), torch.device(DEV), gen).reshape(-1, 9)
+                else:
+                    x = hr.family(name, n, torch.device(DEV), gen).reshape(n, 9).contiguous()
+                xs.append(x)
+            k1, k3 = both(xs)
+            del xs
+            cap1, cap3 = caps[share] if name in hard else (1.15, 1.15)
+            if name == "generic ties" and share == 1.0:
+                cap1 = 2.15                        # both algorithms on every row: no invariant tells a tie from a Gaussian row beforehand
+            report["%s %g %%" % (name, share * 100)] = (round(k1 / g1, 2), round(k3 / g3, 2))
+            assert k1 <= cap1 * g1 and k3 <= cap3 * g3, (name, share, k1, g1, k3, g3, report)
+    print("hard rows, (K1, K3) x Gaussian:", report)
