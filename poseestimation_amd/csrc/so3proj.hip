@@ -1361,9 +1361,6 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
 #ifndef SO3_WPS_K14
 #define SO3_WPS_K14 2
 #endif
-#ifndef SO3_NPL_K14
-#define SO3_NPL_K14 2
-#endif
 
 #define SO3_CHECK_ARGS(cond, name) \
     do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
@@ -1763,7 +1760,7 @@ int so3_project_angle_error_v2_f32(const float *M, const float *Rtrue, float *R,
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS, F32) do { so3::OpProjectAngle<4, WR, WD, WS, F32> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
                                  op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
-                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<SO3_NPL_K14, SO3_WPS_K14, 256>(op, nunits, s); } while (0)
+                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, SO3_WPS_K14, 256>(op, nunits, s); } while (0)
         // the sum without per-row angles: float32 trace and acos outside the band around +-1 (so3::angle_sum_f32) unless SO3_EXACT_F64
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true, false); else if (deg) SLAUNCH(WR, true, false, false); \
                        else if (sum_count && !exact) SLAUNCH(WR, false, true, true); else if (sum_count) SLAUNCH(WR, false, true, false); \

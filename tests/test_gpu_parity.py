@@ -316,7 +316,9 @@ def test_deferred_hard_rows_are_the_rows_the_tile_kernel_gives(rr, bf16):
     ref = torch.empty(n, 9, device=DEV)
     hard = torch.empty(n, dtype=torch.uint8, device=DEV)
     assert lib.so3_project_fwd_diag_f32(x.data_ptr(), ref.data_ptr(), hard.data_ptr(), n, st) == 0
-    assert 0.1 * n < int(hard.sum().item()) < 0.45 * n                     # the mixture really is hard where it is meant to be (bfloat16 rounding breaks some ties)
+    # the mixture really is hard where it is meant to be (bfloat16 rounding breaks some ties; the all-zero rows are answered by the
+    # forward itself since round 4 and are not hard any more)
+    assert 0.07 * n < int(hard.sum().item()) < 0.45 * n
     fn = lib.so3_project_fwd_bf16 if bf16 else lib.so3_project_fwd_f32
     for offset in (0, 1, 2):                                               # rows 36 B apart: 16-, 4- and 8-byte aligned starts
         src = torch.empty((n + 1) * 9, device=DEV, dtype=torch.bfloat16 if bf16 else torch.float32)
