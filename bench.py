@@ -162,7 +162,8 @@ def parse():
 
 
 def host_cores() -> int:
-    """CPU share of this process: cgroup quota if set, else affinity, capped at the 16 cores a one-GPU box grants."""
+    """CPU share of this process: min(os.cpu_count(), the affinity mask, the cgroup quota) -- every core the lease grants, as
+    BASELINE.md section 3 asks (round 3 capped this at 16).  SO3_CPU_BASELINE_THREADS overrides it."""
     n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
@@ -174,7 +175,8 @@ def host_cores() -> int:
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("SO3_CPU_BASELINE_THREADS", "16"))))
+    forced = os.environ.get("SO3_CPU_BASELINE_THREADS")
+    return max(1, int(forced)) if forced else max(1, n)
 
 
 def cpu_baseline(rows: int):
@@ -202,7 +204,8 @@ def cpu_baseline(rows: int):
                     break
     except OSError:
         pass
-    return {"value": rows / best, "unit": "projections/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": rows / best, "unit": "projections/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_name,
+            "host_cpu_count": os.cpu_count(),
             "sample": f"{rows} rows of the same Gaussian workload, torch.linalg.svd-based restatement of "
                       f"rotation_representation.py:199-205 (oracle/so3_oracle.py), best of {reps}, {cpu_name}"}
 
@@ -327,6 +330,9 @@ def secondary_configs(lib, dev):
         torch.cuda.synchronize()
         blocks.append((time.perf_counter() - t0) / 300 * 1e6)
     blocks.sort()
+    # which autograd node served those steps: csrc/autograd_node.cpp's (no interpreter inside forward / backward) or the Python class
+    probe, _ = rr.frobenius_head(xg, t4.view(b, 3, 3))
+    out["config4_head_loss_backward_b512_bf16"]["mirror_path"] = "cpp_node" if "FrobeniusHeadNode" in type(probe.grad_fn).__name__ else "python"
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd"] = 0.5 * (blocks[2] + blocks[3])
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd_best_block"] = blocks[0]
 
@@ -515,6 +521,9 @@ def main():
                 if (flat and spent >= 0.050) or spent >= 0.120:
                     break
             pre["replays"] = len(hist)
+            # every launch of the benchmark kernel that ran before the timed region: the W warm-up steps, one more for the kernel's
+            # name, the timed graph once (upload, first touch), and the short graph's replays ("warmup" in the line is W alone)
+            pre["launches"] = args.warmup + 1 + args.steps + len(hist) * nshort
             pre["us_per_step_first"] = hist[0] * 1e3 / nshort
             pre["us_per_step_last"] = sum(hist[-32:]) / len(hist[-32:]) * 1e3 / nshort
             pre["ms"] = (time.perf_counter() - t_pre) * 1e3

@@ -165,19 +165,31 @@ int so3_scale_f32(const float *src, const float *factor, float *dst, int64_t n, 
 int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, void *stream);
 
 /* float64 arguments (the reference's metric and loss functions accept double tensors; rotation_representation.py:232-233 even
- * casts to double itself): the same quantities from float64 data in float64 arithmetic, one row per thread -- correctness
- * entry points, not tuned.  so3_geodesic_f64 returns float64 radians, so3_frob_loss_f64's dRpred and loss_mean are float64
- * (loss_mean = loss_sum / B), everything else as in the float32 functions. */
+ * casts to double itself): the same quantities from float64 data in float64 arithmetic, one row per thread and trip.
+ * so3_geodesic_f64 returns float64 radians, so3_frob_loss_f64's dRpred and loss_mean are float64 (loss_mean = loss_sum / B),
+ * everything else as in the float32 functions.  `workspace` (nullable) as for the float32 reductions: with it -- and for any batch
+ * of <= 1024 rows -- a call is ONE launch whose last workgroup writes sum, count, flag / loss and mean; without it the
+ * accumulators are zeroed by a launch in front of the kernel (and the mean written by one behind it). */
 int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                        int64_t B, void *stream);
+                        void *workspace, int64_t B, void *stream);
 int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t B, void *stream);
-int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, int64_t B,
-                      void *stream);
+int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace,
+                      int64_t B, void *stream);
 
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
  * point_cloud/main.py:43-57). */
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream);
+
+/* The same angle with the clamp drawn in by eps and reduced over the batch: geodesic(R1, R2, reduction) of
+ * point_cloud/main.py:61-73 (eps = 1e-7: acos(clamp((tr(R1 R2^T) - 1)/2, -1 + eps, 1 - eps)), float32; never called by the
+ * reference's loops, kept beside compute_geodesic_distance_from_two_matrices there).
+ *   theta  out optional B floats (reduction "none")
+ *   sum    optional 1 double of scratch: zeroed by the call, receives sum_b theta_b (float64 accumulation)
+ *   result out optional 1 float (needs `sum`): (float) of that sum, or of sum / B when mean != 0 -- written on `stream` behind the kernels
+ */
+int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps,
+                         int64_t B, void *stream);
 
 /* ---- next row: the SE(3) pose update fused after the head ------------------------
  * Replaces calculate_T_pred, Iterative/utility.py:90-128 (the head at :105, einsum at :124, the translation

@@ -88,6 +88,24 @@ def geodesic_np(m1, m2, dtype=np.float32):
     return np.arccos(cos)                                           # :222
 
 
+def geodesic_eps_np(r1, r2, reduction="mean", eps=1e-7):
+    """geodesic(R1, R2, reduction), point_cloud/main.py:61-73: float32, tr(R1 R2^T), clamp to [-1 + eps, 1 - eps], acos;
+    "none" -> (B,), "mean" / "sum" -> scalar; any other string -> None (the reference's if-chain falls through)."""
+    a = np.asarray(r1, dtype=np.float32).reshape(-1, 3, 3)
+    b = np.asarray(r2, dtype=np.float32).reshape(-1, 3, 3)
+    diffs = a @ b.transpose(0, 2, 1)                                # :63
+    traces = np.trace(diffs, axis1=-2, axis2=-1).astype(np.float32)  # :65
+    lo, hi = np.float32(-1 + eps), np.float32(1 - eps)              # torch.clamp's scalars on a float32 tensor
+    dists = np.arccos(np.clip((traces - np.float32(1)) / np.float32(2), lo, hi))   # :66-67
+    if reduction == "none":
+        return dists
+    if reduction == "mean":
+        return np.float32(dists.astype(np.float64).mean())
+    if reduction == "sum":
+        return np.float32(dists.astype(np.float64).sum())
+    return None
+
+
 def loss_frobenius_np(r_pred, r_true):
     """mean_b ||R_true - R_pred||_F, not squared (3D-Pose/loss.py:7-11)."""
     d = np.asarray(r_true, np.float64).reshape(-1, 3, 3) - np.asarray(r_pred, np.float64).reshape(-1, 3, 3)

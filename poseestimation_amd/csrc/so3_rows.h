@@ -1058,10 +1058,16 @@ struct OpProjectAngle : OpBase {
     }
 };
 
-// K4': float32 radians, tr(m1 m2^T), hard clamp (rotation_representation.py:209-227).
+// K4': float32 radians, tr(m1 m2^T), clamp to [lo, hi], acos: compute_geodesic_distance_from_two_matrices (rotation_representation.py:209-227:
+// lo, hi = -1, 1) and geodesic(R1, R2, reduction) (point_cloud/main.py:61-73: -1 + 1e-7, 1 - 1e-7, and the sum over the batch).
+// SUM: the angles are also summed (float64 per lane, one atomic per workgroup onto `sum`); theta may then be null.
+template <bool SUM>
 struct OpGeodesic : OpBase {
     static constexpr int kIn0 = 4, kIn1 = 4, kOut0 = 0, kOut1 = 0;
+    static constexpr bool kReduce = SUM;
     float *theta = nullptr;
+    double *sum = nullptr;
+    float lo = -1.f, hi = 1.f;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpGeodesic> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
@@ -1075,12 +1081,16 @@ struct OpGeodesic : OpBase {
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             float c = R::get(cs, k);
-            c = (c > 1.f) ? 1.f : c;     // torch.min / torch.max with a constant: NaN stays NaN
-            c = (c < -1.f) ? -1.f : c;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acosf(c)), row_rsrc<4>(theta, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]),
-                                                  ctx.lane * 4, 0, 0);
+            c = (c > hi) ? hi : c;       // torch.min / torch.max with a constant, torch.clamp: NaN stays NaN
+            c = (c < lo) ? lo : c;
+            const float th = acosf(c);
+            if (!SUM || theta != nullptr)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(th), row_rsrc<4>(theta, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]),
+                                                      ctx.lane * 4, 0, 0);
+            if (SUM && ctx.exists[k]) ctx.acc += static_cast<double>(th);
         }
     }
+    __device__ __forceinline__ void finish(double total, bool) const { if (SUM) atomicAdd(sum, total); }
 };
 
 #endif  // !SO3_HOST_MODEL

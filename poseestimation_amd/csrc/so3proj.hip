@@ -503,12 +503,14 @@ __global__ void k_angle_init(double *sum_count, int32_t *range_flag, double coun
     if (range_flag) *range_flag = 0;
 }
 
-// float32 radians variant (rotation_representation.py:209-227): tr(m1 m2^T) in float32, hard clamp.
+// float32 radians variant (rotation_representation.py:209-227; point_cloud/main.py:61-73): tr(m1 m2^T) in float32, clamp to [lo, hi];
+// `sum` (nullable): the block's angles are added to it (one atomic per workgroup); theta nullable then.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict__ R1, const float *__restrict__ R2,
-                                                         float *__restrict__ theta, int64_t B) {
+                                                         float *__restrict__ theta, double *__restrict__ sum, float lo, float hi, int64_t B) {
     __shared__ __attribute__((aligned(16))) float tile_a[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_b[kTileFloats];
+    __shared__ double part[kBlock / 64];
     const int64_t first = static_cast<int64_t>(blockIdx.x) * kBlock;
     const int n = static_cast<int>(min<int64_t>(kBlock, B - first));
     tile_in<false, VEC>(R1, first, n, tile_a);
@@ -523,9 +525,23 @@ __global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict
     const float d1 = fmaf(a[5], b[5], fmaf(a[4], b[4], a[3] * b[3]));
     const float d2 = fmaf(a[8], b[8], fmaf(a[7], b[7], a[6] * b[6]));
     float c = (d0 + d1 + d2 - 1.f) * 0.5f;
-    c = (c > 1.f) ? 1.f : c;     // torch.min / torch.max with a constant: NaN stays NaN
-    c = (c < -1.f) ? -1.f : c;
-    if (active) theta[first + threadIdx.x] = acosf(c);
+    c = (c > hi) ? hi : c;     // torch.min / torch.max with a constant, torch.clamp: NaN stays NaN
+    c = (c < lo) ? lo : c;
+    const float th = acosf(c);
+    if (active && theta != nullptr) theta[first + threadIdx.x] = th;
+    if (sum != nullptr) {
+        double v = active ? static_cast<double>(th) : 0.0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+            atomicAdd(sum, t);
+        }
+    }
 }
 
 // ---- K5 -------------------------------------------------------------------------------------------
@@ -993,53 +1009,77 @@ __global__ __launch_bounds__(kBlock) void k_project_diag(const float *__restrict
 // cast to double themselves: rotation_representation.py:232-233) -- one row per thread straight from global memory: not a
 // benchmark path, but no ATen arithmetic either.  MODE 0: angle_error (float64, range flag, unit = 180/pi or 1);
 // MODE 1: compute_geodesic_distance_from_two_matrices (radians, hard clamp, no flag).
+// Grid-stride (at most 2048 workgroups).  How the reduction is finished -- `how`: 0 = atomics onto accumulators an init launch has
+// zeroed; 1 = ONE workgroup (B <= 1024): it writes sum, count and flag itself; 2 = caller's workspace: partial per workgroup, a ticket,
+// the last one writes everything (so3_rows.h, ticket_finish).  1 and 2 are one launch per call.
 template <int MODE, bool WANT_ROWS, bool WANT_SUM>
 __global__ __launch_bounds__(kBlock) void k_angle_f64(const double *__restrict__ R1, const double *__restrict__ R2, double *__restrict__ out,
-                                                      double *__restrict__ sum_count, int32_t *__restrict__ range_flag, double unit, int64_t B) {
+                                                      double *__restrict__ sum_count, int32_t *__restrict__ range_flag, double unit, int64_t B,
+                                                      so3::ReduceWs *ws, int how) {
     __shared__ double red[4];
-    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const bool active = row < B;
-    double tr = 0.0;
-    if (active) {
+    double acc = 0.0;
+    bool bad = false;
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; row < B; row += static_cast<int64_t>(gridDim.x) * kBlock) {
+        double tr = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) tr = fma(R1[row * 9 + i], R2[row * 9 + i], tr);
+        const double c_raw = (tr - 1.0) * 0.5;
+        bad |= MODE == 0 && (c_raw < -1.1 || c_raw > 1.1);
+        double c = fmin(fmax(c_raw, -1.0), 1.0);
+        if (c_raw != c_raw) c = c_raw;                          // clamp keeps NaN
+        const double ang = so3::acos_f64(c) * unit;
+        if (WANT_ROWS) out[row] = ang;
+        acc += ang;
     }
-    const double c_raw = (tr - 1.0) * 0.5;
-    const bool bad = MODE == 0 && active && (c_raw < -1.1 || c_raw > 1.1);
-    double c = fmin(fmax(c_raw, -1.0), 1.0);
-    if (c_raw != c_raw) c = c_raw;                              // clamp keeps NaN
-    const double ang = so3::acos_f64(c) * unit;
-    if (MODE == 0 && range_flag != nullptr && __any(bad)) {
-        if ((threadIdx.x & 63) == 0) atomicOr(range_flag, 1);
-    }
-    if (WANT_ROWS && active) out[row] = ang;
-    if (WANT_SUM) {
-        const double total = block_sum(active ? ang : 0.0, red);
-        if (threadIdx.x == 0) atomicAdd(sum_count, total);
+    const bool any_bad = MODE == 0 && __syncthreads_or(bad ? 1 : 0) != 0;
+    const double total = WANT_SUM ? block_sum(acc, red) : 0.0;
+    if (MODE != 0) return;
+    if (how == 2) {
+        so3::ticket_finish<kBlock>(ws, blockIdx.x, gridDim.x, gridDim.x, total, any_bad, [&](double t, bool any) {
+            if (WANT_SUM) { sum_count[0] = t; sum_count[1] = static_cast<double>(B); }
+            if (range_flag != nullptr) *range_flag = any ? 1 : 0;
+        });
+    } else if (threadIdx.x == 0) {
+        if (how == 1) {
+            if (WANT_SUM) { sum_count[0] = total; sum_count[1] = static_cast<double>(B); }
+            if (range_flag != nullptr) *range_flag = any_bad ? 1 : 0;
+        } else {
+            if (WANT_SUM) atomicAdd(sum_count, total);
+            if (any_bad && range_flag != nullptr) atomicOr(range_flag, 1);
+        }
     }
 }
 
-// loss_frobenius in float64: loss_sum += sum_b ||Rtrue_b - Rpred_b||_F, optional dRpred_b = (Rpred_b - Rtrue_b) / (B ||.||_F)
+// loss_frobenius in float64: sum_b ||Rtrue_b - Rpred_b||_F, optional dRpred_b = (Rpred_b - Rtrue_b) / (B ||.||_F); `how` as above
+// (1 / 2: loss_sum and, if asked for, loss_mean = loss_sum / B are written by the kernel).
 template <bool WANT_GRAD>
 __global__ __launch_bounds__(kBlock) void k_frob_loss_f64(const double *__restrict__ Rpred, const double *__restrict__ Rtrue,
-                                                          double *__restrict__ dRpred, double *__restrict__ loss_sum, int64_t B, double inv_b) {
+                                                          double *__restrict__ dRpred, double *__restrict__ loss_sum, double *__restrict__ loss_mean,
+                                                          int64_t B, double inv_b, so3::ReduceWs *ws, int how) {
     __shared__ double red[4];
-    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const bool active = row < B;
-    double g[9], n2 = 0.0;
+    double acc = 0.0;
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; row < B; row += static_cast<int64_t>(gridDim.x) * kBlock) {
+        double g[9], n2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        g[i] = active ? Rpred[row * 9 + i] - Rtrue[row * 9 + i] : 0.0;
-        n2 = fma(g[i], g[i], n2);
-    }
-    const double nrm = __builtin_sqrt(n2);
-    if (WANT_GRAD && active) {
-        const double gs = n2 > 0.0 ? inv_b / nrm : 0.0;         // zero difference -> zero gradient (the reference: NaN)
+        for (int i = 0; i < 9; ++i) {
+            g[i] = Rpred[row * 9 + i] - Rtrue[row * 9 + i];
+            n2 = fma(g[i], g[i], n2);
+        }
+        const double nrm = __builtin_sqrt(n2);
+        if (WANT_GRAD) {
+            const double gs = n2 > 0.0 ? inv_b / nrm : 0.0;     // zero difference -> zero gradient (the reference: NaN)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) dRpred[row * 9 + i] = g[i] * gs;
+            for (int i = 0; i < 9; ++i) dRpred[row * 9 + i] = g[i] * gs;
+        }
+        acc += nrm;
     }
-    const double total = block_sum(active ? nrm : 0.0, red);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, total);
+    const double total = block_sum(acc, red);
+    auto write = [&](double t) {
+        *loss_sum = t;
+        if (loss_mean != nullptr) *loss_mean = t * inv_b;
+    };
+    if (how == 2) so3::ticket_finish<kBlock>(ws, blockIdx.x, gridDim.x, gridDim.x, total, false, [&](double t, bool) { write(t); });
+    else if (threadIdx.x == 0) { if (how == 1) write(total); else atomicAdd(loss_sum, total); }
 }
 __global__ void k_mean_from_sum_f64(const double *__restrict__ loss_sum, double *__restrict__ loss_mean, double inv_b) {
     *loss_mean = *loss_sum * inv_b;
@@ -1796,16 +1836,26 @@ int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, v
     return check_launch("so3_scale_bf16");
 }
 
-int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, int64_t B,
-                        void *stream) {
+// one launch for B <= 1024 (one workgroup) and with a workspace; else init / memset launch + kernel (+ the mean's)
+static int reduce_how(void *workspace, int64_t B, unsigned *grid) {
+    const unsigned want = grid_for(B);
+    *grid = B <= kSmallBatch ? 1u : (want < 2048u ? want : 2048u);
+    return B <= kSmallBatch ? 1 : (workspace != nullptr ? 2 : 0);
+}
+
+int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, void *workspace,
+                        int64_t B, void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error_f64: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sum_count || range_flag) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
+    unsigned grid = 1;
+    const int how = B > 0 ? reduce_how(workspace, B, &grid) : 0;
+    if (how == 0 && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
     if (B == 0) return check_launch("so3_angle_error_f64");
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error_f64: null pointer");
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
-    const dim3 grid(grid_for(B)), block(kBlock);
-#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_f64<0, WD, WS>), grid, block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B)
+    const dim3 block(kBlock);
+    so3::ReduceWs *ws = static_cast<so3::ReduceWs *>(workspace);
+#define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_f64<0, WD, WS>), dim3(grid), block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B, ws, how)
     if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
 #undef LAUNCH
     return check_launch("so3_angle_error_f64");
@@ -1816,47 +1866,72 @@ int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t 
     if (B == 0) return 0;
     SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && theta != nullptr, "so3_geodesic_f64: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((k_angle_f64<1, true, false>), dim3(grid_for(B)), dim3(kBlock), 0, s, R1, R2, theta, nullptr, nullptr, 1.0, B);
+    const unsigned want = grid_for(B);
+    hipLaunchKernelGGL((k_angle_f64<1, true, false>), dim3(want < 2048u ? want : 2048u), dim3(kBlock), 0, s, R1, R2, theta, nullptr, nullptr, 1.0, B, nullptr, 0);
     return check_launch("so3_geodesic_f64");
 }
 
-int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, int64_t B, void *stream) {
+int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace, int64_t B,
+                      void *stream) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f64: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f64: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-    if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset");
-    if (B == 0) {
-        if (loss_mean != nullptr) { e = hipMemsetAsync(loss_mean, 0, sizeof(double), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset"); }
-        return 0;
+    unsigned grid = 1;
+    const int how = B > 0 ? reduce_how(workspace, B, &grid) : 0;
+    if (how == 0) {
+        hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
+        if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset");
+        if (B == 0) {
+            if (loss_mean != nullptr) { e = hipMemsetAsync(loss_mean, 0, sizeof(double), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset"); }
+            return 0;
+        }
     }
     SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f64: null pointer");
     const double inv_b = 1.0 / static_cast<double>(B);
-    const dim3 grid(grid_for(B)), block(kBlock);
-    if (dRpred) hipLaunchKernelGGL((k_frob_loss_f64<true>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b);
-    else hipLaunchKernelGGL((k_frob_loss_f64<false>), grid, block, 0, s, Rpred, Rtrue, dRpred, loss_sum, B, inv_b);
-    if (loss_mean != nullptr) k_mean_from_sum_f64<<<1, 1, 0, s>>>(loss_sum, loss_mean, inv_b);
+    const dim3 block(kBlock);
+    so3::ReduceWs *ws = static_cast<so3::ReduceWs *>(workspace);
+    if (dRpred) hipLaunchKernelGGL((k_frob_loss_f64<true>), dim3(grid), block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, B, inv_b, ws, how);
+    else hipLaunchKernelGGL((k_frob_loss_f64<false>), dim3(grid), block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, B, inv_b, ws, how);
+    if (how == 0 && loss_mean != nullptr) k_mean_from_sum_f64<<<1, 1, 0, s>>>(loss_sum, loss_mean, inv_b);
     return check_launch("so3_frob_loss_f64");
 }
 
-int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_geodesic_f32: B");
-    if (B == 0) return 0;
-    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && theta != nullptr, "so3_geodesic_f32: null pointer");
+static int geodesic_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, int64_t B, void *stream,
+                        const char *what) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B && eps >= 0.f && eps < 1.f, what);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int64_t nunits = stream_units(B, {R1, R2, theta});
-    if (nunits > 0) {
-        so3::OpGeodesic op; op.in0 = R1; op.in1 = R2; op.theta = theta;
-        launch_rows<2, 3, 256>(op, nunits, s);
+    if (sum != nullptr) {
+        const hipError_t e = hipMemsetAsync(sum, 0, sizeof(double), s);
+        if (e != hipSuccess) return fail(static_cast<int>(e), what);
     }
-    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
-    if (rest > 0) {
-        const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
-        const dim3 grid(grid_for(rest)), block(kBlock);
-        if (aligned16(A1) && aligned16(A2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, A1, A2, theta + done, rest);
-        else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, theta + done, rest);
+    if (B > 0) {
+        SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && (theta != nullptr || sum != nullptr), what);
+        const float lo = -1.f + eps, hi = 1.f - eps;          // float32 arithmetic, like torch.clamp's scalars on a float32 tensor
+        const int64_t nunits = stream_units(B, {R1, R2, theta});
+        if (nunits > 0) {
+            if (sum) { so3::OpGeodesic<true> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.sum = sum; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
+            else { so3::OpGeodesic<false> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
+        }
+        const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+        if (rest > 0) {
+            const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
+            const dim3 grid(grid_for(rest)), block(kBlock);
+            if (aligned16(A1) && aligned16(A2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest);
+            else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest);
+        }
     }
-    return check_launch("so3_geodesic_f32");
+    // (torch's mean of an empty tensor is NaN, its sum 0: 0 * inf / 0 * 1)
+    if (result != nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(sum, result, mean ? 1.0 / static_cast<double>(B) : 1.0);
+    return check_launch(what);
+}
+int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(theta != nullptr, "so3_geodesic_f32: null pointer");
+    return geodesic_f32(R1, R2, theta, nullptr, nullptr, 0, 0.f, B, stream, "so3_geodesic_f32");
+}
+int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, int64_t B, void *stream) {
+    SO3_CHECK_ARGS(result == nullptr || sum != nullptr, "so3_geodesic_eps_f32: result needs the float64 scratch `sum`");
+    return geodesic_f32(R1, R2, theta, sum, result, mean, eps, B, stream, "so3_geodesic_eps_f32");
 }
 
 int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream) {

@@ -406,8 +406,10 @@ def _angle_call_f64(r1, r2, want_rows, want_sum, radians=False, geodesic=False):
         if geodesic:
             _check(_libh().so3_geodesic_f64(a.data_ptr(), b_.data_ptr(), rows.data_ptr(), n, _stream(dev)), "so3_geodesic_f64")
         else:
-            _check(_libh().so3_angle_error_f64(a.data_ptr(), b_.data_ptr(), _ptr(rows), _ptr(sc), flag.data_ptr(), 1 if radians else 0, n,
-                                               _stream(dev)), "so3_angle_error_f64")
+            st = _stream(dev)
+            ws = _workspace(dev, st) if n > _SMALL_BATCH else None          # one launch either way (above 1024 rows: the ticket finish)
+            _check(_libh().so3_angle_error_f64(a.data_ptr(), b_.data_ptr(), _ptr(rows), _ptr(sc), flag.data_ptr(), 1 if radians else 0, _ptr(ws), n,
+                                               st), "so3_angle_error_f64")
     return rows, sc, flag
 
 
@@ -501,6 +503,26 @@ def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tens
     return theta
 
 
+def geodesic(R1: torch.Tensor, R2: torch.Tensor, reduction: str = "mean"):
+    """point_cloud/main.py:61-73: acos(clamp((tr(R1 R2^T) - 1)/2, -1 + 1e-7, 1 - 1e-7)) in float32, radians;
+    reduction "none" -> (B,), "mean" / "sum" -> 0-dim float32; any other string returns None, as the reference's if-chain does.
+    Angles and their sum leave one launch (float64 accumulation; the reference's float32 .mean() agrees to its own round-off)."""
+    dev = _require_device(R1, R2)
+    a, b_ = _f32_blocks(R1), _f32_blocks(R2)
+    if a.shape != b_.shape:
+        raise RuntimeError(f"geodesic: shape mismatch {tuple(R1.shape)} vs {tuple(R2.shape)}")
+    if reduction not in ("none", "mean", "sum"):
+        return None
+    n = a.shape[0]
+    theta = torch.empty((n,), dtype=torch.float32, device=dev) if reduction == "none" else None
+    acc = None if reduction == "none" else torch.empty((1,), dtype=torch.float64, device=dev)
+    out = None if reduction == "none" else torch.empty((), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _check(_libh().so3_geodesic_eps_f32(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7, n,
+                                            _stream(dev)), "so3_geodesic_eps_f32")
+    return theta if reduction == "none" else out
+
+
 # --------------------------------------------------------------------------------------------
 # K3: loss
 # --------------------------------------------------------------------------------------------
@@ -521,7 +543,8 @@ class _LossFrobenius(torch.autograd.Function):
         with _on_device(dev):
             st = _stream(dev)
             if f64:
-                _check(_libh().so3_frob_loss_f64(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), b, st),
+                ws = _workspace(dev, st) if b > _SMALL_BATCH else None
+                _check(_libh().so3_frob_loss_f64(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
                        "so3_frob_loss_f64")
             else:
                 ws = _workspace(dev, st) if b > _SMALL_BATCH else None

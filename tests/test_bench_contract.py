@@ -49,8 +49,12 @@ def test_bench_json_contract(mode):
     assert d["secondary"]["config1_head_b512_no_grad"]["us_per_call_host_clock"] > 0
     # the kernel is named by the library from the launch's own template arguments, not by a literal in bench.py
     assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false>,") and r["kernel"].endswith(">")
+    assert c4["mirror_path"] in ("cpp_node", "python")                               # which autograd node produced the mirror's figure
+    assert c["cpu_model"] and c["cores"] <= c["host_cpu_count"]                      # every core the lease grants, and the CPU named
     if mode == "graph":
-        assert d["pre_timing"]["replays"] >= 1 and d["pre_timing"]["ms"] <= 200.0
+        pt = d["pre_timing"]
+        assert pt["replays"] >= 1 and pt["ms"] <= 200.0
+        assert pt["launches"] == 3 + 1 + 30 + pt["replays"] * 25                      # what ran untimed in front of the region, all of it
 
 
 def test_bench_under_an_initialised_process_group_rccl_one_rank():

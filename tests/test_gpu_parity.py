@@ -524,6 +524,44 @@ def test_g3_geodesic_radians(rr):
 # ------------------------------------------------------------------------------------------------
 # K2 / K3: backward and the fused loss (config #4)
 # ------------------------------------------------------------------------------------------------
+def test_g14_geodesic_with_reduction(rr):
+    """geodesic(R1, R2, reduction) of point_cloud/main.py:61-73 against the golden the reference function produced: per-row angles
+    (cosines to 1e-6: float32 trace; the eps clamp keeps them off 0 and pi), mean and sum as 0-dim float32, None for anything else;
+    ragged sizes and offset views go through the tile kernel's share of the sum."""
+    from oracle import so3_oracle as so
+    g = load_golden("g14_geodesic_reduction.npz")
+    g3 = load_golden("g3_angles.npz")
+    for tag, (a, b) in (("g3", (g3["r1"], g3["r2"])), ("haar", (g["a"], g["b"]))):
+        da, db = dev(a), dev(b)
+        rad = rr.geodesic(da, db, "none")
+        assert rad.dtype == torch.float32 and rad.shape == (len(a),)
+        assert np.abs(np.cos(rad.double().cpu().numpy()) - np.cos(g[tag + "_none"].astype(np.float64))).max() < 1e-6
+        assert rad.min().item() >= 4.8e-4 and rad.max().item() <= np.pi - 4.8e-4
+        mean, total = rr.geodesic(da, db), rr.geodesic(da, db, "sum")
+        assert mean.dtype == torch.float32 and mean.dim() == 0 and total.dim() == 0
+        assert abs(mean.item() - float(g[tag + "_mean"])) < 2e-6 * float(g[tag + "_mean"]) + 1e-5
+        assert abs(total.item() - float(g[tag + "_sum"])) < 2e-6 * float(g[tag + "_sum"]) + 3e-3
+        assert abs(total.item() - rad.double().sum().item()) < 1e-3
+    assert rr.geodesic(dev(g["a"]), dev(g["b"]), "median") is None
+    gen = torch.Generator(device=DEV).manual_seed(14)
+    big_a, big_b = _haar_rows(100_003, gen), _haar_rows(100_003, gen)
+    for lo in (0, 1):                                                      # 16-byte aligned and a view 36 bytes in
+        a, b = big_a[lo:], big_b[lo:]
+        ref = so.geodesic_eps_np(a.cpu().numpy(), b.cpu().numpy(), "none").astype(np.float64)
+        rad = rr.geodesic(a, b, "none").double().cpu().numpy()
+        assert np.abs(np.cos(rad) - np.cos(ref)).max() < 1e-6
+        assert abs(rr.geodesic(a, b, "sum").item() - ref.sum()) < 2e-6 * ref.sum() + 0.05
+        assert abs(rr.geodesic(a, b, "mean").item() - ref.mean()) < 1e-5
+
+
+def _haar_rows(n, gen):
+    q = torch.randn(n, 4, device=DEV, generator=gen)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                        2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+
+
 def test_g4_backward_generic_gradient(rr):
     g = load_golden("g4_frobenius512.npz")
     x = torch.from_numpy(g["x_bf16_bits"]).view(torch.bfloat16).float().to(DEV).requires_grad_(True)

@@ -101,6 +101,22 @@ def test_g3_geodesic_radians():
     assert np.abs(np.degrees(g["rad"].astype(np.float64)) - g["deg"])[5:].max() < 0.05
 
 
+def test_g14_geodesic_with_reduction():
+    """geodesic(R1, R2, reduction) (point_cloud/main.py:61-73), golden from the reference function: the eps-clamped angles (no exact
+    0 or pi: acos(1 - 1.19e-7) = 4.9e-4 rad at the ends), their float32 mean and sum, and None for an unknown reduction."""
+    g = load_golden("g14_geodesic_reduction.npz")
+    g3 = load_golden("g3_angles.npz")
+    for tag, (a, b) in (("g3", (g3["r1"], g3["r2"])), ("haar", (g["a"], g["b"]))):
+        rad = so.geodesic_eps_np(a, b, "none")
+        assert rad.dtype == np.float32
+        assert np.abs(np.cos(rad.astype(np.float64)) - np.cos(g[tag + "_none"].astype(np.float64))).max() < 1e-6
+        assert rad.min() >= 4.8e-4 and rad.max() <= np.pi - 4.8e-4        # the clamp keeps every angle off 0 and pi
+        assert abs(float(so.geodesic_eps_np(a, b, "mean")) - float(g[tag + "_mean"])) < 2e-6 * float(g[tag + "_mean"]) + 1e-5
+        assert abs(float(so.geodesic_eps_np(a, b, "sum")) - float(g[tag + "_sum"])) < 2e-6 * float(g[tag + "_sum"]) + 3e-3
+    assert so.geodesic_eps_np(g["a"], g["b"], "median") is None
+    assert list(g["dtypes"]) == ["torch.float32"] * 3
+
+
 def test_g4_loss_and_gradients(c_oracle):
     g = load_golden("g4_frobenius512.npz")
     x = torch.from_numpy(g["x_bf16_bits"]).view(torch.bfloat16).float().numpy()

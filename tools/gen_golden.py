@@ -233,7 +233,27 @@ def g13_dtype_fidelity():
     save("g13_dtype_fidelity.npz", **out)
 
 
+def g14_geodesic_reduction():
+    """geodesic(R1, R2, reduction) of point_cloud/main.py:61-73 (the eps-clamped geodesic with "none" / "mean" / "sum"), run from
+    the reference file on G3's pairs (0 and 180 degrees included: the clamp is what differs from the other geodesic) and on 2000
+    Haar-like pairs."""
+    (geodesic,) = functions_from(os.path.join(REF, "point_cloud", "main.py"), ["geodesic"])
+    g3 = np.load(os.path.join(OUT, "g3_angles.npz"))
+    r1, r2 = torch.from_numpy(g3["r1"]), torch.from_numpy(g3["r2"])
+    torch.manual_seed(14)
+    a = rr.symmetric_orthogonalization(torch.randn(2000, 9))
+    b = rr.symmetric_orthogonalization(torch.randn(2000, 9))
+    out = {"a": a, "b": b}
+    for tag, (p, q) in (("g3", (r1, r2)), ("haar", (a, b))):
+        out.update({tag + "_none": geodesic(p, q, "none"), tag + "_mean": geodesic(p, q, "mean"), tag + "_sum": geodesic(p, q, "sum")})
+    assert geodesic(a, b, "median") is None                 # any other string falls through the if-chain
+    out["dtypes"] = np.array([str(out["haar_none"].dtype), str(out["haar_mean"].dtype), str(out["haar_sum"].dtype)])
+    save("g14_geodesic_reduction.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g14":
+        return g14_geodesic_reduction()
     if len(sys.argv) > 1 and sys.argv[1] == "g13":
         return g13_dtype_fidelity()
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
