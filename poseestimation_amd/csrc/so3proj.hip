@@ -1200,88 +1200,63 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 }
 
 // ---- next row f3: per-class evaluation statistics of K4's angles (3D-Pose/test_per_class.py:174-216) ----------
-// Count, sum, sum of squares, max and three accuracy thresholds, and an EXACT median by radix select on the float64 bit
-// patterns (non-negative doubles order like their bits): 8 passes of 8 bits over the rows still matching the selected
-// prefix; two selections run side by side (the lower and upper middle element; numpy averages them).  One kernel per
-// pass (round 2; round 1 took 20 launches and 430 us): the first pass also gathers the statistics, every pass ends with
-// the LAST workgroup to arrive (a ticket per pass) picking the digit for every class -- a wave per (selection, class),
-// 256 bins in four loads per lane and a wave prefix sum -- and the last pass writes the result.  The grid is two
-// workgroups per CU: round 1's 2048 workgroups each flushed their private histograms with same-address global atomics,
-// which is what its kernels spent their time on.
+// Count, mean, std, max, three accuracy thresholds and an EXACT median (the two middle elements averaged, as np.median) with TWO
+// passes over the rows (round 2 / 3: a radix select of eight launches, 8 bits each, every one a pass over all rows, a ticket and two
+// release fences per workgroup and launch: 152 us per 1M rows):
+//   1. k_stats_window (all rows): per class the sum, the sum of squares, the maximum, and a histogram of the angles over a WINDOW of
+//      512 bins -- the top 16 bits of the float64 pattern (non-negative doubles order like their bits): sixteen bins per octave from
+//      2^-23 to 2^9 degrees, one bin below and one above.  The thresholds 7.5, 15 and 30 are bin edges (1.875 x 2^k), so the three
+//      accuracies and the count are sums over bins -- no atomics of their own.  Workgroup-private in LDS, flushed once.
+//   2. k_stats_collect (all rows): first, per class, the bins holding the lower and the upper middle element (every workgroup for
+//      itself, from the L2-resident histograms); then the rows of those bins (1/16 octave: a few per cent of a class) are compacted,
+//      each workgroup into a region of its own (an LDS cursor: no global atomic, no barrier in the loop), grouped by class.
+//   3. k_stats_finish (one workgroup per class): the regions' counts for the class become prefix sums (which makes its share of the
+//      regions one list), the candidates are gathered (into LDS when they fit) and both middle elements radix-selected at once on
+//      the remaining 48 bits; then the class's row of the result.
+// Launch boundaries order everything: no ticket, no fence (measured: the two release fences per workgroup were 4-9 us per launch,
+// three float64 LDS atomics per row 11 us, the histogram and its flush nothing; profiles/r04_angle_stats_experiments.txt).
+// Exact for every input: an edge bin (zeros, denormals, angles above 512 degrees) is selected on all 64 bits, and if a workgroup's
+// region overflows (more than ~4000 of its rows inside the selected bins: e.g. a million equal angles) the finishing workgroups
+// select over the rows themselves -- slow, never wrong.
 constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
 constexpr int kMaxClasses = 64;
-constexpr int kStatPasses = 8;
-struct StatWork {                                  // layout of the caller's workspace (zero-filled by the call)
-    double acc[kMaxClasses][8];                    // count, sum, sumsq, max, n30, n15, n7.5, nan_count
-    unsigned long long prefix[2][kMaxClasses];     // selected high bits so far (lower / upper middle)
-    long long krem[2][kMaxClasses];                // rank still to find inside the prefix
-    unsigned int hist[2][kMaxClasses][256];
-    unsigned int tickets[kStatPasses];             // workgroups that have finished pass p
+constexpr int kWinBase = 0x3E80;                   // (bits >> 48) of 2^-23
+constexpr int kWinBins = 512;
+constexpr int kHistBins = kWinBins + 2;            // [0]: below the window, [kHistBins - 1]: above it (and +inf)
+constexpr unsigned int kCandCap = 1u << 20;
+constexpr int kStatMaxWgs = 1024;
+constexpr int kStatLdsKeys = 16384;                // candidates of one class that k_stats_finish keeps in LDS (128 KB + 16 KB of tags)
+struct StatWork {                                  // layout of the caller's workspace; the call zeroes it up to the classes' histograms
+    double acc[kMaxClasses][4];                    // sum, sumsq, max (bits), nan_count
+    unsigned int overflow, pad;
+    unsigned int hist[kMaxClasses][kHistBins];     // (zeroed for the classes in use)
+    double count[kMaxClasses], below[3][kMaxClasses];      // rows of the class (NaN included), non-NaN rows below 30 / 15 / 7.5
+    int sel_bin[2][kMaxClasses];                   // the window bin of the lower / upper middle element (-1: empty class)
+    long long krem[2][kMaxClasses];                // its rank inside that bin
+    unsigned int wg_cstart[kStatMaxWgs][kMaxClasses], wg_ccount[kStatMaxWgs][kMaxClasses];   // k_stats_collect: where a workgroup's region holds class c, how many
+    unsigned char tag[kCandCap];                   // bit 0: counts for the lower middle element, bit 1: for the upper
+    unsigned long long cand[kCandCap];
 };
+constexpr unsigned int kStatRegion = 4096;         // candidates one workgroup of k_stats_collect stages in LDS (48 KB) and owns in the buffer
+static_assert(kStatRegion * 256u <= kCandCap, "one region per CU");
 
-__device__ __forceinline__ unsigned int coherent_u32(const unsigned int *p) {     // other workgroups' atomics, read past L1
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned long long angle_key(double a) { return static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)); }
+__device__ __forceinline__ int window_bin(unsigned long long key) {
+    const int top = static_cast<int>(key >> 48);
+    return top < kWinBase ? 0 : (top >= kWinBase + kWinBins ? kHistBins - 1 : top - kWinBase + 1);
 }
-using so3::coherent_f64;
+// bins [0, edge) hold exactly the angles below the threshold: 30, 15 and 7.5 are 1.875 x 2^k, i.e. edges of the 1/16-octave bins
+constexpr int kEdge30 = 0x403E - kWinBase + 1, kEdge15 = 0x402E - kWinBase + 1, kEdge7p5 = 0x401E - kWinBase + 1;
 
-// LDS: workgroup-private histograms first (early passes put almost every row into one or two digits -- the
-// exponent bytes -- and a million same-address global atomics would serialise), then one flush per bin.
-// 1024-thread workgroups, two rows per thread and trip: at 1M rows and two workgroups per CU every thread loads its
-// rows once, up front (the loop of round 1 walked eight dependent load latencies per pass).  The selected prefixes sit
-// in LDS (they were a dependent global load per row), the first pass's float64 sums go to sixteen lane-private slots per
-// class and field (64 lanes on 10 classes were six-way conflicts on ds_add_f64).
-// LCLS = how many classes the workgroup's histograms hold: 16 (32 KB of counters, sixteen sum slots) or all 64 the interface
-// allows (128 KB of the CU's 160 KB, four sum slots) -- ModelNet40's 40 classes went through global atomics before, 545 us
-// per call against 150 us for ten classes.
 constexpr int kStatLdsClasses = 16;
 constexpr int kStatBlock = 1024;
-template <int LCLS, bool FIRST>
-__global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restrict__ deg, const int32_t *__restrict__ cls,
-                                                           int ncls, StatWork *w, int64_t B, int pass, double *__restrict__ stats, int mode) {
-    // gfx950 only: the 64-class instantiation holds 128 KB of histograms + 16 KB of sums in LDS (the CU has 160 KB; 64 KB parts
-    // could not build it), one 1024-thread workgroup per CU
-    static_assert(sizeof(unsigned int) * 2 * LCLS * 256 + sizeof(double) * (FIRST ? LCLS : 1) * 8 * (FIRST ? (LCLS <= 16 ? 16 : 4) : 1)
-                      + sizeof(unsigned long long) * 2 * kMaxClasses + 64 <= 160 * 1024, "k_stats_pass: LDS budget of a gfx950 CU");
-    constexpr bool LDS = true;
-    constexpr int kSlots = LCLS <= 16 ? 16 : 4;
-    __shared__ unsigned int sh[2][LCLS][256];
-    __shared__ double sacc[FIRST ? LCLS : 1][8][FIRST ? kSlots : 1];
-    __shared__ unsigned long long spre[2][kMaxClasses];
-    __shared__ int is_last;
-    const int shift = 56 - 8 * pass;
-    for (int i = threadIdx.x; i < 2 * LCLS * 256; i += kStatBlock) (&sh[0][0][0])[i] = 0;
-    if (FIRST) for (int i = threadIdx.x; i < ncls * 8 * kSlots; i += kStatBlock) (&sacc[0][0][0])[i] = 0.0;
-    for (int i = threadIdx.x; i < 2 * ncls; i += kStatBlock) spre[i / ncls][i % ncls] = FIRST ? 0ull : w->prefix[i / ncls][i % ncls];
-    __syncthreads();
-    const int slot = threadIdx.x & (kSlots - 1);
-    auto row = [&](double a, int c) {
-        if (c < 0 || c >= ncls) return;
-        if (FIRST) {
-            atomicAdd(&sacc[c][0][slot], 1.0);
-            if (a != a) { atomicAdd(&sacc[c][7][slot], 1.0); return; }
-            atomicAdd(&sacc[c][1][slot], a);
-            atomicAdd(&sacc[c][2][slot], a * a);
-            atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][3][slot]), static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)));
-            if (a < 30.0) atomicAdd(&sacc[c][4][slot], 1.0);
-            if (a < 15.0) atomicAdd(&sacc[c][5][slot], 1.0);
-            if (a < 7.5) atomicAdd(&sacc[c][6][slot], 1.0);
-        } else if (a != a) {
-            return;
-        }
-        const unsigned long long key = static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a));
-        const unsigned long long hi = shift >= 56 ? 0ull : key >> (shift + 8);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if (hi == spre[t][c]) {
-                if (LDS) atomicAdd(&sh[t][c][(key >> shift) & 0xFF], 1u);
-                else atomicAdd(&w->hist[t][c][(key >> shift) & 0xFF], 1u);
-            }
-    };
-    // two rows per thread and trip: one 16-byte and one 8-byte load where both arrays allow it from row `head` on (mode 0 / 1:
-    // head = 0 / 1 -- views like deg[1:], cls[1:] are 8 / 4 bytes off), two scalar loads each otherwise (mode 2); a leading
-    // and an odd last row by themselves
+// Every row once: body(angle, class) -- two rows per thread and trip: one 16-byte and one 8-byte load where both arrays allow it
+// from row `head` on (mode 0 / 1: head = 0 / 1 -- views like deg[1:], cls[1:] are 8 / 4 bytes off), two scalar loads each otherwise
+// (mode 2); a leading and an odd last row by themselves.
+template <class F>
+__device__ __forceinline__ void stats_rows(const double *__restrict__ deg, const int32_t *__restrict__ cls, int64_t B, int mode, F &&body) {
     const int64_t head = mode == 1 ? 1 : 0;
-    const int64_t pairs = (B - head) / 2;
+    const int64_t pairs = B > head ? (B - head) / 2 : 0;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kStatBlock + threadIdx.x; i < pairs; i += static_cast<int64_t>(gridDim.x) * kStatBlock) {
         double2 a;
         int2 c = make_int2(0, 0);
@@ -1292,97 +1267,273 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_pass(const double *__restr
             a = reinterpret_cast<const double2 *>(deg + head)[i];
             if (cls) c = reinterpret_cast<const int2 *>(cls + head)[i];
         }
-        row(a.x, c.x);
-        row(a.y, c.y);
+        body(a.x, c.x);
+        body(a.y, c.y);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (head == 1 && B > 0) row(deg[0], cls ? cls[0] : 0);
-        if ((B - head) & 1) row(deg[B - 1], cls ? cls[B - 1] : 0);
+        if (head == 1 && B > 0) body(deg[0], cls ? cls[0] : 0);
+        if (B > head && ((B - head) & 1)) body(deg[B - 1], cls ? cls[B - 1] : 0);
     }
+}
+
+__global__ __launch_bounds__(kStatBlock) void k_stats_zero(unsigned int *p, unsigned int n) {
+    const unsigned int i = blockIdx.x * kStatBlock + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+// LCLS = how many classes the workgroup's histograms hold: 16 (33 KB of counters) or all 64 the interface allows (132 KB of the CU's
+// 160 KB).  The float64 sums go to 32 (8) lane-private LDS slots per class and field, the slot index fastest: a wave's 64 lanes then
+// fall on 32 distinct bank pairs whatever their classes (sixteen slots were four-way conflicts: 11 us of a 30-us launch).
+template <int LCLS>
+__global__ __launch_bounds__(kStatBlock) void k_stats_window(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
+                                                             int64_t B, int mode) {
+    constexpr int kSlots = LCLS <= 16 ? 32 : 8;
+    static_assert(sizeof(unsigned int) * LCLS * kHistBins + sizeof(double) * LCLS * 4 * kSlots + 64 <= 160 * 1024, "k_stats_window: LDS budget of a gfx950 CU");
+    __shared__ unsigned int sh[LCLS][kHistBins];
+    __shared__ double sacc[LCLS][4][kSlots];
+    for (int i = threadIdx.x; i < LCLS * kHistBins; i += kStatBlock) (&sh[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < ncls * 4 * kSlots; i += kStatBlock) (&sacc[0][0][0])[i] = 0.0;
     __syncthreads();
-    if (LDS) {
-        for (int i = threadIdx.x; i < 2 * ncls * 256; i += kStatBlock) {
-            const int t = i / (ncls * 256), c = (i / 256) % ncls, d = i % 256;
-            const unsigned int v = sh[t][c][d];
-            if (v) atomicAdd(&w->hist[t][c][d], v);
-        }
-    }
-    if (FIRST) {
-        for (int i = threadIdx.x; i < ncls * 8; i += kStatBlock) {
-            const int c = i / 8, f = i % 8;
-            if (f == 3) {
-                unsigned long long m = 0;
-                for (int k = 0; k < kSlots; ++k) { const unsigned long long v = static_cast<unsigned long long>(__double_as_longlong(sacc[c][3][k])); m = v > m ? v : m; }
-                atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][3]), m);
-            } else {
-                double v = 0.0;
-                for (int k = 0; k < kSlots; ++k) v += sacc[c][f][k];
-                if (v != 0.0) atomicAdd(&w->acc[c][f], v);
-            }
-        }
-    }
-    // The last workgroup to get here closes the pass.  Every wave drains its own atomics (they stay in vmcnt until the
-    // memory side has acknowledged them), the barrier collects the waves, then ONE lane publishes: a release fence by all
-    // 1024 threads of 512 workgroups (each a write-back of the XCD's L2) cost 75 us per pass.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int slot = threadIdx.x & (kSlots - 1);
+    stats_rows(deg, cls, B, mode, [&](double a, int c) {
+        if (c < 0 || c >= ncls) return;
+        if (a != a) { atomicAdd(&sacc[c][3][slot], 1.0); return; }
+        atomicAdd(&sacc[c][0][slot], a);
+        atomicAdd(&sacc[c][1][slot], a * a);
+        const unsigned long long key = angle_key(a);
+        atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][2][slot]), key);
+        atomicAdd(&sh[c][window_bin(key)], 1u);
+    });
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        is_last = atomicAdd(&w->tickets[pass], 1u) == gridDim.x - 1 ? 1 : 0;
-        if (is_last) __threadfence();
+    for (int i = threadIdx.x; i < ncls * kHistBins; i += kStatBlock) {
+        const unsigned int v = sh[i / kHistBins][i % kHistBins];
+        if (v) atomicAdd(&w->hist[i / kHistBins][i % kHistBins], v);
     }
-    __syncthreads();
-    if (!is_last) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int pair = wave; pair < 2 * ncls; pair += kStatBlock / 64) {      // a wave per (selection, class)
-        const int t = pair / ncls, c = pair % ncls;
-        long long k;
-        if (FIRST) {                                                    // middle ranks among the non-NaN rows of the class
-            const long long n = static_cast<long long>(coherent_f64(&w->acc[c][0]) - coherent_f64(&w->acc[c][7]));
-            k = n > 0 ? (t == 0 ? (n - 1) / 2 : n / 2) : 0;
+    for (int i = threadIdx.x; i < ncls * 4; i += kStatBlock) {
+        const int c = i / 4, f = i % 4;
+        if (f == 2) {
+            unsigned long long m = 0;
+            for (int k = 0; k < kSlots; ++k) { const unsigned long long v = static_cast<unsigned long long>(__double_as_longlong(sacc[c][2][k])); m = v > m ? v : m; }
+            if (m) atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][2]), m);
         } else {
-            k = w->krem[t][c];
+            double v = 0.0;
+            for (int k = 0; k < kSlots; ++k) v += sacc[c][f][k];
+            if (v != 0.0) atomicAdd(&w->acc[c][f], v);
         }
-        unsigned int h[4];
-        unsigned int mine = 0;
+    }
+}
+
+// A wave per (selection, class): the bin holding the middle element and its rank inside the bin; the counts that are sums over
+// bins.  Runs as the prologue of EVERY workgroup of k_stats_collect (a launch of its own cost 4.8 us for 2 us of work: the
+// histograms are 20 KB per ten classes, L2-resident); every workgroup keeps the bins in LDS, workgroup 0 also writes the workspace.
+__device__ __forceinline__ void stats_select(int ncls, StatWork *w, int (*sbin)[kMaxClasses], bool publish) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int kPerLane = (kHistBins + 63) / 64;                         // 9 bins per lane
+    for (int pair = wave; pair < 2 * ncls; pair += kStatBlock / 64) {
+        const int t = pair / ncls, c = pair % ncls;
+        unsigned int h[kPerLane];
+        unsigned int mine = 0, b30 = 0, b15 = 0, b7 = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = coherent_u32(&w->hist[t][c][4 * lane + j]); mine += h[j]; }
+        for (int j = 0; j < kPerLane; ++j) {
+            const int bin = kPerLane * lane + j;
+            h[j] = bin < kHistBins ? w->hist[c][bin] : 0u;
+            mine += h[j];
+            b30 += bin < kEdge30 ? h[j] : 0u; b15 += bin < kEdge15 ? h[j] : 0u; b7 += bin < kEdge7p5 ? h[j] : 0u;
+        }
         unsigned int incl = mine;                                       // inclusive prefix sum over the lanes
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned int up = __shfl_up(incl, off, 64);
             if (lane >= off) incl += up;
         }
+        const long long n = static_cast<long long>(__shfl(incl, 63, 64));   // the non-NaN rows of the class
+        const long long k = n > 0 ? (t == 0 ? (n - 1) / 2 : n / 2) : 0;
         const long long before = static_cast<long long>(incl - mine);
-        // the digit holding rank k: the first bin whose cumulative count exceeds k (the last bin if none does)
-        const bool here = k >= before && k < before + static_cast<long long>(mine);
-        const unsigned long long vote = __ballot(here);
-        const int owner = vote ? __ffsll(static_cast<long long>(vote)) - 1 : 63;
-        if (lane == owner) {
+        if (n > 0 && k >= before && k < before + static_cast<long long>(mine)) {       // exactly one lane (the counts add up to n > k)
             long long kk = k - before;
-            unsigned int d = 0;
-            if (vote) { for (; d < 3; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; } }
-            else { d = 3; kk = k - before - (mine - h[3]); if (kk < 0) kk = 0; }
-            w->krem[t][c] = kk;
-            w->prefix[t][c] = (spre[t][c] << 8) | static_cast<unsigned long long>(4 * lane + d);
+            int d = 0;
+            for (; d < kPerLane - 1; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; }
+            sbin[t][c] = kPerLane * lane + d;
+            if (publish) { w->sel_bin[t][c] = kPerLane * lane + d; w->krem[t][c] = kk; }
         }
+        if (n <= 0 && lane == 0) {
+            sbin[t][c] = -1;
+            if (publish) { w->sel_bin[t][c] = -1; w->krem[t][c] = 0; }
+        }
+        if (t == 0 && publish) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w->hist[t][c][4 * lane + j] = 0;     // ready for the next pass (next launch)
+            for (int off = 32; off > 0; off >>= 1) { b30 += __shfl_xor(b30, off, 64); b15 += __shfl_xor(b15, off, 64); b7 += __shfl_xor(b7, off, 64); }
+            if (lane == 0) {
+                w->count[c] = static_cast<double>(n) + w->acc[c][3];
+                w->below[0][c] = b30; w->below[1][c] = b15; w->below[2][c] = b7;
+            }
+        }
     }
-    if (pass != kStatPasses - 1) return;
+}
+
+// The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
+// counting sort in LDS -- into the region of the candidate buffer the workgroup owns; where each class starts in the region and how
+// many it holds goes into a table, so that a finishing workgroup reads its own class only.
+__global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
+                                                              int64_t B, int mode) {
+    __shared__ unsigned long long skey[kStatRegion];
+    __shared__ unsigned short stag[kStatRegion];
+    __shared__ int sbin[2][kMaxClasses];
+    __shared__ unsigned int ccount[kMaxClasses], cstart[kMaxClasses], ccur[kMaxClasses];
+    __shared__ unsigned int cur;
+    stats_select(ncls, w, sbin, blockIdx.x == 0);
+    for (int i = threadIdx.x; i < ncls; i += kStatBlock) ccount[i] = 0;
+    if (threadIdx.x == 0) cur = 0;
     __syncthreads();
-    for (int c = threadIdx.x; c < ncls; c += kStatBlock) {
-        const double n = coherent_f64(&w->acc[c][0]), nan = coherent_f64(&w->acc[c][7]), m = n - nan;
+    stats_rows(deg, cls, B, mode, [&](double a, int c) {
+        if (c < 0 || c >= ncls || a != a) return;
+        const unsigned long long key = angle_key(a);
+        const int bin = window_bin(key);
+        const unsigned int t0 = bin == sbin[0][c] ? 1u : 0u, t1 = bin == sbin[1][c] ? 1u : 0u;
+        if (t0 | t1) {
+            const unsigned int at = atomicAdd(&cur, 1u);
+            if (at < kStatRegion) { skey[at] = key; stag[at] = static_cast<unsigned short>(c | t0 << 8 | t1 << 9); }
+        }
+    });
+    __syncthreads();
+    const unsigned int n = cur < kStatRegion ? cur : kStatRegion;
+    if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);
+    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) atomicAdd(&ccount[stag[i] & 0xFF], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int at = 0;
+        for (int c = 0; c < ncls; ++c) { cstart[c] = at; ccur[c] = at; at += ccount[c]; }
+    }
+    __syncthreads();
+    unsigned long long *mine = w->cand + static_cast<size_t>(blockIdx.x) * kStatRegion;
+    unsigned char *mine_tag = w->tag + static_cast<size_t>(blockIdx.x) * kStatRegion;
+    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) {
+        const unsigned int at = atomicAdd(&ccur[stag[i] & 0xFF], 1u);
+        mine[at] = skey[i];
+        mine_tag[at] = static_cast<unsigned char>(stag[i] >> 8);
+    }
+    for (int c = threadIdx.x; c < ncls; c += kStatBlock) { w->wg_cstart[blockIdx.x][c] = cstart[c]; w->wg_ccount[blockIdx.x][c] = ccount[c]; }
+}
+
+// One workgroup per class: the regions' counts -> prefix sums in LDS (entry i of the list: the region is found by bisection over
+// them), the class's candidates out of the regions (into LDS when they fit), both middle elements by ONE radix select of 8-bit
+// digits -- two (prefix, rank) states side by side, they part where the two elements differ -- then the class's row of the result
+// (np.mean / np.std / np.max / np.median / the thresholds).
+__global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__restrict__ deg, const int32_t *__restrict__ cls, StatWork *w, int64_t B,
+                                                             double *__restrict__ stats, unsigned int groups) {
+    __shared__ unsigned long long lkey[kStatLdsKeys];
+    __shared__ unsigned char ltag[kStatLdsKeys];
+    __shared__ unsigned int prefix_of[kStatMaxWgs + 1], start_of[kStatMaxWgs];
+    __shared__ unsigned int hh[2][256];
+    __shared__ unsigned long long s_prefix[2];
+    __shared__ long long s_k[2];
+    const int c = blockIdx.x;
+    const double n = w->count[c], nan = w->acc[c][3], m = n - nan;
+    const bool overflow = w->overflow != 0u;
+    const int bins[2] = {w->sel_bin[0][c], w->sel_bin[1][c]};
+    // inclusive scan of the regions' counts for THIS class (groups <= 1024: one value per thread, Hillis-Steele), shifted into prefix_of[1..]
+    unsigned int run = threadIdx.x < groups ? w->wg_ccount[threadIdx.x][c] : 0u;
+    start_of[threadIdx.x] = threadIdx.x < groups ? w->wg_cstart[threadIdx.x][c] : 0u;
+    prefix_of[threadIdx.x + 1] = run;
+    if (threadIdx.x == 0) prefix_of[0] = 0;
+    __syncthreads();
+    for (int off = 1; off < kStatBlock; off <<= 1) {
+        const unsigned int up = static_cast<int>(threadIdx.x) >= off ? prefix_of[threadIdx.x + 1 - off] : 0u;
+        __syncthreads();
+        run += up;
+        prefix_of[threadIdx.x + 1] = run;
+        __syncthreads();
+    }
+    const unsigned int total = prefix_of[groups];                       // the class's candidates
+    auto entry = [&](unsigned int i) -> size_t {
+        unsigned int lo = 0, hi = groups;                               // the last g with prefix_of[g] <= i
+        while (hi - lo > 1) { const unsigned int mid = (lo + hi) >> 1; if (prefix_of[mid] <= i) lo = mid; else hi = mid; }
+        return static_cast<size_t>(lo) * kStatRegion + start_of[lo] + (i - prefix_of[lo]);
+    };
+    const bool cached = m > 0 && !overflow && total <= static_cast<unsigned int>(kStatLdsKeys);
+    if (cached) {
+        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) {
+            const size_t e = entry(i);
+            lkey[i] = w->cand[e];
+            ltag[i] = w->tag[e];
+        }
+        __syncthreads();
+    }
+    double middle[2] = {0.0, 0.0};
+    if (m > 0) {
+        const bool edge[2] = {bins[0] == 0 || bins[0] == kHistBins - 1, bins[1] == 0 || bins[1] == kHistBins - 1};
+        if (threadIdx.x < 2) {
+            const int t = threadIdx.x;
+            s_prefix[t] = edge[t] ? 0ull : static_cast<unsigned long long>(kWinBase + bins[t] - 1);
+            s_k[t] = w->krem[t][c];
+        }
+        __syncthreads();
+        // digits from bit 56 down when an edge bin is involved (it does not fix the top 16 bits), else from bit 40; a selection whose
+        // bin fixes them sits out the two top digits
+        for (int shift = (edge[0] || edge[1]) ? 56 : 40; shift >= 0; shift -= 8) {
+            for (int i = threadIdx.x; i < 512; i += kStatBlock) (&hh[0][0])[i] = 0;
+            __syncthreads();
+            const bool active[2] = {edge[0] || shift <= 40, edge[1] || shift <= 40};
+            const unsigned long long prefix[2] = {s_prefix[0], s_prefix[1]};
+            auto vote = [&](unsigned long long key, unsigned int which) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (active[t] && (which >> t & 1u) && (shift == 56 || (key >> (shift + 8)) == prefix[t])) atomicAdd(&hh[t][(key >> shift) & 0xFF], 1u);
+            };
+            if (cached) {
+                for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) vote(lkey[i], ltag[i]);
+            } else if (!overflow) {
+                for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) {
+                    const size_t e = entry(i);
+                    vote(w->cand[e], w->tag[e]);
+                }
+            } else {                                                    // the rows themselves, filtered to the class and the bins
+                for (int64_t i = threadIdx.x; i < B; i += kStatBlock) {
+                    const double a = deg[i];
+                    const int cc = cls ? cls[i] : 0;
+                    if (cc != c || a != a) continue;
+                    const unsigned long long key = angle_key(a);
+                    const int bin = window_bin(key);
+                    vote(key, (bin == bins[0] ? 1u : 0u) | (bin == bins[1] ? 2u : 0u));
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 128) {                                    // wave t: the digit holding selection t's rank -- 256 bins, four per lane, a wave prefix sum
+                const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                unsigned int h[4], mine = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { h[j] = hh[t][4 * lane + j]; mine += h[j]; }
+                unsigned int incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned int up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                const long long before = static_cast<long long>(incl - mine), k = s_k[t];
+                if (active[t] && k >= before && k < before + static_cast<long long>(mine)) {
+                    long long kk = k - before;
+                    unsigned int d = 0;
+                    for (; d < 3; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; }
+                    s_k[t] = kk;
+                    s_prefix[t] = (prefix[t] << 8) | static_cast<unsigned long long>(4 * lane + d);
+                }
+            }
+            __syncthreads();
+        }
+        middle[0] = __longlong_as_double(static_cast<long long>(s_prefix[0]));
+        middle[1] = __longlong_as_double(static_cast<long long>(s_prefix[1]));
+    }
+    if (threadIdx.x == 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
         double *o = stats + c * kStatFields;
-        const double mean = coherent_f64(&w->acc[c][1]) / m;
+        const double mean = w->acc[c][0] / m;
         o[0] = n;
-        o[1] = nan > 0 ? __longlong_as_double(0x7ff8000000000000ll) : mean;
-        const double var = coherent_f64(&w->acc[c][2]) / m - mean * mean;
+        o[1] = nan > 0 ? qnan : mean;
+        const double var = w->acc[c][1] / m - mean * mean;
         o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
-        o[3] = nan > 0 ? o[1] : coherent_f64(&w->acc[c][3]);
-        const double lo = __longlong_as_double(static_cast<long long>(w->prefix[0][c])), hi = __longlong_as_double(static_cast<long long>(w->prefix[1][c]));
-        o[4] = (nan > 0 || m <= 0) ? __longlong_as_double(0x7ff8000000000000ll) : 0.5 * (lo + hi);
-        o[5] = coherent_f64(&w->acc[c][4]) / n; o[6] = coherent_f64(&w->acc[c][5]) / n; o[7] = coherent_f64(&w->acc[c][6]) / n;   // (x < t).sum() / len(x)
+        o[3] = nan > 0 ? o[1] : w->acc[c][2];
+        o[4] = (nan > 0 || m <= 0) ? qnan : 0.5 * (middle[0] + middle[1]);
+        o[5] = w->below[0][c] / n; o[6] = w->below[1][c] / n; o[7] = w->below[2][c] / n;   // (x < t).sum() / len(x)
     }
 }
 
@@ -1838,8 +1989,10 @@ int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, v
 
 // one launch for B <= 1024 (one workgroup) and with a workspace; else init / memset launch + kernel (+ the mean's)
 static int reduce_how(void *workspace, int64_t B, unsigned *grid) {
-    const unsigned want = grid_for(B);
-    *grid = B <= kSmallBatch ? 1u : (want < 2048u ? want : 2048u);
+    // two workgroups' worth per CU, grid-stride: the ticket at the end is one same-address atomic per workgroup (~12 ns each,
+    // serialised at the memory side -- 2048 of them were 7 us on top of a 37-us kernel)
+    const unsigned want = grid_for(B), cap = 2u * static_cast<unsigned>(device_cus());
+    *grid = B <= kSmallBatch ? 1u : (want < cap ? want : cap);
     return B <= kSmallBatch ? 1 : (workspace != nullptr ? 2 : 0);
 }
 
@@ -2050,22 +2203,23 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     SO3_CHECK_ARGS(stats != nullptr && workspace != nullptr && (B == 0 || deg != nullptr), "so3_angle_stats: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
     StatWork *w = static_cast<StatWork *>(workspace);
-    const hipError_t e = hipMemsetAsync(w, 0, sizeof(StatWork), s);
-    if (e != hipSuccess) return fail(static_cast<int>(e), "so3_angle_stats: memset");
+    // (the sums, the overflow flag and the histograms of the classes in use; a memset node of this size costs two fill kernels, ~5 us each)
+    const unsigned int zwords = static_cast<unsigned int>((offsetof(StatWork, hist) + sizeof(unsigned int) * kHistBins * static_cast<size_t>(ncls)) / 4);
+    k_stats_zero<<<(zwords + kStatBlock - 1) / kStatBlock, kStatBlock, 0, s>>>(reinterpret_cast<unsigned int *>(w), zwords);
     // 16-byte loads of deg and 8-byte loads of cls from row 0 (mode 0) or row 1 (mode 1) on, wherever both arrays are aligned there
     auto vec_ok = [&](int64_t head) {
         return (reinterpret_cast<uintptr_t>(deg + head) & 15u) == 0 && (cls == nullptr || (reinterpret_cast<uintptr_t>(cls + head) & 7u) == 0);
     };
     const int mode = vec_ok(0) ? 0 : (vec_ok(1) ? 1 : 2);
+    // one 1024-thread workgroup per CU, two rows per thread and trip (two per CU measured slower: twice the flushes and LDS histograms)
+    int64_t cap = static_cast<int64_t>(device_cus());
+    if (cap > kStatMaxWgs) cap = kStatMaxWgs;
     const int64_t want = (B / 2 + kStatBlock - 1) / kStatBlock;
-    const int64_t cap = 2 * static_cast<int64_t>(device_cus());
     const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));
-    for (int pass = 0; pass < kStatPasses; ++pass) {
-#define PASS(LC, FI) k_stats_pass<LC, FI><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, pass, stats, mode)
-        if (ncls <= kStatLdsClasses) { if (pass == 0) PASS(kStatLdsClasses, true); else PASS(kStatLdsClasses, false); }
-        else { if (pass == 0) PASS(kMaxClasses, true); else PASS(kMaxClasses, false); }
-#undef PASS
-    }
+    if (ncls <= kStatLdsClasses) k_stats_window<kStatLdsClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+    else k_stats_window<kMaxClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+    k_stats_collect<<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+    k_stats_finish<<<static_cast<unsigned>(ncls), kStatBlock, 0, s>>>(deg, cls, w, B, stats, grid);
     return check_launch("so3_angle_stats");
 }
 

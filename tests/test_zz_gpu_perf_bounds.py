@@ -28,8 +28,8 @@ def test_hard_rows_cost_is_bounded(rr):
     workgroup shares in LDS -- when they are few in their round, and redone one matrix per lane when the workgroup has streamed
     its share; a round dense in them runs the Jacobi path on the spot.  Caps = the worst ratio measured over round 4's devices
     plus ~12 %: a batch with 1 % of hard rows K1 <= 1.35 x / K3 <= 1.2 x a Gaussian batch (round 3: 1.3-1.46 / 1.3-1.5), 10 %
-    K1 <= 1.7 x / K3 <= 1.45 x, whole batches K1 <= 1.8 x (ties: 2.15 x) / K3 <= 1.6 x; zero rows (dead heads) and rows that are
-    merely far from unit scale or of rank two cost nothing extra (<= 1.15 x)."""
+    K1 <= 1.7 x / K3 <= 1.45 x, whole batches K1 <= 1.8 x (ties: 2.15 x) / K3 <= 1.6 x; zero rows (dead heads) cost the forward
+    nothing extra (their backward stays a hard row's), nor do rows that are merely far from unit scale or of rank two (<= 1.15 x)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
     hr = importlib.util.module_from_spec(spec)
@@ -83,6 +83,8 @@ def test_hard_rows_cost_is_bounded(rr):
             k1, k3 = both(xs)
             del xs
             cap1, cap3 = caps[share] if name in hard else (1.15, 1.15)
+            if name == "all zero":
+                cap3 = caps[share][1]              # the BACKWARD of a zero row still goes through the Jacobi frames' floored denominators: hard for K3
             if name == "generic ties" and share == 1.0:
                 cap1 = 2.15                        # both algorithms on every row: no invariant tells a tie from a Gaussian row beforehand
             report["%s %g %%" % (name, share * 100)] = (round(k1 / g1, 2), round(k3 / g3, 2))
