@@ -36,7 +36,7 @@ class F1(torch.autograd.Function):
         return None, None
 
 
-fwd = rr._fn("so3_frob_fwd_bwd_ws_bf16")
+fwd = rr._fn("so3_frob_fwd_bwd_v2_bf16")
 scale = rr._fn("so3_scale_bf16")
 dm = torch.empty_like(x)
 loss = torch.empty((), device=dev)
@@ -50,7 +50,7 @@ items = [
     ("_stream(dev)", lambda: rr._stream(dev)),
     ("_on_device(dev) with-block", lambda: rr._on_device(dev).__enter__()),
     ("data_ptr() x4", lambda: (x.data_ptr(), t.data_ptr(), r.data_ptr(), dm.data_ptr())),
-    ("K3 launch through _so3fast (enqueue only)", lambda: fwd(x.data_ptr(), t.data_ptr(), r.data_ptr(), dm.data_ptr(), None, loss.data_ptr(), None, 512, rr._stream(dev))),
+    ("K3 launch through _so3fast (enqueue only)", lambda: fwd(x.data_ptr(), t.data_ptr(), r.data_ptr(), dm.data_ptr(), None, loss.data_ptr(), None, 0, 512, rr._stream(dev))),
     ("scale launch through _so3fast", lambda: scale(dm.data_ptr(), g1.data_ptr(), dm.data_ptr(), 4608, rr._stream(dev))),
     ("torch mul launch (dm * g)", lambda: dm * g1),
     ("Function.apply, 2 inputs, 1 output, no grad path", lambda: F1.apply(xf, t)),
