@@ -61,26 +61,28 @@ def main():
     timeit("K1 so3_project_fwd_bf16 (bf16 in, f32 out)", lambda i: lib.so3_project_fwd_bf16(p(xb[i % NB]), p(r[i % NB]), None, n, st), 54 * n)
     timeit("K2 so3_project_bwd_f32", lambda i: lib.so3_project_bwd_f32(p(x[i % NB]), p(g[i % NB]), p(dm[i % NB]), n, st), 108 * n)
     timeit("K2 so3_project_bwd_bf16", lambda i: lib.so3_project_bwd_bf16(p(xb[i % NB]), p(g[i % NB]), p(dmb[i % NB]), n, st), 72 * n)
-    timeit("K3 so3_frob_fwd_bwd_f32 (R + dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), n, st), 144 * n)
-    timeit("K3 so3_frob_fwd_bwd_f32 (dM + loss)", lambda i: lib.so3_frob_fwd_bwd_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), n, st), 108 * n)
-    timeit("K3' so3_frob_loss_f32 (loss + dRpred)", lambda i: lib.so3_frob_loss_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), n, st), 108 * n)
-    # the same reductions with a caller-owned workspace (what the Python mirror passes): no memset / init launch, no atomics on the result
+    # the reducing entry points exist once (round 4): workspace nullable, a flags word.  "atomics" = no workspace (a zero-fill launch in front,
+    # one atomic per workgroup behind); "workspace" = caller-owned, one launch, what the Python mirror passes for K3 / K3';
+    # "zeroed slots" = SO3_PREZEROED, one launch, what the mirror passes for the metrics
     ws = torch.zeros(lib.so3_reduce_workspace_bytes(), dtype=torch.uint8, device=dev)
     lm = torch.empty((), dtype=torch.float32, device=dev)
-    timeit("K3 so3_frob_fwd_bwd_ws_f32 (R + dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 144 * n)
-    timeit("K3 so3_frob_fwd_bwd_ws_f32 (dM + loss, workspace)", lambda i: lib.so3_frob_fwd_bwd_ws_f32(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
-    timeit("K3' so3_frob_loss_ws_f32 (loss + dRpred, workspace)", lambda i: lib.so3_frob_loss_ws_f32(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), n, st), 108 * n)
-    # ... and the metric kernels with accumulators the caller zeroed (the mirror hands out slots of a zero-filled pool): one launch
     pool = torch.zeros(4096, 4, dtype=torch.float64, device=dev)
     slot = lambda i: (P(pool[i % 4096].data_ptr()), P(pool[i % 4096].data_ptr() + 16))
-    timeit("K4 so3_angle_error_acc (fused sum,count, zeroed slots)", lambda i: lib.so3_angle_error_acc(p(r[i % NB]), p(rt[i % NB]), None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
-    timeit("K1+K4 so3_project_angle_error_acc_f32 (sum: float64 on every row, zeroed slots)", lambda i: lib.so3_project_angle_error_acc_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], 0, n, st), 72 * n)
-    f32sum = _lib.PREZEROED
-    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, zeroed slots)", lambda i: lib.so3_project_angle_error_v2_f32(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], None, f32sum, n, st), 72 * n)
-    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, workspace)", lambda i: lib.so3_project_angle_error_v2_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), p(ws), 0, n, st), 72 * n)
-    timeit("K4 so3_angle_error (per-row deg)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), 0, n, st), 80 * n)
-    timeit("K4 so3_angle_error (fused sum,count)", lambda i: lib.so3_angle_error(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), 0, n, st), 72 * n)
-    timeit("K1+K4 so3_project_angle_error_f32 (fused sum,count)", lambda i: lib.so3_project_angle_error_f32(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), 0, n, st), 72 * n)
+    PZ, EX = _lib.PREZEROED, _lib.EXACT_F64
+    k3, k3p, k4, k14 = lib.so3_frob_fwd_bwd_v2_f32, lib.so3_frob_loss_v2_f32, lib.so3_angle_error_v2, lib.so3_project_angle_error_v2_f32
+    timeit("K3 so3_frob_fwd_bwd_v2_f32 (R + dM + loss, atomics)", lambda i: k3(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), None, None, 0, n, st), 144 * n)
+    timeit("K3 so3_frob_fwd_bwd_v2_f32 (dM + loss, atomics)", lambda i: k3(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), None, None, 0, n, st), 108 * n)
+    timeit("K3 so3_frob_fwd_bwd_v2_f32 (R + dM + loss + mean, workspace)", lambda i: k3(p(x[i % NB]), p(rt[i % NB]), p(r[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), 0, n, st), 144 * n)
+    timeit("K3 so3_frob_fwd_bwd_v2_f32 (dM + loss + mean, workspace)", lambda i: k3(p(x[i % NB]), p(rt[i % NB]), None, p(dm[i % NB]), p(ls), p(lm), p(ws), 0, n, st), 108 * n)
+    timeit("K3' so3_frob_loss_v2_f32 (loss + dRpred, atomics)", lambda i: k3p(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), None, None, 0, n, st), 108 * n)
+    timeit("K3' so3_frob_loss_v2_f32 (loss + dRpred + mean, workspace)", lambda i: k3p(p(r[i % NB]), p(rt[i % NB]), p(dm[i % NB]), p(ls), p(lm), p(ws), 0, n, st), 108 * n)
+    timeit("K4 so3_angle_error_v2 (per-row deg)", lambda i: k4(p(r[i % NB]), p(rt[i % NB]), p(deg), None, p(fl), None, 0, n, st), 80 * n)
+    timeit("K4 so3_angle_error_v2 (sum,count, zeroed slots)", lambda i: k4(p(r[i % NB]), p(rt[i % NB]), None, slot(i)[0], slot(i)[1], None, PZ, n, st), 72 * n)
+    timeit("K4 so3_angle_error_v2 (sum,count, init launch + atomics)", lambda i: k4(p(r[i % NB]), p(rt[i % NB]), None, p(sc), p(fl), None, 0, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, zeroed slots)", lambda i: k14(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], None, PZ, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: float64 on every row, zeroed slots)", lambda i: k14(p(x[i % NB]), p(rt[i % NB]), None, None, slot(i)[0], slot(i)[1], None, PZ | EX, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (sum: f32 outside the band, workspace)", lambda i: k14(p(x[i % NB]), p(rt[i % NB]), None, None, p(sc), p(fl), p(ws), 0, n, st), 72 * n)
+    timeit("K1+K4 so3_project_angle_error_v2_f32 (per-row deg: float64)", lambda i: k14(p(x[i % NB]), p(rt[i % NB]), None, p(deg), None, p(fl), None, 0, n, st), 80 * n)
     # float64 arguments (the reference's metric casts to double itself; callers that already hold double rotations): one launch with the workspace
     r64 = [t.double() for t in rt[:2]]
     g64 = torch.empty(n, 9, dtype=torch.float64, device=dev)
