@@ -332,7 +332,7 @@ def secondary_configs(lib, dev):
     blocks.sort()
     # which autograd node served those steps: csrc/autograd_node.cpp's (no interpreter inside forward / backward) or the Python class
     probe, _ = rr.frobenius_head(xg, t4.view(b, 3, 3))
-    out["config4_head_loss_backward_b512_bf16"]["mirror_path"] = "cpp_node" if "FrobeniusHeadNode" in type(probe.grad_fn).__name__ else "python"
+    out["config4_head_loss_backward_b512_bf16"]["mirror_path"] = "cpp_node" if "FrobeniusHeadNode" in probe.grad_fn.name() else "python"
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd"] = 0.5 * (blocks[2] + blocks[3])
     out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd_best_block"] = blocks[0]
 
