@@ -279,8 +279,11 @@ int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const floa
  *   cls       in  optional B int32 class ids in [0, ncls) (NULL: one class); rows with other ids are ignored
  *   stats     out ncls x 8 doubles: count, mean, std (population, as np.std), max, median (EXACT: radix select
  *                 on the float64 bits, the two middle elements averaged as np.median does), acc<30, acc<15, acc<7.5
- *   workspace     caller-owned scratch of so3_angle_stats_workspace_bytes() bytes (contents undefined before/after)
+ *   workspace     caller-owned scratch of so3_angle_stats_workspace_bytes() bytes (~10 MB: histograms and a buffer for the
+ *                 candidates of the medians; contents undefined before/after)
  * ncls <= 64.  A class containing a NaN angle reports NaN for mean/std/max/median, as numpy does.
+ * Four launches (a zero kernel, a histogram pass, a pass that compacts the rows of the medians' 1/16-octave bins, one workgroup
+ * per class to select among them): two passes over the rows; 45 us per 1M angles in 10 classes.
  */
 size_t so3_angle_stats_workspace_bytes(void);
 int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double *stats, void *workspace,
