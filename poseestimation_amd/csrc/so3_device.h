@@ -222,6 +222,14 @@ template <class T> __device__ __forceinline__ V3<T> sel(typename Tr<T>::mask c, 
     return mk<T>(Tr<T>::sel(c, a.x, b.x), Tr<T>::sel(c, a.y, b.y), Tr<T>::sel(c, a.z, b.z));
 }
 
+// ---- the Jacobi path (section 3b) and the backward through its frames: contraction as WRITTEN ------------------------------
+// hipcc's default (-ffp-contract=fast-honor-pragmas) lets the backend fuse a multiply with an add from ANOTHER statement, and
+// whether it does depends on what the inliner put next to what: s1 = |t1|^2 rsq(.) followed by s1 + s2 became one fma where the
+// frames were used straight away (the redo of parked rows) and stayed two operations where they passed through a branch (the
+// tile kernels, a dense round) -- one ulp in a denominator, 1e-5 (near-reflections) to 1e-1 (ties) in dM.  Everything a hard
+// row goes through therefore fuses only what one expression spells out (fma calls, a * b + c): a row's bits do not depend on
+// the kernel, the instantiation or the wave-mates it met (tests/test_gpu_parity.py::test_parked_and_dense_hard_rows_*).
+#pragma clang fp contract(on)
 // Orthogonalise columns p and q by a plane rotation (p, q) <- (c p + s q, c q - s p).
 // With d = |p|^2 - |q|^2, g = 2 p.q, h = sqrt(d^2 + g^2):  (c, s) = (d + sgn(d) h, g) normalised,
 // i.e. tan(theta) = g / (d + sgn(d) h), |theta| <= pi/4 (up to a common sign of both new columns,
@@ -442,6 +450,8 @@ template <class T> __device__ __forceinline__ void rotation_rows(V3<T> u1, V3<T>
 template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd<T> &f, T (&r)[9]) {
     rotation_rows<T>(f.u1, f.u2, f.v1, f.v2, r);
 }
+
+#pragma clang fp contract(fast)
 
 // =====================================================================================================================
 // K1 forward, fast path: the rotation as the dominant eigenvector of Davenport's 4x4 matrix.
@@ -851,6 +861,7 @@ __device__ __forceinline__ bool det_negative(const float (&m)[9]) {
 }
 
 // dM = U' Bm V^T for upstream G (row-major), Bm_ij = (A_ij - A_ji)/(s_i + s_j), A = U'^T G V.
+#pragma clang fp contract(on)         // (see the Jacobi path)
 template <class T>
 __device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T (&g)[9], T (&dm)[9]) {
     typedef Tr<T> R;
@@ -878,6 +889,8 @@ __device__ __forceinline__ void project_backward(const SignedSvd<T> &f, const T 
     dm[3] = r1.x; dm[4] = r1.y; dm[5] = r1.z;
     dm[6] = r2.x; dm[7] = r2.y; dm[8] = r2.z;
 }
+
+#pragma clang fp contract(fast)
 
 // =====================================================================================================================
 // Backward of the projection in terms of R alone (round 2): with S = R^T M (symmetric at the optimum, eigenvalues

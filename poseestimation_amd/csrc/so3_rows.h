@@ -668,6 +668,7 @@ struct OpProject : OpBase {
     }
     template <int NPL>
     __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+#pragma clang fp contract(on)         // as the Jacobi path it continues (so3_device.h)
         float m[9], r[9];
         parked_words<kParkCap, 9>(ctx.park, e, 0, m);
         rotation_from(signed_svd<false, float>(m), r);
@@ -705,6 +706,7 @@ struct OpProjectBwd : OpBase {
     }
     template <int NPL>
     __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+#pragma clang fp contract(on)         // as the Jacobi path it continues (so3_device.h)
         float m[9], g[9], dm[9];
         parked_words<kParkCap, 9>(ctx.park, e, 0, m);
         parked_words<kParkCap, 9>(ctx.park, e, 9, g);
@@ -769,6 +771,7 @@ struct OpFrobHead : OpBase {
     }
     template <int NPL>
     __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+#pragma clang fp contract(on)         // as the Jacobi path it continues (so3_device.h)
         float m[9], t[9], r[9], g[9];
         parked_words<kParkCap, 9>(ctx.park, e, 0, m);
         parked_words<kParkCap, 9>(ctx.park, e, 9, t);
@@ -1027,6 +1030,7 @@ struct OpProjectAngle : OpBase {
     }
     template <int NPL>
     __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
+#pragma clang fp contract(on)         // as the Jacobi path it continues (so3_device.h)
         float m[9], t[9], r[9];
         parked_words<kParkCap, 9>(ctx.park, e, 0, m);
         parked_words<kParkCap, 9>(ctx.park, e, 9, t);

@@ -401,6 +401,77 @@ def test_hard_row_queue_over_the_rounds_of_a_wave(rr, plan):
             assert 0.01 < share < 0.06, (kind, share)
 
 
+def test_parked_and_dense_hard_rows_in_the_two_input_kernels(rr):
+    """K2, K3 and K1+K4 park the hard rows of a round that holds few of them (both inputs and the row number, in the workgroup's LDS
+    list) and redo them one matrix per lane behind the loop; a dense round runs the packed Jacobi path on the spot.  Every row of a
+    batch whose share of hard rows runs from none to all by region, bit for bit against the same rows through the one-row-per-thread
+    kernels (K2: the tile kernel in 63-row calls; K3, K1+K4: the one-workgroup kernels in 1024-row calls -- 1/16 of the batch, so the
+    1/B in the gradient differs by an exact power of two), every output of every variant; the loss and the angle sum to round-off."""
+    from poseestimation_amd import _lib
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
+    hr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hr)
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(321)
+    d = torch.device(DEV)
+    n, chunk = 16384, 1024
+    x = torch.randn(n, 9, device=DEV, generator=gen)
+    families = ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one", "all zero")
+    region = n // 8
+    for j, share in enumerate((0.0, 0.005, 0.03, 0.1, 0.2, 0.35, 0.6, 1.0)):   # parked (sparse), the list filling up, dense
+        lo, hi = j * region, (j + 1) * region
+        pick = torch.nonzero(torch.rand(hi - lo, device=DEV, generator=gen) < share).flatten() + lo
+        for f, name in enumerate(families):
+            idx = pick[f::len(families)]
+            if idx.numel():
+                x[idx] = hr.family(name, idx.numel(), d, gen).reshape(-1, 9)
+    g = torch.randn(n, 9, device=DEV, generator=gen)
+    t = hr.haar(n, d, gen).reshape(n, 9).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda a: None if a is None else a.data_ptr()
+    new = lambda *shape, dt=torch.float32: torch.full(shape, float("nan"), device=DEV, dtype=dt)
+    # K2
+    dm_e, dm_r = new(n, 9), new(n, 9)
+    assert lib.so3_project_bwd_f32(p(x), p(g), p(dm_e), n, st) == 0
+    for lo in range(0, n, 63):
+        m = min(63, n - lo)
+        assert lib.so3_project_bwd_f32(p(x[lo:]), p(g[lo:]), p(dm_r[lo:]), m, st) == 0
+    same = lambda a, b_: bool(((a == b_) | (torch.isnan(a) & torch.isnan(b_))).all())
+    assert same(dm_e, dm_r), int((~((dm_e == dm_r) | (torch.isnan(dm_e) & torch.isnan(dm_r)))).any(dim=1).sum().item())
+    # K3, every variant
+    for want_r, want_dm in ((True, True), (False, True), (True, False), (False, False)):
+        r_e, d_e = (new(n, 9) if want_r else None), (new(n, 9) if want_dm else None)
+        r_r, d_r = (new(n, 9) if want_r else None), (new(n, 9) if want_dm else None)
+        ls_e, ls_r = new(1, dt=torch.float64), new(1, dt=torch.float64)
+        assert lib.so3_frob_fwd_bwd_v2_f32(p(x), p(t), p(r_e), p(d_e), p(ls_e), None, None, 0, n, st) == 0
+        total = 0.0
+        for lo in range(0, n, chunk):
+            sub = lambda a: None if a is None else a[lo:].data_ptr()
+            assert lib.so3_frob_fwd_bwd_v2_f32(sub(x), sub(t), sub(r_r), sub(d_r), p(ls_r), None, None, 0, chunk, st) == 0
+            total += ls_r.item()
+        if want_r:
+            assert same(r_e, r_r), (want_r, want_dm)
+        if want_dm:
+            assert same(d_e * float(n // chunk), d_r), (want_r, want_dm)      # 1/B: an exact power of two apart
+        assert abs(ls_e.item() - total) < 1e-9 * total
+    # K1+K4: per-row angles + R (float64 on every row), and the sum
+    deg_e, deg_r, rr_e, rr_r = new(n, dt=torch.float64), new(n, dt=torch.float64), new(n, 9), new(n, 9)
+    fl = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert lib.so3_project_angle_error_v2_f32(p(x), p(t), p(rr_e), p(deg_e), None, p(fl), None, 0, n, st) == 0
+    sc = new(2, dt=torch.float64)
+    for lo in range(0, n, chunk):
+        assert lib.so3_project_angle_error_v2_f32(x[lo:].data_ptr(), t[lo:].data_ptr(), rr_r[lo:].data_ptr(), deg_r[lo:].data_ptr(), p(sc), p(fl), None, 0,
+                                                  chunk, st) == 0
+    assert same(rr_e, rr_r) and same(deg_e, deg_r)
+    for flags in (_lib.EXACT_F64, 0):
+        assert lib.so3_project_angle_error_v2_f32(p(x), p(t), None, None, p(sc), p(fl), None, flags, n, st) == 0
+        assert sc[1].item() == n and abs(sc[0].item() - deg_r.sum().item()) < (1e-9 if flags else 1e-5) * n
+    # and what the hard rows got is a rotation
+    r3 = rr_e.view(n, 3, 3).double()
+    assert (r3.transpose(1, 2) @ r3 - torch.eye(3, device=DEV, dtype=torch.float64)).abs().amax() < 1e-5
+
+
 def test_device_rows_match_the_host_model_of_the_same_templates(rr):
     """csrc/so3_device.h compiled for the host (oracle/kernel_model.cpp) against the device: same algorithm, the only
     difference being 1-ulp v_rsq/v_sqrt/v_rcp versus correctly rounded libm."""
