@@ -187,9 +187,12 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
  *   theta  out optional B floats (reduction "none")
  *   sum    optional 1 double of scratch: zeroed by the call, receives sum_b theta_b (float64 accumulation)
  *   result out optional 1 float (needs `sum`): (float) of that sum, or of sum / B when mean != 0 -- written on `stream` behind the kernels
+ *   workspace optional so3_reduce_workspace_bytes() of device memory (zeroed once, private to the stream): the reduction is
+ *          finished by the kernel's last workgroup -- one launch instead of memset + kernel + mean, and a sum that does not
+ *          depend on the order the workgroups finish in
  */
 int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps,
-                         int64_t B, void *stream);
+                         void *workspace, int64_t B, void *stream);
 
 /* ---- next row: the SE(3) pose update fused after the head ------------------------
  * Replaces calculate_T_pred, Iterative/utility.py:90-128 (the head at :105, einsum at :124, the translation

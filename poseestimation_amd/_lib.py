@@ -32,7 +32,7 @@ SYMBOLS = {
     "so3_angle_error_v2": (_INT, [_P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_project_angle_error_v2_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
-    "so3_geodesic_eps_f32": (_INT, [_P, _P, _P, _P, _P, _INT, ctypes.c_float, _I64, _P]),
+    "so3_geodesic_eps_f32": (_INT, [_P, _P, _P, _P, _P, _INT, ctypes.c_float, _P, _I64, _P]),
     "so3_angle_error_f64": (_INT, [_P, _P, _P, _P, _P, _INT, _P, _I64, _P]),
     "so3_geodesic_f64": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_frob_loss_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P]),

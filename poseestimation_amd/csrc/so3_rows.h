@@ -1094,7 +1094,13 @@ struct OpGeodesic : OpBase {
             if (SUM && ctx.exists[k]) ctx.acc += static_cast<double>(th);
         }
     }
+    float *result = nullptr;     // with a workspace: the reduced value, float32 like the reference's tensor
+    double scale = 1.0;          // 1 / B for "mean"
     __device__ __forceinline__ void finish(double total, bool) const { if (SUM) atomicAdd(sum, total); }
+    __device__ __forceinline__ void finish_total(double total, bool) const {
+        *sum = total;
+        if (result != nullptr) *result = static_cast<float>(total * scale);
+    }
 };
 
 #endif  // !SO3_HOST_MODEL

@@ -507,7 +507,8 @@ __global__ void k_angle_init(double *sum_count, int32_t *range_flag, double coun
 // `sum` (nullable): the block's angles are added to it (one atomic per workgroup); theta nullable then.
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict__ R1, const float *__restrict__ R2,
-                                                         float *__restrict__ theta, double *__restrict__ sum, float lo, float hi, int64_t B) {
+                                                         float *__restrict__ theta, double *__restrict__ sum, float lo, float hi, int64_t B,
+                                                         so3::ReduceWs *__restrict__ ws) {
     __shared__ __attribute__((aligned(16))) float tile_a[kTileFloats];
     __shared__ __attribute__((aligned(16))) float tile_b[kTileFloats];
     __shared__ double part[kBlock / 64];
@@ -539,7 +540,8 @@ __global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict
             double t = 0.0;
 #pragma unroll
             for (int w = 0; w < kBlock / 64; ++w) t += part[w];
-            atomicAdd(sum, t);
+            if (ws != nullptr) publish_partial(ws, t, false);
+            else atomicAdd(sum, t);
         }
     }
 }
@@ -1543,6 +1545,12 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
 // Resident waves per SIMD the two-input kernels K2 / K3 / K1+K4 are built for (K1 runs at 3): their rare Jacobi branch keeps the frames
 // live across the backward (190-216 VGPRs).  Round 4 measured what three waves would buy with that branch out of the loop
 // (profiles/r04_row_number_queue_ab.txt): K2 at 168 VGPRs, spill-free, 22.10 us against 22.01 us at two -- occupancy is not what bounds it.
+#ifndef SO3_BLOCK_K3
+#define SO3_BLOCK_K3 256
+#endif
+#ifndef SO3_BLOCK_K14
+#define SO3_BLOCK_K14 256
+#endif
 #ifndef SO3_WPS_K2
 #define SO3_WPS_K2 2
 #endif
@@ -1751,7 +1759,7 @@ int frob(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum
     if (nunits > 0) {
 #define SLAUNCH(WD, WR) do { so3::OpFrobHead<EB, WD, WR> op; op.in0 = M; op.in1 = Rtrue; op.out0 = dM; op.out1 = R; \
                              op.loss_sum = loss_sum; op.inv_b = inv_b; op.loss_mean = loss_mean; op.inv_b_f64 = 1.0 / static_cast<double>(B); \
-                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, SO3_WPS_K3, 256>(op, nunits, s); } while (0)
+                             op.ws = ws; op.ws_slot0 = tile_wgs; launch_rows<2, SO3_WPS_K3, SO3_BLOCK_K3>(op, nunits, s); } while (0)
         if (R && dM) SLAUNCH(true, true); else if (dM) SLAUNCH(true, false); else if (R) SLAUNCH(false, true); else SLAUNCH(false, false);
 #undef SLAUNCH
     }
@@ -1951,7 +1959,7 @@ int so3_project_angle_error_v2_f32(const float *M, const float *Rtrue, float *R,
     if (nunits > 0) {
 #define SLAUNCH(WR, WD, WS, F32) do { so3::OpProjectAngle<4, WR, WD, WS, F32> op; op.in0 = M; op.in1 = Rtrue; op.out0 = R; op.deg = deg; \
                                  op.sum_count = sum_count; op.range_flag = range_flag; op.unit_scale = unit; op.count = static_cast<double>(B); \
-                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, SO3_WPS_K14, 256>(op, nunits, s); } while (0)
+                                 op.ws = ws; op.ws_slot0 = tile_wgs; op.store_count = store_count; launch_rows<2, SO3_WPS_K14, SO3_BLOCK_K14>(op, nunits, s); } while (0)
         // the sum without per-row angles: float32 trace and acos outside the band around +-1 (so3::angle_sum_f32) unless SO3_EXACT_F64
 #define PICKR(WR) do { if (deg && sum_count) SLAUNCH(WR, true, true, false); else if (deg) SLAUNCH(WR, true, false, false); \
                        else if (sum_count && !exact) SLAUNCH(WR, false, true, true); else if (sum_count) SLAUNCH(WR, false, true, false); \
@@ -2049,42 +2057,52 @@ int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, 
     return check_launch("so3_frob_loss_f64");
 }
 
-static int geodesic_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, int64_t B, void *stream,
-                        const char *what) {
+static int geodesic_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, void *workspace, int64_t B,
+                        void *stream, const char *what) {
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B && eps >= 0.f && eps < 1.f, what);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sum != nullptr) {
+    const int64_t nunits = B > 0 ? stream_units(B, {R1, R2, theta}) : 0;
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    const unsigned tile_wgs = rest > 0 ? grid_for(rest) : 0u;
+    // with a workspace: ONE launch (two with a remainder) -- the last workgroup writes the sum and the reduced result
+    so3::ReduceWs *ws = sum != nullptr && use_workspace(workspace, nunits, tile_wgs) ? static_cast<so3::ReduceWs *>(workspace) : nullptr;
+    if (sum != nullptr && ws == nullptr) {
         const hipError_t e = hipMemsetAsync(sum, 0, sizeof(double), s);
         if (e != hipSuccess) return fail(static_cast<int>(e), what);
     }
+    const double scale = mean ? 1.0 / static_cast<double>(B) : 1.0;
     if (B > 0) {
         SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && (theta != nullptr || sum != nullptr), what);
         const float lo = -1.f + eps, hi = 1.f - eps;          // float32 arithmetic, like torch.clamp's scalars on a float32 tensor
-        const int64_t nunits = stream_units(B, {R1, R2, theta});
-        if (nunits > 0) {
-            if (sum) { so3::OpGeodesic<true> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.sum = sum; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
-            else { so3::OpGeodesic<false> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
-        }
-        const int64_t done = nunits * so3::kUnitRows, rest = B - done;
-        if (rest > 0) {
+        if (rest > 0) {                                       // (first: its partials are in the workspace when the engine's last workgroup sums)
             const float *A1 = R1 + done * 9, *A2 = R2 + done * 9;
-            const dim3 grid(grid_for(rest)), block(kBlock);
-            if (aligned16(A1) && aligned16(A2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest);
-            else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest);
+            const dim3 grid(tile_wgs), block(kBlock);
+            if (aligned16(A1) && aligned16(A2)) hipLaunchKernelGGL((k_geodesic_f32<true>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest, ws);
+            else hipLaunchKernelGGL((k_geodesic_f32<false>), grid, block, 0, s, A1, A2, advance(theta, done), sum, lo, hi, rest, ws);
+        }
+        if (nunits > 0) {
+            if (sum) {
+                so3::OpGeodesic<true> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.sum = sum; op.lo = lo; op.hi = hi;
+                op.ws = ws; op.ws_slot0 = tile_wgs; op.result = result; op.scale = scale;
+                // 1024-thread workgroups as K4: 256 partials / same-address atomics at the end, not 768 (at ~12 ns each the
+                // <2, 3, 256> shape spent 5 us of its 18.5 queueing on one address: profiles/r04_all_kernels_stats.csv)
+                launch_rows<1, 4, 1024>(op, nunits, s);
+            } else { so3::OpGeodesic<false> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
         }
     }
     // (torch's mean of an empty tensor is NaN, its sum 0: 0 * inf / 0 * 1)
-    if (result != nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(sum, result, mean ? 1.0 / static_cast<double>(B) : 1.0);
+    if (result != nullptr && ws == nullptr) k_mean_from_sum<<<1, 1, 0, s>>>(sum, result, scale);
     return check_launch(what);
 }
 int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, void *stream) {
     if (B == 0) return 0;
     SO3_CHECK_ARGS(theta != nullptr, "so3_geodesic_f32: null pointer");
-    return geodesic_f32(R1, R2, theta, nullptr, nullptr, 0, 0.f, B, stream, "so3_geodesic_f32");
+    return geodesic_f32(R1, R2, theta, nullptr, nullptr, 0, 0.f, nullptr, B, stream, "so3_geodesic_f32");
 }
-int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, int64_t B, void *stream) {
+int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, void *workspace, int64_t B,
+                         void *stream) {
     SO3_CHECK_ARGS(result == nullptr || sum != nullptr, "so3_geodesic_eps_f32: result needs the float64 scratch `sum`");
-    return geodesic_f32(R1, R2, theta, sum, result, mean, eps, B, stream, "so3_geodesic_eps_f32");
+    return geodesic_f32(R1, R2, theta, sum, result, mean, eps, workspace, B, stream, "so3_geodesic_eps_f32");
 }
 
 int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream) {

@@ -518,8 +518,10 @@ def geodesic(R1: torch.Tensor, R2: torch.Tensor, reduction: str = "mean"):
     acc = None if reduction == "none" else torch.empty((1,), dtype=torch.float64, device=dev)
     out = None if reduction == "none" else torch.empty((), dtype=torch.float32, device=dev)
     with _on_device(dev):
-        _check(_libh().so3_geodesic_eps_f32(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7, n,
-                                            _stream(dev)), "so3_geodesic_eps_f32")
+        st = _stream(dev)
+        ws = _workspace(dev, st) if reduction != "none" else None               # the kernel's last workgroup writes the reduced value
+        _check(_libh().so3_geodesic_eps_f32(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7,
+                                            _ptr(ws), n, st), "so3_geodesic_eps_f32")
     return theta if reduction == "none" else out
 
 

@@ -625,6 +625,25 @@ def test_g14_geodesic_with_reduction(rr):
         assert np.abs(np.cos(rad) - np.cos(ref)).max() < 1e-6
         assert abs(rr.geodesic(a, b, "sum").item() - ref.sum()) < 2e-6 * ref.sum() + 0.05
         assert abs(rr.geodesic(a, b, "mean").item() - ref.mean()) < 1e-5
+    # the C ABI with and without the reduction workspace: one launch (the last workgroup writes sum and mean) against
+    # memset + kernel + mean; the same float64 sum to its last bits' worth of ordering, twice in a row on one workspace
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.zeros(lib.so3_reduce_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    for n in (100_003, 65_536, 1025):
+        a, b = big_a[:n].contiguous(), big_b[:n].contiguous()
+        got = []
+        for w in (ws, ws, None):
+            acc = torch.full((1,), float("nan"), dtype=torch.float64, device=DEV)
+            out = torch.full((), float("nan"), dtype=torch.float32, device=DEV)
+            rc = lib.so3_geodesic_eps_f32(a.data_ptr(), b.data_ptr(), None, acc.data_ptr(), out.data_ptr(), 1, 1e-7,
+                                          w.data_ptr() if w is not None else None, n, st)
+            assert rc == 0
+            got.append((acc.item(), out.item()))
+        assert got[0] == got[1]                                            # the workspace is left as it was found
+        assert abs(got[0][0] - got[2][0]) < 1e-9 * got[2][0] and abs(got[0][1] - got[2][1]) < 1e-6
+        assert abs(got[0][1] - np.float32(got[0][0] / n)) < 1e-7
 
 
 def _haar_rows(n, gen):

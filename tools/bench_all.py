@@ -91,7 +91,8 @@ def main():
     timeit("K4 f64 so3_angle_error_f64 (sum,count, no workspace: init + kernel)", lambda i: lib.so3_angle_error_f64(p(r64[i % 2]), p(r64[1 - i % 2]), None, p(sc), p(fl), 0, None, n, st), 144 * n)
     timeit("K4 f64 so3_angle_error_f64 (per-row deg)", lambda i: lib.so3_angle_error_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(deg), None, p(fl), 0, p(ws), n, st), 152 * n)
     timeit("K3' f64 so3_frob_loss_f64 (loss + dRpred, workspace: one launch)", lambda i: lib.so3_frob_loss_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(g64), p(ls), p(lm64), p(ws), n, st), 216 * n)
-    timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (memset + kernel + mean)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), n, st), 72 * n)
+    timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (workspace: one launch)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), p(ws), n, st), 72 * n)
+    timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (no workspace: memset + kernel + mean)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), None, n, st), 72 * n)
     del r64, g64
     timeit("K4' so3_geodesic_f32", lambda i: lib.so3_geodesic_f32(p(r[i % NB]), p(rt[i % NB]), p(th), n, st), 76 * n)
     print("--- next rows (f1, f2, f3) at 1M rows ---")
