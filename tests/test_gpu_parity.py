@@ -455,6 +455,22 @@ def test_parked_and_dense_hard_rows_in_the_two_input_kernels(rr):
         if want_dm:
             assert same(d_e * float(n // chunk), d_r), (want_r, want_dm)      # 1/B: an exact power of two apart
         assert abs(ls_e.item() - total) < 1e-9 * total
+    # bfloat16 storage (config #4's): K2 and K3 with M read and dM written as bfloat16 -- a parked row's dM is overwritten element by element
+    xb = x.to(torch.bfloat16)
+    db_e, db_r = new(n, 9, dt=torch.bfloat16), new(n, 9, dt=torch.bfloat16)
+    assert lib.so3_project_bwd_bf16(p(xb), p(g), p(db_e), n, st) == 0
+    for lo in range(0, n, 63):
+        assert lib.so3_project_bwd_bf16(p(xb[lo:]), p(g[lo:]), p(db_r[lo:]), min(63, n - lo), st) == 0
+    assert same(db_e.float(), db_r.float())
+    r_e, r_r, db_e, db_r = new(n, 9), new(n, 9), new(n, 9, dt=torch.bfloat16), new(n, 9, dt=torch.bfloat16)
+    ls_e, ls_r = new(1, dt=torch.float64), new(1, dt=torch.float64)
+    assert lib.so3_frob_fwd_bwd_v2_bf16(p(xb), p(t), p(r_e), p(db_e), p(ls_e), None, None, 0, n, st) == 0
+    total = 0.0
+    for lo in range(0, n, chunk):
+        assert lib.so3_frob_fwd_bwd_v2_bf16(p(xb[lo:]), p(t[lo:]), p(r_r[lo:]), p(db_r[lo:]), p(ls_r), None, None, 0, chunk, st) == 0
+        total += ls_r.item()
+    # (1/B enters the gradient before the bfloat16 rounding: a power of two commutes with it, short of underflow)
+    assert same(r_e, r_r) and same(db_e.float() * float(n // chunk), db_r.float()) and abs(ls_e.item() - total) < 1e-9 * total
     # K1+K4: per-row angles + R (float64 on every row), and the sum
     deg_e, deg_r, rr_e, rr_r = new(n, dt=torch.float64), new(n, dt=torch.float64), new(n, 9), new(n, 9)
     fl = torch.zeros(1, dtype=torch.int32, device=DEV)
