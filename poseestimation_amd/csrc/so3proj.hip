@@ -1210,16 +1210,17 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 //      2^-23 to 2^9 degrees, one bin below and one above.  The thresholds 7.5, 15 and 30 are bin edges (1.875 x 2^k), so the three
 //      accuracies and the count are sums over bins -- no atomics of their own.  Workgroup-private in LDS, flushed once.
 //   2. k_stats_collect (all rows): first, per class, the bins holding the lower and the upper middle element (every workgroup for
-//      itself, from the L2-resident histograms); then the rows of those bins (1/16 octave: a few per cent of a class) are compacted,
-//      each workgroup into a region of its own (an LDS cursor: no global atomic, no barrier in the loop), grouped by class.
-//   3. k_stats_finish (one workgroup per class): the regions' counts for the class become prefix sums (which makes its share of the
-//      regions one list), the candidates are gathered (into LDS when they fit) and both middle elements radix-selected at once on
-//      the remaining 48 bits; then the class's row of the result.
+//      itself, from the L2-resident histograms); then the rows of those bins (1/16 octave: a few per cent of a class) are compacted:
+//      staged in LDS (a cursor: no global atomic, no barrier in the loop), grouped by class, and appended to the class's stretch of
+//      the candidate buffer -- the histogram says exactly how long each stretch is; one atomic per workgroup and class takes a share.
+//   3. k_stats_finish (one workgroup per class): the class's candidates -- a contiguous list -- go into LDS (when more than 16 384:
+//      after the first digit has thinned them out) and both middle elements are radix-selected at once on the remaining 48 bits;
+//      then the class's row of the result.
 // Launch boundaries order everything: no ticket, no fence (measured: the two release fences per workgroup were 4-9 us per launch,
 // three float64 LDS atomics per row 11 us, the histogram and its flush nothing; profiles/r04_angle_stats_experiments.txt).
 // Exact for every input: an edge bin (zeros, denormals, angles above 512 degrees) is selected on all 64 bits, and if a workgroup's
-// region overflows (more than ~4000 of its rows inside the selected bins: e.g. a million equal angles) the finishing workgroups
-// select over the rows themselves -- slow, never wrong.
+// staging overflows (more than 4096 of its rows inside the selected bins: e.g. a million equal angles) the finishing workgroups
+// select over the rows themselves (two sweeps, then from LDS) -- slow, never wrong.
 constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
 constexpr int kMaxClasses = 64;
 constexpr int kWinBase = 0x3E80;                   // (bits >> 48) of 2^-23
@@ -1231,16 +1232,17 @@ constexpr int kStatLdsKeys = 16384;                // candidates of one class th
 struct StatWork {                                  // layout of the caller's workspace; the call zeroes it up to the classes' histograms
     double acc[kMaxClasses][4];                    // sum, sumsq, max (bits), nan_count
     unsigned int overflow, pad;
-    unsigned int hist[kMaxClasses][kHistBins];     // (zeroed for the classes in use)
+    unsigned int class_cursor[kMaxClasses];        // k_stats_collect: how much of class c's stretch of the candidate buffer is taken
+    unsigned int hist[kMaxClasses][kHistBins];     // (zeroed up to here for the classes in use)
     double count[kMaxClasses], below[3][kMaxClasses];      // rows of the class (NaN included), non-NaN rows below 30 / 15 / 7.5
     int sel_bin[2][kMaxClasses];                   // the window bin of the lower / upper middle element (-1: empty class)
     long long krem[2][kMaxClasses];                // its rank inside that bin
-    unsigned int wg_cstart[kStatMaxWgs][kMaxClasses], wg_ccount[kStatMaxWgs][kMaxClasses];   // k_stats_collect: where a workgroup's region holds class c, how many
+    unsigned int cand_base[kMaxClasses], cand_count[kMaxClasses];   // class c's candidates: cand[base, base + count) -- the rows of its selected bins, counted by the histogram
     unsigned char tag[kCandCap];                   // bit 0: counts for the lower middle element, bit 1: for the upper
     unsigned long long cand[kCandCap];
 };
-constexpr unsigned int kStatRegion = 4096;         // candidates one workgroup of k_stats_collect stages in LDS (48 KB) and owns in the buffer
-static_assert(kStatRegion * 256u <= kCandCap, "one region per CU");
+constexpr unsigned int kStatRegion = 4096;         // candidates one workgroup of k_stats_collect can stage in LDS (48 KB)
+static_assert(kStatRegion * 256u <= kCandCap, "what 256 workgroups can stage fits the buffer");
 
 __device__ __forceinline__ unsigned long long angle_key(double a) { return static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)); }
 __device__ __forceinline__ int window_bin(unsigned long long key) {
@@ -1374,19 +1376,36 @@ __device__ __forceinline__ void stats_select(int ncls, StatWork *w, int (*sbin)[
 }
 
 // The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
-// counting sort in LDS -- into the region of the candidate buffer the workgroup owns; where each class starts in the region and how
-// many it holds goes into a table, so that a finishing workgroup reads its own class only.
+// counting sort in LDS -- and appended to the class's stretch of the candidate buffer.  The stretches are exact: the histogram says how
+// many rows each class has in its selected bins, every workgroup derives the same offsets from it, and a workgroup takes its share of
+// a stretch with ONE atomic per class it holds; a finishing workgroup then reads a contiguous list (round 4's first build gave every
+// workgroup a region of its own and a table of (start, count) per class: the finishing workgroup found entry i by bisection over 256
+// prefix sums -- with one class of a million rows, 44 000 entries, two sweeps of 18 us each).
 __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
                                                               int64_t B, int mode) {
     __shared__ unsigned long long skey[kStatRegion];
     __shared__ unsigned short stag[kStatRegion];
     __shared__ int sbin[2][kMaxClasses];
-    __shared__ unsigned int ccount[kMaxClasses], cstart[kMaxClasses], ccur[kMaxClasses];
+    __shared__ unsigned int ccount[kMaxClasses], cstart[kMaxClasses], ccur[kMaxClasses], cbase[kMaxClasses], gbase[kMaxClasses];
     __shared__ unsigned int cur;
     stats_select(ncls, w, sbin, blockIdx.x == 0);
     for (int i = threadIdx.x; i < ncls; i += kStatBlock) ccount[i] = 0;
     if (threadIdx.x == 0) cur = 0;
     __syncthreads();
+    if (threadIdx.x < static_cast<unsigned>(ncls)) {                  // how many candidates class c has in all: the rows of its one or two selected bins
+        const int c = threadIdx.x, b0 = sbin[0][c], b1 = sbin[1][c];
+        cbase[c] = (b0 >= 0 ? w->hist[c][b0] : 0u) + (b1 >= 0 && b1 != b0 ? w->hist[c][b1] : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int at = 0;
+        for (int c = 0; c < ncls; ++c) {
+            const unsigned int k = cbase[c];
+            if (blockIdx.x == 0) { w->cand_base[c] = at; w->cand_count[c] = k; }
+            cbase[c] = at;
+            at = at + k < at ? 0xFFFFFFFFu : at + k;                    // (saturating: beyond the buffer nothing is written anyway)
+        }
+    }
     stats_rows(deg, cls, B, mode, [&](double a, int c) {
         if (c < 0 || c >= ncls || a != a) return;
         const unsigned long long key = angle_key(a);
@@ -1399,66 +1418,53 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
     });
     __syncthreads();
     const unsigned int n = cur < kStatRegion ? cur : kStatRegion;
-    if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);
+    if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);     // (the finishing workgroups then select over the rows themselves)
     for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) atomicAdd(&ccount[stag[i] & 0xFF], 1u);
     __syncthreads();
+    if (threadIdx.x < static_cast<unsigned>(ncls)) {
+        const int c = threadIdx.x;
+        gbase[c] = ccount[c] ? cbase[c] + atomicAdd(&w->class_cursor[c], ccount[c]) : 0u;
+    }
     if (threadIdx.x == 0) {
         unsigned int at = 0;
         for (int c = 0; c < ncls; ++c) { cstart[c] = at; ccur[c] = at; at += ccount[c]; }
     }
     __syncthreads();
-    unsigned long long *mine = w->cand + static_cast<size_t>(blockIdx.x) * kStatRegion;
-    unsigned char *mine_tag = w->tag + static_cast<size_t>(blockIdx.x) * kStatRegion;
     for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) {
-        const unsigned int at = atomicAdd(&ccur[stag[i] & 0xFF], 1u);
-        mine[at] = skey[i];
-        mine_tag[at] = static_cast<unsigned char>(stag[i] >> 8);
+        const int c = stag[i] & 0xFF;
+        const unsigned int at = gbase[c] + (atomicAdd(&ccur[c], 1u) - cstart[c]);
+        if (at < kCandCap) {                                            // (past the buffer only after some workgroup has overflowed)
+            w->cand[at] = skey[i];
+            w->tag[at] = static_cast<unsigned char>(stag[i] >> 8);
+        }
     }
-    for (int c = threadIdx.x; c < ncls; c += kStatBlock) { w->wg_cstart[blockIdx.x][c] = cstart[c]; w->wg_ccount[blockIdx.x][c] = ccount[c]; }
 }
 
-// One workgroup per class: the regions' counts -> prefix sums in LDS (entry i of the list: the region is found by bisection over
-// them), the class's candidates out of the regions (into LDS when they fit), both middle elements by ONE radix select of 8-bit
-// digits -- two (prefix, rank) states side by side, they part where the two elements differ -- then the class's row of the result
-// (np.mean / np.std / np.max / np.median / the thresholds).
+// One workgroup per class: the class's candidates (a contiguous stretch of the buffer; into LDS when they fit), both middle elements by
+// ONE radix select of 8-bit digits -- two (prefix, rank) states side by side, they part where the two elements differ -- then the
+// class's row of the result (np.mean / np.std / np.max / np.median / the thresholds).
 __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__restrict__ deg, const int32_t *__restrict__ cls, StatWork *w, int64_t B,
-                                                             double *__restrict__ stats, unsigned int groups) {
+                                                             double *__restrict__ stats) {
     __shared__ unsigned long long lkey[kStatLdsKeys];
     __shared__ unsigned char ltag[kStatLdsKeys];
-    __shared__ unsigned int prefix_of[kStatMaxWgs + 1], start_of[kStatMaxWgs];
     __shared__ unsigned int hh[2][256];
     __shared__ unsigned long long s_prefix[2];
     __shared__ long long s_k[2];
     const int c = blockIdx.x;
     const double n = w->count[c], nan = w->acc[c][3], m = n - nan;
-    const bool overflow = w->overflow != 0u;
     const int bins[2] = {w->sel_bin[0][c], w->sel_bin[1][c]};
-    // inclusive scan of the regions' counts for THIS class (groups <= 1024: one value per thread, Hillis-Steele), shifted into prefix_of[1..]
-    unsigned int run = threadIdx.x < groups ? w->wg_ccount[threadIdx.x][c] : 0u;
-    start_of[threadIdx.x] = threadIdx.x < groups ? w->wg_cstart[threadIdx.x][c] : 0u;
-    prefix_of[threadIdx.x + 1] = run;
-    if (threadIdx.x == 0) prefix_of[0] = 0;
-    __syncthreads();
-    for (int off = 1; off < kStatBlock; off <<= 1) {
-        const unsigned int up = static_cast<int>(threadIdx.x) >= off ? prefix_of[threadIdx.x + 1 - off] : 0u;
-        __syncthreads();
-        run += up;
-        prefix_of[threadIdx.x + 1] = run;
-        __syncthreads();
-    }
-    const unsigned int total = prefix_of[groups];                       // the class's candidates
-    auto entry = [&](unsigned int i) -> size_t {
-        unsigned int lo = 0, hi = groups;                               // the last g with prefix_of[g] <= i
-        while (hi - lo > 1) { const unsigned int mid = (lo + hi) >> 1; if (prefix_of[mid] <= i) lo = mid; else hi = mid; }
-        return static_cast<size_t>(lo) * kStatRegion + start_of[lo] + (i - prefix_of[lo]);
-    };
-    const bool cached = m > 0 && !overflow && total <= static_cast<unsigned int>(kStatLdsKeys);
+    const unsigned int total = w->cand_count[c];                        // the class's candidates
+    const unsigned long long *cand = w->cand + w->cand_base[c];
+    const unsigned char *ctag = w->tag + w->cand_base[c];
+    // (a stretch that would leave the buffer can only belong to a call in which some workgroup overflowed; the flag is set then)
+    const bool overflow = w->overflow != 0u || static_cast<unsigned long long>(w->cand_base[c]) + total > kCandCap;
+    constexpr int kAhead = 8;                                           // loads in flight per thread: the workgroup is alone on its CU
+    __shared__ unsigned int s_rem[2], s_cur;
+    bool cached = m > 0 && !overflow && total <= static_cast<unsigned int>(kStatLdsKeys);      // (workgroup-uniform throughout)
+    unsigned int held = total;                                                                // how many candidates LDS holds once cached
     if (cached) {
-        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) {
-            const size_t e = entry(i);
-            lkey[i] = w->cand[e];
-            ltag[i] = w->tag[e];
-        }
+#pragma unroll 4
+        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) { lkey[i] = cand[i]; ltag[i] = ctag[i]; }
         __syncthreads();
     }
     double middle[2] = {0.0, 0.0};
@@ -1482,22 +1488,49 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
                 for (int t = 0; t < 2; ++t)
                     if (active[t] && (which >> t & 1u) && (shift == 56 || (key >> (shift + 8)) == prefix[t])) atomicAdd(&hh[t][(key >> shift) & 0xFF], 1u);
             };
+            // every candidate of the class (or, after an overflow, every row of it inside the selected bins): f(key, which selections it counts for)
+            // (eight loads in flight per thread: the workgroup is alone on its CU, and one load at a time -- the votes' LDS atomics keep the
+            // compiler from overlapping iterations -- made a pass over 44 000 candidates 43 round trips to memory, 20 us)
+            auto every_far_candidate = [&](auto &&f) {
+                if (!overflow) {
+                    for (unsigned int i0 = threadIdx.x; i0 < total; i0 += kAhead * kStatBlock) {
+                        unsigned long long key[kAhead];
+                        unsigned int which[kAhead];
+#pragma unroll
+                        for (int j = 0; j < kAhead; ++j) {
+                            const unsigned int i = i0 + j * kStatBlock;
+                            key[j] = cand[i < total ? i : i0];
+                            which[j] = i < total ? static_cast<unsigned int>(ctag[i]) : 0u;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kAhead; ++j)
+                            if (which[j]) f(key[j], which[j]);
+                    }
+                } else {
+                    for (int64_t i0 = threadIdx.x; i0 < B; i0 += kAhead * kStatBlock) {
+                        double a[kAhead];
+                        int cc[kAhead];
+#pragma unroll
+                        for (int j = 0; j < kAhead; ++j) {
+                            const int64_t i = i0 + j * kStatBlock;
+                            a[j] = deg[i < B ? i : i0];
+                            cc[j] = i < B ? (cls ? cls[i] : 0) : -1;
+                        }
+#pragma unroll
+                        for (int j = 0; j < kAhead; ++j) {
+                            if (cc[j] != c || a[j] != a[j]) continue;
+                            const unsigned long long key = angle_key(a[j]);
+                            const int bin = window_bin(key);
+                            const unsigned int which = (bin == bins[0] ? 1u : 0u) | (bin == bins[1] ? 2u : 0u);
+                            if (which) f(key, which);
+                        }
+                    }
+                }
+            };
             if (cached) {
-                for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) vote(lkey[i], ltag[i]);
-            } else if (!overflow) {
-                for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) {
-                    const size_t e = entry(i);
-                    vote(w->cand[e], w->tag[e]);
-                }
-            } else {                                                    // the rows themselves, filtered to the class and the bins
-                for (int64_t i = threadIdx.x; i < B; i += kStatBlock) {
-                    const double a = deg[i];
-                    const int cc = cls ? cls[i] : 0;
-                    if (cc != c || a != a) continue;
-                    const unsigned long long key = angle_key(a);
-                    const int bin = window_bin(key);
-                    vote(key, (bin == bins[0] ? 1u : 0u) | (bin == bins[1] ? 2u : 0u));
-                }
+                for (unsigned int i = threadIdx.x; i < held; i += kStatBlock) vote(lkey[i], ltag[i]);
+            } else {
+                every_far_candidate(vote);
             }
             __syncthreads();
             if (threadIdx.x < 128) {                                    // wave t: the digit holding selection t's rank -- 256 bins, four per lane, a wave prefix sum
@@ -1518,9 +1551,28 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
                     for (; d < 3; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; }
                     s_k[t] = kk;
                     s_prefix[t] = (prefix[t] << 8) | static_cast<unsigned long long>(4 * lane + d);
+                    s_rem[t] = h[d];                                    // how many candidates share the element's digits so far
                 }
             }
+            if (threadIdx.x == 0) s_cur = 0;
             __syncthreads();
+            // Candidates that did not fit LDS (one class of a million rows: 44 000 in its middle bin; or the rows themselves after an
+            // overflow): once the digits chosen so far leave few enough, those move into LDS and the remaining digits are read there --
+            // two passes over the far candidates instead of six (eight).
+            if (!cached && active[0] && active[1] && shift > 0 && s_rem[0] + s_rem[1] <= static_cast<unsigned int>(kStatLdsKeys)) {
+                const unsigned long long np[2] = {s_prefix[0], s_prefix[1]};
+                every_far_candidate([&](unsigned long long key, unsigned int which) {
+                    const unsigned int keep = ((which & 1u) && (key >> shift) == np[0] ? 1u : 0u) | ((which & 2u) && (key >> shift) == np[1] ? 2u : 0u);
+                    if (keep) {
+                        const unsigned int at = atomicAdd(&s_cur, 1u);
+                        lkey[at] = key;                                 // (at < s_rem[0] + s_rem[1] <= kStatLdsKeys)
+                        ltag[at] = static_cast<unsigned char>(keep);
+                    }
+                });
+                __syncthreads();
+                held = s_cur;
+                cached = true;
+            }
         }
         middle[0] = __longlong_as_double(static_cast<long long>(s_prefix[0]));
         middle[1] = __longlong_as_double(static_cast<long long>(s_prefix[1]));
@@ -2237,7 +2289,7 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     if (ncls <= kStatLdsClasses) k_stats_window<kStatLdsClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
     else k_stats_window<kMaxClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
     k_stats_collect<<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
-    k_stats_finish<<<static_cast<unsigned>(ncls), kStatBlock, 0, s>>>(deg, cls, w, B, stats, grid);
+    k_stats_finish<<<static_cast<unsigned>(ncls), kStatBlock, 0, s>>>(deg, cls, w, B, stats);
     return check_launch("so3_angle_stats");
 }
 

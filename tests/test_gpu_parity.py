@@ -1562,6 +1562,42 @@ def test_angle_error_statistics_match_numpy(rr, n, ncls):
         assert np.allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-10, equal_nan=True)
 
 
+@pytest.mark.parametrize("case", ["one class of a million", "two classes of a million each", "a third of the rows tie at the median",
+                                  "every row the same", "all rows inside one bin", "one bin, two classes, NaN in one"])
+def test_angle_error_statistics_far_candidates_and_overflow(rr, case):
+    """The exact median where the candidates of a class do not fit the finishing workgroup's LDS (one class of 1M rows: 44 000 rows in its
+    middle 1/16-octave bin -- they move into LDS once the first digit has thinned them out) and where a collecting workgroup's region
+    overflows (ties, a distribution narrower than a bin: the finishing workgroup then selects over the rows themselves, and again
+    moves to LDS when few enough are left): bit-equal to np.median every time."""
+    from oracle import so3_oracle as so
+    rng = np.random.default_rng(len(case))
+    n, ncls = 1_000_000, 1
+    if case == "one class of a million":
+        ang = np.minimum(np.abs(rng.standard_normal(n)) * 25.0, 180.0)
+    elif case == "two classes of a million each":
+        n, ncls = 2_000_000, 2
+        ang = np.minimum(np.abs(rng.standard_normal(n)) * 25.0, 180.0)
+    elif case == "a third of the rows tie at the median":
+        ang = np.minimum(np.abs(rng.standard_normal(n)) * 25.0, 180.0)
+        ang[rng.integers(0, n, n // 3)] = float(np.median(ang))
+    elif case == "every row the same":
+        ang = np.full(n, 12.5)
+    elif case == "all rows inside one bin":
+        ang = 20.0 + 1e-3 * rng.random(n)                              # 16 < x < 17: one bin of the window, every digit but the last few alike
+    else:
+        n, ncls = 1_000_001, 2
+        ang = 20.0 + 1e-9 * rng.random(n)
+        ang[5] = np.nan
+    cls = rng.integers(0, ncls, n) if ncls > 1 else None
+    if case.endswith("NaN in one"):
+        cls[5] = 1
+    got = rr.angle_error_statistics(dev(ang, torch.float64), None if cls is None else dev(cls, torch.int32), ncls)
+    ref = so.angle_statistics_np(ang, cls, ncls)
+    for k in ("count", "max", "median", "acc30", "acc15", "acc7.5"):
+        assert np.array_equal(got[k].cpu().numpy(), ref[k], equal_nan=True), (k, got[k], ref[k])
+    assert np.allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-9, equal_nan=True)
+
+
 def test_angle_error_statistics_end_to_end_and_nan(rr):
     """K1 -> K4 -> statistics without leaving the device, against the oracle chain; NaN propagates like numpy."""
     from oracle import so3_oracle as so

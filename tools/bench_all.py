@@ -120,6 +120,7 @@ def main():
     stats = torch.empty(10, 8, dtype=torch.float64, device=dev)
     work = torch.empty(lib.so3_angle_stats_workspace_bytes(), dtype=torch.uint8, device=dev)
     timeit("f3 so3_angle_stats (10 classes, exact median)", lambda i: lib.so3_angle_stats(p(deg), p(cls), 10, p(stats), p(work), n, st), 12 * n, iters=20)
+    timeit("f3 so3_angle_stats (one class: the whole batch's median)", lambda i: lib.so3_angle_stats(p(deg), None, 1, p(stats), p(work), n, st), 8 * n, iters=20)
     del x, xb, g, r, dm, dmb, rt
     torch.cuda.empty_cache()
     print("--- config #3: 65536 clouds x 1024 points ---")
