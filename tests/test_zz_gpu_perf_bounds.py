@@ -29,7 +29,7 @@ def test_hard_rows_cost_is_bounded(rr):
     its share; a round dense in them runs the Jacobi path on the spot.  Measured over round 4's devices (x a Gaussian batch): 1 % of
     hard rows K1 1.11-1.30 / K3 1.05-1.17 (round 3: 1.16-1.46 / 1.09-1.51), 10 % K1 1.24-1.59 / K3 1.10-1.31, whole batches K1
     1.31-1.77 (ties: 1.80-2.02) / K3 1.05-1.42; zero rows (dead heads) cost the forward nothing extra (their backward stays a hard
-    row's), nor do rows that are merely far from unit scale or of rank two (0.9-1.12).  The caps below are those plus ~10 %: ratios
+    row's), nor do rows that are merely far from unit scale or of rank two (0.9-1.12).  The caps below are those plus ~20 % (a timing assertion on a shared pool: it guards against gross regressions, parity is elsewhere): ratios
     between launches of one process on one device, but devices differ in how low they clock K1."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("k1_hard_rows", os.path.join(ROOT, "tools", "k1_hard_rows.py"))
@@ -69,7 +69,7 @@ def test_hard_rows_cost_is_bounded(rr):
     g1, g3 = both([torch.randn(n, 9, device=DEV, generator=gen) for _ in range(nb)])
     report = {}
     hard = ("near-reflection", "entries in {-1,0,1}", "generic ties", "rank one")
-    caps = {0.01: (1.45, 1.3), 0.10: (1.75, 1.5), 1.0: (1.9, 1.6)}
+    caps = {0.01: (1.55, 1.4), 0.10: (1.9, 1.6), 1.0: (2.1, 1.7)}
     for name in hard + ("all zero", "1e5 * Gaussian", "rank two"):
         for share in (0.01, 0.10, 1.0):
             xs = []
@@ -83,11 +83,11 @@ def test_hard_rows_cost_is_bounded(rr):
                 xs.append(x)
             k1, k3 = both(xs)
             del xs
-            cap1, cap3 = caps[share] if name in hard else (1.25, 1.25)
+            cap1, cap3 = caps[share] if name in hard else (1.35, 1.35)
             if name == "all zero":
                 cap3 = caps[share][1]              # the BACKWARD of a zero row still goes through the Jacobi frames' floored denominators: hard for K3
             if name == "generic ties" and share == 1.0:
-                cap1 = 2.25                        # both algorithms on every row: no invariant tells a tie from a Gaussian row beforehand
+                cap1 = 2.4                         # both algorithms on every row: no invariant tells a tie from a Gaussian row beforehand
             report["%s %g %%" % (name, share * 100)] = (round(k1 / g1, 2), round(k3 / g3, 2))
             assert k1 <= cap1 * g1 and k3 <= cap3 * g3, (name, share, k1, g1, k3, g3, report)
     print("hard rows, (K1, K3) x Gaussian:", report)
