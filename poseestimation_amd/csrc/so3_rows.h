@@ -611,6 +611,49 @@ template <class T> __device__ __forceinline__ void jacobi_rotation_by_halves(con
     }
 }
 
+// K1's arithmetic for a round (so3_device.h sections 3a / 3b) with the round's hard rows parked -- inputs and row numbers -- when they are
+// few, or through the Jacobi path on the spot when the round is dense in them.  Returns the PARKED rows (their r is whatever the fast path
+// left; Op::redo_parked answers for them).
+template <class T, int NPL, int CAP, int WORDS>
+__device__ __forceinline__ typename Tr<T>::mask project_or_park(const T (&m)[9], T (&r)[9], RowCtx<NPL> &ctx) {
+    typedef Tr<T> R;
+    const typename R::mask none = R::gt(R::splat(0.f), R::splat(1.f));
+    // After a round dense in hard rows the next one is asked first whether ALL its rows are hard by their invariants alone
+    // (a batch of reflections, rank-one or zero rows): then it takes the Jacobi path without running the fast path at all.
+    if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
+        rotation_from(signed_svd<false, T>(m), r);
+        return none;
+    }
+    const int asked = ctx.dense;                     // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
+    const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
+    ctx.dense = 0;
+    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+        bool dense;
+        const int base = park_hard_rows<T, NPL, CAP>(ctx, hard, &dense);
+        ctx.dense = dense ? (asked != 0 ? 2 : 1) : 0;
+        if (base >= 0) {
+            park_words<T, NPL, CAP, WORDS, true, 9>(ctx, base, hard, 0, m);
+            return hard;
+        } else {
+            // The fast path's rotations wait in the wave's LDS slot meanwhile (the round's inputs have left it, its outputs are
+            // not staged yet): 18 registers that the Jacobi path's peak would otherwise sit on top of.
+            typedef UnitIO<4, 9, NPL> Stash;
+            const int lane = lane_id_now();
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) Stash::write_row(ctx.slot, k, lane, k, r);
+            wave_lds_fence();                                // (also keeps the compiler from forwarding the stores to the loads below)
+            T rj[9];
+            jacobi_rotation_by_halves<T>(m, rj);
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) Stash::read_row(ctx.slot, k, lane, k, r);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) r[j] = R::sel(hard, rj[j], r[j]);
+        }
+    }
+    return none;
+}
+
 // K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path; its hard rows parked, or
 // through the packed Jacobi path on the spot when the round is dense in them.
 template <int IN_BYTES, bool FLIP>
@@ -633,38 +676,7 @@ struct OpProject : OpBase {
                 __builtin_amdgcn_raw_buffer_store_b8(bit, row_rsrc<1>(flip, ctx.exists[k] ? ctx.unit[k] : 0, ctx.exists[k]), ctx.lane, 0, 0);
             }
         }
-        // After a round dense in hard rows the next one is asked first whether ALL its rows are hard by their invariants alone
-        // (a batch of reflections, rank-one or zero rows): then it takes the Jacobi path without running the fast path at all.
-        if (__builtin_expect(ctx.dense == 1, 0) && all_rows_invariant_hard<T>(m)) {
-            rotation_from(signed_svd<false, T>(m), r);
-            return;
-        }
-        const int asked = ctx.dense;                     // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
-        const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
-        ctx.dense = 0;
-        if (__builtin_expect(wave_any(R::any(hard)), 0)) {
-            bool dense;
-            const int base = park_hard_rows<T, NPL, kParkCap>(ctx, hard, &dense);
-            ctx.dense = dense ? (asked != 0 ? 2 : 1) : 0;
-            if (base >= 0) {
-                park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, hard, 0, m);
-            } else {
-                // The fast path's rotations wait in the wave's LDS slot meanwhile (the round's inputs have left it, its outputs are
-                // not staged yet): 18 registers that the Jacobi path's peak would otherwise sit on top of.
-                typedef UnitIO<4, 9, NPL> Stash;
-                const int lane = lane_id_now();
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) Stash::write_row(ctx.slot, k, lane, k, r);
-                wave_lds_fence();                                // (also keeps the compiler from forwarding the stores to the loads below)
-                T rj[9];
-                jacobi_rotation_by_halves<T>(m, rj);
-                wave_lds_fence();
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) Stash::read_row(ctx.slot, k, lane, k, r);
-#pragma unroll
-                for (int j = 0; j < 9; ++j) r[j] = R::sel(hard, rj[j], r[j]);
-            }
-        }
+        project_or_park<T, NPL, kParkCap, kParkWords>(m, r, ctx);
     }
     template <int NPL>
     __device__ __forceinline__ void redo_parked(RowCtx<NPL> &ctx, int e, bool valid) const {
