@@ -132,3 +132,47 @@ void model_se3_update_bwd(const float *out12, const float *Tinit, const float *G
     run_rows(op, out12, Tinit, G, dout12, B);
 }
 }  // extern "C"
+
+// The parked-rows list's reservation protocol (so3_rows.h: park_reserve_protocol) under a replayed interleaving: actor 0 reads the
+// count, then actors 1..k-1 run their whole reservations (in order; actor j > 0 itself is interrupted by actor j+1.. when `nested`),
+// then actor 0's compare-and-swap is attempted -- and retried, now undisturbed, if it finds the count changed.  base[j] = the entry
+// actor j was given or -1.  Returns the final count.  (Every side effect of the protocol is one successful compare-and-swap, so
+// any schedule of the device's waves is equivalent to some such nesting.)
+namespace {
+struct ParkReplay {
+    unsigned *count; const unsigned *n; int *base; int k; unsigned cap; bool nested;
+    void run(int j) {
+        bool disturbed = false;
+        base[j] = so3::park_reserve_protocol(
+            count, n[j], cap,
+            [&](unsigned *p) {
+                const unsigned v = *p;
+                if (!disturbed) {
+                    disturbed = true;
+                    if (j == 0 && !nested) { for (int i = 1; i < k; ++i) run(i); }
+                    else if (nested && j + 1 < k) run(j + 1);
+                }
+                return v;
+            },
+            [&](unsigned *p, unsigned expected, unsigned desired) {
+                const unsigned seen = *p;
+                if (seen == expected) *p = desired;
+                return seen;
+            });
+    }
+};
+}  // namespace
+
+extern "C" unsigned model_park_reserve_interleaved(unsigned start, unsigned cap, const unsigned *n, int k, int nested, int *base) {
+    unsigned count = start;
+    ParkReplay r{&count, n, base, k, cap, nested != 0};
+    r.run(0);
+    return count;
+}
+
+// the fast path's own statistics since the last call (so3_device.h: HostCounters)
+extern "C" void model_fast_path_counters(long long *out2, int reset) {
+    out2[0] = so3::host_counters().refined_rows;
+    out2[1] = so3::host_counters().refinements;
+    if (reset) so3::host_counters() = so3::HostCounters{};
+}

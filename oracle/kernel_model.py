@@ -139,3 +139,20 @@ def se3_update_bwd(out12, t_init, g, fx, fy):
     d = np.empty_like(o)
     lib().model_se3_update_bwd(_p(o), _p(t), _p(g), _p(d), ctypes.c_float(fx), ctypes.c_float(fy), ctypes.c_int64(o.shape[0]))
     return d
+
+
+def park_reserve_interleaved(start, cap, n, nested=False):
+    """so3_rows.h's reservation protocol under a replayed interleaving (see kernel_model.cpp): (final count, base per actor)."""
+    n = np.ascontiguousarray(n, np.uint32)
+    base = np.full(n.shape[0], -2, np.int32)
+    f = lib().model_park_reserve_interleaved
+    f.restype = ctypes.c_uint
+    count = f(ctypes.c_uint(start), ctypes.c_uint(cap), _p(n), ctypes.c_int(n.shape[0]), ctypes.c_int(1 if nested else 0), _p(base))
+    return int(count), base
+
+
+def fast_path_counters(reset=True):
+    """(rows whose first eigenvector was not final, adjugates computed for them) since the last reset."""
+    out = np.zeros(2, np.int64)
+    lib().model_fast_path_counters(_p(out), ctypes.c_int(1 if reset else 0))
+    return int(out[0]), int(out[1])

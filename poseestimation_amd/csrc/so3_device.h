@@ -85,14 +85,27 @@ template <> struct Consts<double> {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
-// Per-half predicate of a packed pair.  Two bools (not an integer vector): the compiler then keeps the predicates as
-// lane masks in SGPRs and does the and / or / not on the scalar unit instead of materialising 0 / -1 in VGPRs.
+// Per-half predicate of a packed pair.
+#ifdef SO3_HOST_MODEL
 struct bool2 {
     bool x, y;
 };
 __device__ __forceinline__ bool2 operator&(bool2 a, bool2 b) { return bool2{a.x && b.x, a.y && b.y}; }
 __device__ __forceinline__ bool2 operator|(bool2 a, bool2 b) { return bool2{a.x || b.x, a.y || b.y}; }
 __device__ __forceinline__ bool2 operator^(bool2 a, bool2 b) { return bool2{a.x != b.x, a.y != b.y}; }
+#else
+// On the device a predicate IS its wave's lane mask, one 64-bit word per half (an SGPR pair): v_cmp writes it there, and / or /
+// not / "any lane" run on the scalar unit, and a select takes it back as v_cndmask's condition (inverse ballot).  Round 4 kept two
+// bools; wherever a predicate crossed a branch or a return the compiler packed the pair into a 16-bit VGPR (v_cndmask 0/1, v_or,
+// v_cmp_ne_u16: four vector instructions per "does any row ...", thirty per round of K1).  Every use sits in wave-uniform control
+// flow (the engine's loop), which the ballots need.
+struct bool2 {
+    unsigned long long x, y;
+};
+__device__ __forceinline__ bool2 operator&(bool2 a, bool2 b) { return bool2{a.x & b.x, a.y & b.y}; }
+__device__ __forceinline__ bool2 operator|(bool2 a, bool2 b) { return bool2{a.x | b.x, a.y | b.y}; }
+__device__ __forceinline__ bool2 operator^(bool2 a, bool2 b) { return bool2{a.x ^ b.x, a.y ^ b.y}; }
+#endif
 
 // ---- scalar-type traits ------------------------------------------------------------------------------
 template <class T> struct Tr;
@@ -128,6 +141,7 @@ template <> struct Tr<float> {
     static __device__ __forceinline__ bool ge(float a, float b) { return a >= b; }
     static __device__ __forceinline__ bool gt(float a, float b) { return a > b; }
     static __device__ __forceinline__ bool any(bool m) { return m; }
+    static __device__ __forceinline__ bool wave_any(bool m) { return hw::any_lane(m); }     // wave-uniform: on any lane of the wave
     static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
     static __device__ __forceinline__ bool mnot(bool m) { return !m; }
 };
@@ -164,13 +178,27 @@ template <> struct Tr<f32x2> {
         return i32x2{min(-hw::frexp_exp(x.x), 126), min(-hw::frexp_exp(x.y), 126)};
     }
     static __device__ __forceinline__ f32x2 ldexp(f32x2 x, i32x2 e) { return f32x2{ldexpf(x.x, e.x), ldexpf(x.y, e.y)}; }
+#ifdef SO3_HOST_MODEL
     static __device__ __forceinline__ f32x2 sel(bool2 c, f32x2 a, f32x2 b) { return f32x2{c.x ? a.x : b.x, c.y ? a.y : b.y}; }
     static __device__ __forceinline__ bool2 le(f32x2 a, f32x2 b) { return bool2{a.x <= b.x, a.y <= b.y}; }
     static __device__ __forceinline__ bool2 ge(f32x2 a, f32x2 b) { return bool2{a.x >= b.x, a.y >= b.y}; }
     static __device__ __forceinline__ bool2 gt(f32x2 a, f32x2 b) { return bool2{a.x > b.x, a.y > b.y}; }
     static __device__ __forceinline__ bool any(bool2 m) { return m.x || m.y; }
+    static __device__ __forceinline__ bool wave_any(bool2 m) { return m.x || m.y; }
     static __device__ __forceinline__ bool lane_of(bool2 m, int i) { return i ? m.y : m.x; }
     static __device__ __forceinline__ bool2 mnot(bool2 m) { return bool2{!m.x, !m.y}; }
+#else
+    static __device__ __forceinline__ bool mine(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+    static __device__ __forceinline__ f32x2 sel(bool2 c, f32x2 a, f32x2 b) { return f32x2{mine(c.x) ? a.x : b.x, mine(c.y) ? a.y : b.y}; }
+    static __device__ __forceinline__ bool2 le(f32x2 a, f32x2 b) { return bool2{__builtin_amdgcn_ballot_w64(a.x <= b.x), __builtin_amdgcn_ballot_w64(a.y <= b.y)}; }
+    static __device__ __forceinline__ bool2 ge(f32x2 a, f32x2 b) { return bool2{__builtin_amdgcn_ballot_w64(a.x >= b.x), __builtin_amdgcn_ballot_w64(a.y >= b.y)}; }
+    static __device__ __forceinline__ bool2 gt(f32x2 a, f32x2 b) { return bool2{__builtin_amdgcn_ballot_w64(a.x > b.x), __builtin_amdgcn_ballot_w64(a.y > b.y)}; }
+    // (a complement sets the bits of lanes that are switched off as well: the live ones are what counts)
+    static __device__ __forceinline__ bool any(bool2 m) { return ((m.x | m.y) & __builtin_amdgcn_ballot_w64(true)) != 0; }
+    static __device__ __forceinline__ bool wave_any(bool2 m) { return any(m); }
+    static __device__ __forceinline__ bool lane_of(bool2 m, int i) { return mine(i ? m.y : m.x); }
+    static __device__ __forceinline__ bool2 mnot(bool2 m) { return bool2{~m.x, ~m.y}; }
+#endif
 };
 
 template <> struct Tr<double> {           // one matrix per lane in float64 (so3_project_*_f64; not a benchmark path)
@@ -199,6 +227,7 @@ template <> struct Tr<double> {           // one matrix per lane in float64 (so3
     static __device__ __forceinline__ bool ge(double a, double b) { return a >= b; }
     static __device__ __forceinline__ bool gt(double a, double b) { return a > b; }
     static __device__ __forceinline__ bool any(bool m) { return m; }
+    static __device__ __forceinline__ bool wave_any(bool m) { return hw::any_lane(m); }
     static __device__ __forceinline__ bool lane_of(bool m, int) { return m; }
     static __device__ __forceinline__ bool mnot(bool m) { return !m; }
 };
@@ -311,7 +340,7 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         const T h01 = dot(a0, a1), h02 = dot(a0, a2), h12 = dot(a1, a2);
         const T t2 = R::splat(K::tol2);
         const typename R::mask early = R::le(h01 * h01, e0 * e1 * t2) & R::le(h02 * h02, e0 * e2 * t2) & R::le(h12 * h12, e1 * e2 * t2);
-        if (wave_any(R::any(R::mnot(early)))) {
+        if (R::wave_any(R::mnot(early))) {
             const V3<T> f0 = a0, f1 = a1, f2 = a2;
 #pragma unroll
             for (int sweep = 1; sweep < SWEEPS; ++sweep) {
@@ -332,7 +361,7 @@ __device__ __forceinline__ SignedSvd<T> signed_svd(const T (&m_in)[9]) {
         while (true) {
             const T g01 = dot(a0, a1);
             const typename R::mask need = R::gt(g01 * g01, n0 * n1 * R::splat(K::tol2));   // NaN / zero rows compare false
-            if (!wave_any(R::any(need))) break;
+            if (!R::wave_any(need)) break;
             // The branch is wave-uniform, the update is per matrix: a row keeps its three-sweep columns unless IT failed
             // the test, so its result does not depend on which other rows happen to share the wave.
             // float32: one more rotation of the pair that was tested is enough -- the other two residuals are already
@@ -482,14 +511,26 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 // be a little above the root, a Newton iterate thrown off near a critical point can be far above the whole spectrum, where
 // the adjugate is huge and looks healthy.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
 // time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
-constexpr float kQuatTau = 1e-3f;       // first pass
-constexpr float kQuatTau2 = 1e-5f;      // after a further refinement
-constexpr int kQuatExtra = 2;           // how many further refinements a row may take
+constexpr float kQuatTau2 = 1e-5f;      // a gap product below half of this (times lambda^3) cannot be helped by refining lambda (see `hopeless`)
+constexpr int kQuatExtra = 3;           // how many refinements of (lambda, q) a row may take
 constexpr float kQuatConv = 4e-4f;
 constexpr float kQuatUlps = 1.2e-7f;    // 2 ulp: the round-off of a float32 Rayleigh quotient, added to every measured move of lambda
-constexpr float kQuatResid = 8e-7f;     // residual of the first eigenvector, relative to lambda |q|, below which it is final
+#ifndef SO3_QUAT_CLOSE
+#define SO3_QUAT_CLOSE 8e-7f
+#endif
+constexpr float kQuatClose = SO3_QUAT_CLOSE;     // a first eigenvector whose Rayleigh quotient lies within this of its shift (relative) is final
 constexpr float kQuatWindowLo = 3.7252903e-9f, kQuatWindowHi = 17179869184.0f;   // 2^-28 <= |M|_F^2 <= 2^34 (see quat_rotation, step 1)
 constexpr float kQuatCurv = 0.5f;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
+
+#ifdef SO3_HOST_MODEL
+// What the CPU suite counts while it drives these templates (oracle/kernel_model.cpp): deterministic stand-ins for "how often does
+// a wave take the rare branch", which on the device is a matter of timing runs.
+struct HostCounters {
+    long long refined_rows = 0;      // rows whose first eigenvector was not final (quat_rotation_core, step 6)
+    long long refinements = 0;       // adjugates computed for them
+};
+inline HostCounters &host_counters() { static HostCounters c; return c; }
+#endif
 
 template <class T> struct Sym4 {        // symmetric 4x4, upper triangle
     T a00, a01, a02, a03, a11, a12, a13, a22, a23, a33;
@@ -525,12 +566,8 @@ template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T>
     q[0] = R::sel(mab, a0, e0); q[1] = R::sel(mab, a1, e1); q[2] = R::sel(mab, a2, e2); q[3] = R::sel(mab, a3, e3);
 }
 
-// Rayleigh quotient lambda = q^T K q / q^T q, and the squared residual |K q - lambda q|^2 / |q|^2 next to lambda^2.  With eps the
-// share of the neighbouring eigenvector in q, the residual is eps g2 |q|, and eps g2 / (2 lambda) is the error of R in the very
-// measure it is judged by (|dR| gap / s1): the residual over lambda bounds that error whatever the gap is.  (Divided by |q|^2
-// before it is compared: q is a column of the adjugate, |q|^2 ~ lambda^6, and lambda^2 |q|^2 leaves the float32 range for
-// entries above 2e4 -- where an infinite reference would call every row accurate.)
-template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4], T &res2, T &ref2) {
+// Rayleigh quotient lambda = q^T K q / q^T q; inv_n = 1 / q^T q (R(q) needs it again).
+template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4], T &inv_n) {
     typedef Tr<T> R;
     const T kq0 = R::fma(k.a03, q[3], R::fma(k.a02, q[2], R::fma(k.a01, q[1], k.a00 * q[0])));
     const T kq1 = R::fma(k.a13, q[3], R::fma(k.a12, q[2], R::fma(k.a11, q[1], k.a01 * q[0])));
@@ -538,46 +575,35 @@ template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const
     const T kq3 = R::fma(k.a33, q[3], R::fma(k.a23, q[2], R::fma(k.a13, q[1], k.a03 * q[0])));
     const T num = R::fma(q[3], kq3, R::fma(q[2], kq2, R::fma(q[1], kq1, q[0] * kq0)));
     const T den = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    const T inv = R::rcp(den);
-    const T lam = num * inv;
-    const T r0 = R::fma(-lam, q[0], kq0), r1 = R::fma(-lam, q[1], kq1), r2 = R::fma(-lam, q[2], kq2), r3 = R::fma(-lam, q[3], kq3);
-    // (r inv) r, not (r r) inv: a converged row's residual is ~1e-6 lambda |q| ~ 1e-6 lambda^4, whose square underflows for entries
-    // below 1e-4 -- and a zero residual called every such row accurate
-    res2 = R::fma(r3 * inv, r3, R::fma(r2 * inv, r2, R::fma(r1 * inv, r1, (r0 * inv) * r0)));
-    ref2 = lam * lam;
-    return lam;
-}
-template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4]) {
-    T a, b;
-    return rayleigh<T>(k, q, a, b);
+    inv_n = R::rcp(den);
+    return num * inv_n;
 }
 
-// A row is settled when (1) the product of the gaps -- the trace of the adjugate at the refined lambda, which is P'(lambda)
-// -- clears tau lambda^3, (2) the Rayleigh quotient moved lambda by at most kQuatConv times the gap's lower bound
-// trace / (2 lambda)^2, and (3) lambda is the LARGEST root: with P' > 0 (from 1), P'' > 0 and the third derivative
-// 24 lambda > 0 the Budan-Fourier count allows at most one root above lambda.  (Without 3 an exact double root at the top
-// -- small-integer matrices with s2 = s3 and det < 0 -- could throw the iteration below it and on to the third eigenvalue,
-// whose adjugate looks just as healthy.)  (3) is asked with a margin, P'' >= kQuatCurv |M|_F^2, which is criterion (4):
-// with gaps g2 <= g3 <= g4 of lambda to the other eigenvalues, P''/2 = g2 g3 + g2 g4 + g3 g4 <= 3 g3 g4, so the margin
-// bounds the SECOND gap g3 = 2 (s1 + s3') from below.  The adjugate's round-off is eps g4^3 / (g2 g3 g4): a small g2 is the
-// conditioning of R itself, a small g3 (all three singular values close and det < 0: a near-reflection) is a weakness of
-// the quaternion formulation only, and such rows go to the Jacobi path.
+// A row is settled when (1) the Rayleigh quotient moved lambda by at most kQuatConv times the gap's lower bound
+// trace / (2 lambda)^2 -- trace = tr adj(lambda I - K) = P'(lambda), the product of the three gaps -- and (2) lambda is the LARGEST
+// root: with P' > 0 (from 1), P'' > 0 and the third derivative 24 lambda > 0 the Budan-Fourier count allows at most one root above
+// lambda.  (Without 2 an exact double root at the top -- small-integer matrices with s2 = s3 and det < 0 -- could throw the
+// iteration below it and on to the third eigenvalue, whose adjugate looks just as healthy.)  (2) is asked with a margin,
+// P'' >= kQuatCurv |M|_F^2, criterion (3): with gaps g2 <= g3 <= g4 of lambda to the other eigenvalues,
+// P''/2 = g2 g3 + g2 g4 + g3 g4 <= 3 g3 g4, so the margin bounds the SECOND gap g3 = 2 (s1 + s3') from below.  The adjugate's
+// round-off is eps g4^3 / (g2 g3 g4): a small g2 is the conditioning of R itself, a small g3 (all three singular values close
+// and det < 0: a near-reflection) is a weakness of the quaternion formulation only, and such rows go to the Jacobi path.
+// The scale of (1) is L = lam_after + |move| >= both values (a settled row's lambda is positive): a shift far above the spectrum
+// has a huge, healthy-looking adjugate.  The measured move carries a floor of 2 ulp of L: lambda itself has that much round-off
+// however still the iteration stands (a move of exactly zero proved nothing: round 3's search on the device found rows with a gap
+// of 7e-6 s1 accepted that way, their rotation off by 0.7).  With the floor, (1) also says trace >= 4 kQuatUlps / kQuatConv L^3 =
+// 1.2e-3 L^3 -- which is why rounds 2-4's separate bar "trace > 1e-3 lambda^3" is gone: it was implied.
+// `move` (out): |lam_before - lam_after|, for the caller's own use.
 template <class T>
-__device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam_after, T trace, T tau, T twoc2, T f) {
+__device__ __forceinline__ typename Tr<T>::mask quat_settled(T lam_before, T lam_after, T trace, T twoc2, T f, T &move) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
-    const T l2 = lam_after * lam_after;
-    const typename R::mask separated = R::gt(trace, (l2 * lam_after) * tau);
-    // the scale of (2) is the LARGER of the two: a shift far above the spectrum has a huge, healthy-looking adjugate
-    const T lmax = R::max_fast(lam_before, lam_after);          // (a settled row's lambda is positive: criterion 3)
-    const T lmax2 = lmax * lmax;
-    // ... plus what float32 cannot see: lambda itself carries ~2 ulp of round-off however still the iteration stands (a move of
-    // exactly zero proved nothing: round 3's search on the device found rows with a gap of 7e-6 s1 accepted that way, their
-    // rotation off by 0.7).  With the floor, (2) also bounds the gap from below: gap >= 2 ulp lambda / kQuatConv ~ 3e-4 lambda.
-    const T moved = R::fma(lmax, R::splat(S(kQuatUlps)), R::abs(lam_before - lam_after));
-    const typename R::mask converged = R::le(moved * (lmax2 * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
-    const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)), l2, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
-    return separated & converged & topmost;
+    move = R::abs(lam_before - lam_after);
+    const T big = lam_after + move;
+    const T moved = R::fma(big, R::splat(S(kQuatUlps)), move);
+    const typename R::mask converged = R::le(moved * ((big * big) * R::splat(S(4))), trace * R::splat(S(kQuatConv)));
+    const typename R::mask topmost = R::gt(R::fma(R::splat(S(12)) * lam_after, lam_after, twoc2), f * R::splat(S(kQuatCurv))) & R::gt(lam_after, R::splat(S(0)));
+    return converged & topmost;
 }
 
 // The exact power of two a row outside the fast path's scale window was multiplied by (1 elsewhere): the backward from the
@@ -653,7 +679,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // one instead of 1.34 x.  (K1's engine kernel asks the same question in front of the fast path, OpProject; inside it, the second
     // way out costs 20 registers that kernel does not have at three waves per SIMD.)
     const typename R::mask usable = in_window & R::mnot(invariant_hard<T>(head));
-    if (SKIP && __builtin_expect(!wave_any(R::any(usable)), 0)) return R::mnot(usable);      // r is not used for hard rows
+    if (SKIP && __builtin_expect(!R::wave_any(usable), 0)) return R::mnot(usable);      // r is not used for hard rows
     const T c2 = f * R::splat(S(-2)), c1 = det * R::splat(S(-8)), c0 = R::fma(f, f, cf * R::splat(S(-4)));
     const T twoc2 = c2 + c2;
     // 4. lambda_max = s1 + s2 + s3'.  Start: the squared singular values are the roots of  mu^3 - f mu^2 + cf mu - det^2,
@@ -688,64 +714,64 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
         const T dp = R::fma(R::fma(R::splat(S(4)), l2, twoc2), lam, c1);
         lam = R::fma(-p, R::rcp(dp), lam);
     }
-    // 5. eigenvector; its Rayleigh quotient and residual.  On Gaussian input the root is good to an ulp or two for all but
-    // 2e-3 of the rows, and then the first vector is already as good as a second one: a row whose residual is below
-    // kQuatResid lambda |q| keeps it (that bounds its error of R, in the measure |dR| gap / s1, by kQuatResid / 2).  Only when
-    // some row of the wave fails that test is the eigenvector recomputed at the Rayleigh quotient (one round of 128 rows in five), and only
-    // the rows that failed take it.
-    T q[4], trace;
+    // 5. eigenvector and its Rayleigh quotient lam2.  On Gaussian input the root is good to an ulp or two for all but 2e-3 of the
+    // rows, and then the first vector is as good as a second one would be: with delta = lam - lambda the vector carries
+    // eps = delta / g2 of its neighbour, the error of R in the measure it is judged by (|dR| gap / s1) is delta / s1, and the quotient,
+    // being second-order accurate, MEASURES delta: a row whose quotient lies within kQuatClose of its shift, and which is settled
+    // (quat_settled above), keeps its first vector.  (Rounds 2-4 asked the residual |K q - lam2 q| instead: 13 packed instructions per
+    // pair for the same decision -- what else the residual sees, the adjugate's own round-off, a second vector has too.)
+    T q[4], trace, inv_n, move;
     dominant_column<T>(k, lam, q, trace);
-    T res2, ref2;
-    T lam2 = rayleigh<T>(k, q, res2, ref2);
-    const typename R::mask accurate = R::le(res2, ref2 * R::splat(S(kQuatResid * kQuatResid)));
-    T shift = lam;                               // the shift the current q was computed at
-    if (__builtin_expect(wave_any(R::any(R::mnot(accurate))), 0)) {
-        T q2[4], trace2;
-        dominant_column<T>(k, lam2, q2, trace2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) q[i] = R::sel(accurate, q[i], q2[i]);
-        trace = R::sel(accurate, trace, trace2);
-        shift = R::sel(accurate, lam, lam2);
-    }
-    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled)
-    typename R::mask settled = quat_settled<T>(lam, lam2, trace, R::splat(S(kQuatTau)), twoc2, f);
-    // More refinements, each a wave-uniform branch kept by the rows that needed it (the first about one round in sixty on
-    // Gaussian input, the second one in five hundred): the quotient squares the error again, which settles rows whose
-    // root was still on its way and rows with a gap down to ~3e-4 of lambda.  Each is judged by how far the quotient
-    // of q lies from the shift q was computed at.  What is left (rank-deficient, ties, gaps at round-off) is hard.
-    // A row whose gap product does not reach half the second pass's threshold, or whose curvature P'' does not reach half of
-    // criterion (4)'s bar (a near-reflection: refining lambda does not move either by a factor of two), cannot be settled
-    // by refining it: it is FROZEN -- it takes no refinement and does not hold its wave in this loop -- and goes to the Jacobi path.
-    // Batches of ties, reflections and rank-deficient rows then pay the fast path once, not three times.  (Per row, like
-    // everything here: a frozen row never takes a refinement that a wave-mate asked for.)
-    if (__builtin_expect(wave_any(R::any(R::mnot(settled))), 0)) {
+    const T lam2 = rayleigh<T>(k, q, inv_n);
+    typename R::mask settled = quat_settled<T>(lam, lam2, trace, twoc2, f, move);
+    settled = settled & R::le(move, lam2 * R::splat(S(kQuatClose)));
+    // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled) are refined -- q again from the
+    // adjugate at the quotient, which squares the error -- under ONE wave-uniform branch (one round of 128 rows in five on Gaussian
+    // input), in a loop that its own rows keep running (a second pass one round in sixty, a third one in five hundred): a refined
+    // vector is judged by how far the quotient of its predecessor lay from the shift the predecessor was computed at.  That settles
+    // rows whose root was still on its way and rows with a gap down to ~3e-4 of lambda; what is left (rank-deficient, ties, gaps at
+    // round-off) is hard.  A row whose gap product does not reach half of kQuatTau2 lambda^3, or whose curvature P'' does not
+    // reach half of criterion (3)'s bar (a near-reflection), cannot be settled by refining lambda (neither moves by a factor of
+    // two): it is FROZEN -- it takes no refinement and does not hold its wave in the loop -- and goes to the Jacobi path, so that
+    // batches of ties, reflections and rank-deficient rows pay the fast path once.  Per row, like everything here: a settled or
+    // frozen row never takes a refinement that a wave-mate asked for.
+    if (__builtin_expect(R::wave_any(R::mnot(settled)), 0)) {
+#ifdef SO3_HOST_MODEL
+        ++host_counters().refined_rows;          // (one "lane" per row on the host: how often the device's wave-uniform branch would be asked for)
+#endif
         const T l22 = lam2 * lam2;
         const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
                                                   & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
         typename R::mask frozen = settled | hopeless;
+        T shift = lam, quot = lam2;              // the shift the current q was computed at, and q's Rayleigh quotient
 #pragma unroll 1
-        for (int extra = 0; extra < kQuatExtra && wave_any(R::any(R::mnot(frozen))); ++extra) {
-            T q3[4], trace3;
-            const T lam3 = rayleigh<T>(k, q);
-            dominant_column<T>(k, lam3, q3, trace3);
-            const typename R::mask settled3 = quat_settled<T>(shift, lam3, trace3, R::splat(S(kQuatTau2)), twoc2, f);
+        for (int extra = 0;; ++extra) {
+            T qn[4], tracen, unused;
+#ifdef SO3_HOST_MODEL
+            ++host_counters().refinements;
+#endif
+            dominant_column<T>(k, quot, qn, tracen);
+            const typename R::mask good = quat_settled<T>(shift, quot, tracen, twoc2, f, unused);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], q3[i]);
-            shift = R::sel(frozen, shift, lam3);
-            settled = settled | (settled3 & R::mnot(frozen));
+            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], qn[i]);
+            shift = R::sel(frozen, shift, quot);
+            settled = settled | (good & R::mnot(frozen));
             frozen = settled | hopeless;
+            if (extra + 1 >= kQuatExtra || !R::wave_any(R::mnot(frozen))) break;
+            quot = rayleigh<T>(k, q, inv_n);
         }
+        inv_n = R::rcp(R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0]))));
     }
     // 7. R(q), q = (w, x, y, z) unnormalised
-    const T nq = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    const T s2 = R::rcp(nq) * two;
+    const T s2 = inv_n + inv_n;
     const T w = q[0], x = q[1], y = q[2], z = q[3];
     const T xs = x * s2, ys = y * s2, zs = z * s2;
-    const T wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const T wx = w * xs, wy = w * ys, wz = w * zs;
     const T one = R::splat(S(1));
-    r[0] = one - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
-    r[3] = xy + wz; r[4] = one - (xx + zz); r[5] = yz - wx;
-    r[6] = xz - wy; r[7] = yz + wx; r[8] = one - (xx + yy);
+    const T dz = R::fma(-z, zs, one), dy = R::fma(-y, ys, one);
+    r[0] = R::fma(-y, ys, dz); r[1] = R::fma(x, ys, -wz); r[2] = R::fma(x, zs, wy);
+    r[3] = R::fma(x, ys, wz); r[4] = R::fma(-x, xs, dz); r[5] = R::fma(y, zs, -wx);
+    r[6] = R::fma(x, zs, -wy); r[7] = R::fma(y, zs, wx); r[8] = R::fma(-x, xs, dy);
     const typename R::mask finite = R::le(R::abs(s2), R::splat(S(3e38)));
     return R::mnot(settled & finite & usable);
 }
@@ -761,11 +787,13 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // 2^36, inside round 2's window, came out hard -- and sixth powers of the entries a few orders clear of the underflow
     // threshold: entries between 2e-5 and 4e4).  Network outputs are O(1): no unconditional prescale (it cost
     // 9 packed and 16 plain instructions per pair of matrices), and the common path works on m_in itself, without a copy.
-    T f = m_in[0] * m_in[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) f = R::fma(m_in[i], m_in[i], f);
+    // (row by row: three chains of three -- one chain of nine dependent packed instructions issues with a wait state between each two)
+    const T f0 = R::fma(m_in[2], m_in[2], R::fma(m_in[1], m_in[1], m_in[0] * m_in[0]));
+    const T f1 = R::fma(m_in[5], m_in[5], R::fma(m_in[4], m_in[4], m_in[3] * m_in[3]));
+    const T f2 = R::fma(m_in[8], m_in[8], R::fma(m_in[7], m_in[7], m_in[6] * m_in[6]));
+    const T f = (f0 + f1) + f2;
     const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
-    const bool any_outside = wave_any(R::any(R::mnot(inside)));
+    const bool any_outside = R::wave_any(R::mnot(inside));
     if (prescale != nullptr) { prescale->factor = R::splat(S(1)); prescale->any = any_outside; }
     if (__builtin_expect(!any_outside, 1)) return quat_rotation_core<T, SKIP>(m_in, f, inside, r);
     // Rows outside the window get an exact power-of-two prescale (largest |entry| -> [0.5, 1); R does not depend on the scale)
@@ -779,11 +807,12 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     if (prescale != nullptr) prescale->factor = sc;
 #pragma unroll
     for (int i = 0; i < 9; ++i) m[i] = m_in[i] * sc;
-    T f2 = m[0] * m[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) f2 = R::fma(m[i], m[i], f2);
-    const typename R::mask inside2 = R::ge(f2, R::splat(S(kQuatWindowLo))) & R::le(f2, R::splat(S(kQuatWindowHi)));
-    typename R::mask hard = quat_rotation_core<T, SKIP>(m, f2, inside2, r);
+    const T fs0 = R::fma(m[2], m[2], R::fma(m[1], m[1], m[0] * m[0]));
+    const T fs1 = R::fma(m[5], m[5], R::fma(m[4], m[4], m[3] * m[3]));
+    const T fs2 = R::fma(m[8], m[8], R::fma(m[7], m[7], m[6] * m[6]));
+    const T fs = (fs0 + fs1) + fs2;
+    const typename R::mask inside2 = R::ge(fs, R::splat(S(kQuatWindowLo))) & R::le(fs, R::splat(S(kQuatWindowHi)));
+    typename R::mask hard = quat_rotation_core<T, SKIP>(m, fs, inside2, r);
     // An all-zero row (a dead head) is the identity (the reference: the SVD of the zero matrix comes back with U = V = I), and the Jacobi
     // path gives exactly that -- so the forward says so here, in the branch such a row has taken anyway, instead of sending it
     // there: 1 % of zero rows cost K1 1.2-1.36 x a Gaussian batch.  Forward only (no `prescale`): the backward of a zero row goes
@@ -803,12 +832,13 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
 template <class T> __device__ __forceinline__ bool all_rows_invariant_hard(const T (&m)[9]) {
     typedef Tr<T> R;
     typedef typename R::scalar S;
-    T f = m[0] * m[0];
-#pragma unroll
-    for (int i = 1; i < 9; ++i) f = R::fma(m[i], m[i], f);
+    const T f0 = R::fma(m[2], m[2], R::fma(m[1], m[1], m[0] * m[0]));         // (the same bits as quat_rotation's)
+    const T f1 = R::fma(m[5], m[5], R::fma(m[4], m[4], m[3] * m[3]));
+    const T f2 = R::fma(m[8], m[8], R::fma(m[7], m[7], m[6] * m[6]));
+    const T f = (f0 + f1) + f2;
     const typename R::mask inside = R::ge(f, R::splat(S(kQuatWindowLo))) & R::le(f, R::splat(S(kQuatWindowHi)));
     const typename R::mask sure = inside & invariant_hard<T>(cubic_head<T>(m, f));
-    return !wave_any(R::any(R::mnot(sure)));
+    return !R::wave_any(R::mnot(sure));
 }
 
 // K1's arithmetic for every forward entry point: the fast path, and the Jacobi path for the rows it declares hard.
@@ -828,7 +858,7 @@ template <class T> struct HardRows {
 template <bool WANT_BWD, class T, bool SKIP = true> __device__ __forceinline__ void project_rotation_frames(const T (&m)[9], T (&r)[9], HardRows<T> &h) {
     typedef Tr<T> R;
     h.hard = quat_rotation<T, SKIP>(m, r, WANT_BWD ? &h.prescale : nullptr);
-    h.any = wave_any(R::any(h.hard));
+    h.any = R::wave_any(h.hard);
     if (__builtin_expect(h.any, 0)) {
         h.frames = signed_svd<WANT_BWD, T>(m);
         T rj[9];

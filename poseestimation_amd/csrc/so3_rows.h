@@ -139,6 +139,41 @@ template <int EB, int N = 9, int G = 1> struct UnitIO {
 #pragma unroll
         for (int i = 0; i < N; ++i) Tr<T>::set(m[i], k, img[lane * N + i]);
     }
+    // the lane's rows of ALL the round's units.  For the packed engine (two units of nine-element rows: K1, K2, K3, K1+K4) that is
+    // eighteen ds_read_b32 with immediate offsets off ONE address register, each straight into its half of a register pair, and
+    // one wait behind them -- spelled out, because the compiler pairs NEIGHBOURING elements of one row into ds_read2_b32 (it sorts a
+    // base's reads by offset) and then moves every dword into its pair: 18 v_mov per round and array, 4 % of K1's vector instructions.
+    // (Its waitcnt bookkeeping does not see into an asm statement, hence the wait inside.)
+    // The phantom second unit of an odd tail reads its own image: zeros, since the range check returned zeros for it.
+    template <class T> static __device__ __forceinline__ void read_rows(const char *slot, int lane, T (&m)[N]) {
+        if constexpr (N == 9 && G == 2 && Tr<T>::kLanes == 2) {
+            static_assert(kUnitImage == 2304, "the offsets below");
+            const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(slot)) + static_cast<unsigned>(lane) * 36u;   // (low word of a flat LDS address = the LDS address)
+            float a0, a1, a2, a3, a4, a5, a6, a7, a8, b0, b1, b2, b3, b4, b5, b6, b7, b8;
+            asm volatile("ds_read_b32 %0, %18\n\tds_read_b32 %9, %18 offset:2304\n\t"
+                         "ds_read_b32 %1, %18 offset:4\n\tds_read_b32 %10, %18 offset:2308\n\t"
+                         "ds_read_b32 %2, %18 offset:8\n\tds_read_b32 %11, %18 offset:2312\n\t"
+                         "ds_read_b32 %3, %18 offset:12\n\tds_read_b32 %12, %18 offset:2316\n\t"
+                         "ds_read_b32 %4, %18 offset:16\n\tds_read_b32 %13, %18 offset:2320\n\t"
+                         "ds_read_b32 %5, %18 offset:20\n\tds_read_b32 %14, %18 offset:2324\n\t"
+                         "ds_read_b32 %6, %18 offset:24\n\tds_read_b32 %15, %18 offset:2328\n\t"
+                         "ds_read_b32 %7, %18 offset:28\n\tds_read_b32 %16, %18 offset:2332\n\t"
+                         "ds_read_b32 %8, %18 offset:32\n\tds_read_b32 %17, %18 offset:2336\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7), "=&v"(a8),
+                           "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7), "=&v"(b8)
+                         : "v"(addr)
+                         : "memory");
+            m[0] = T{a0, b0}; m[1] = T{a1, b1}; m[2] = T{a2, b2}; m[3] = T{a3, b3}; m[4] = T{a4, b4};
+            m[5] = T{a5, b5}; m[6] = T{a6, b6}; m[7] = T{a7, b7}; m[8] = T{a8, b8};
+        } else {
+            const float *img = reinterpret_cast<const float *>(slot);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int k = 0; k < G; ++k) Tr<T>::set(m[i], k, img[k * (kUnitImage / 4) + lane * N + i]);
+        }
+    }
     template <class T> static __device__ __forceinline__ void write_row(char *slot, int u, int lane, int k, const T (&m)[N]) {
         float *img = reinterpret_cast<float *>(slot + u * kUnitImage);
 #pragma unroll
@@ -218,6 +253,23 @@ __device__ __forceinline__ void ticket_finish(ReduceWs *ws, unsigned slot, unsig
 }
 
 #endif  // !SO3_HOST_MODEL
+
+// A reservation of n consecutive entries in a list of `cap` (the workgroup's list of parked hard rows, below): -1 when they do
+// not fit.  A compare-and-swap, so an attempt that fails never touches the count: round 4 added n and took it back on failure, and
+// with three waves racing near a full list a reservation could succeed BETWEEN another's add and its subtract -- its base then
+// counted entries nobody wrote, and the redo pass would have stored through row numbers read from uninitialised LDS.  Generic
+// over the primitive (cas(p, expected, desired) returns what it found; load(p) reads the count) so that the CPU suite replays
+// interleavings on it (oracle/kernel_model.cpp: model_park_reserve_interleaved).
+template <class Load, class Cas>
+__device__ __forceinline__ int park_reserve_protocol(unsigned *count, unsigned n, unsigned cap, Load &&load, Cas &&cas) {
+    unsigned old = load(count);
+    while (true) {
+        if (old + n > cap) return -1;
+        const unsigned seen = cas(count, old, old + n);
+        if (seen == old) return static_cast<int>(old);
+        old = seen;
+    }
+}
 
 template <int NPL> struct LaneT;
 template <> struct LaneT<1> { typedef float type; };
@@ -338,12 +390,11 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 ctx.unit[k] = t * NPL + k;
-                ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail,
-                const int u = ctx.exists[k] ? k : 0;    // whose lanes work on the round's first unit instead (results dropped)
-                I0::read_row(img, u, lane, k, rows.a);
-                if constexpr (Op::kIn1 != 0 && !Op::kLateIn1) I1::read_row(img + kIn0B, u, lane, k, rows.b);
-                if constexpr (Op::kIn2 != 0) I2::read_row(img + kIn0B + kIn1B, u, lane, k, rows.c);
-            }
+                ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail, whose lanes
+            }                                           // work on the zeros the range check returned for it (results dropped)
+            I0::template read_rows<T>(img, lane, rows.a);
+            if constexpr (Op::kIn1 != 0 && !Op::kLateIn1) I1::template read_rows<T>(img + kIn0B, lane, rows.b);
+            if constexpr (Op::kIn2 != 0) I2::template read_rows<T>(img + kIn0B + kIn1B, lane, rows.c);
         };
         // the round's results: rows -> image (over the consumed inputs) -> float4 per lane -> HBM
         auto put_rows = [&](char *img, const Rows<T, Op> &rows) {
@@ -469,8 +520,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 // The rows of the second input for an operation with kLateIn1 (called from its compute(), before the results are staged).
 template <class T, class Op, int NPL> __device__ __forceinline__ void late_in1(const RowCtx<NPL> &ctx, T (&b)[Op::kIn1N]) {
     typedef UnitIO<Op::kIn1, Op::kIn1N, NPL> I1;
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) I1::read_row(ctx.img1, ctx.exists[k] ? k : 0, ctx.lane, k, b);
+    I1::template read_rows<T>(ctx.img1, ctx.lane, b);
 }
 #endif
 
@@ -516,13 +566,10 @@ struct OpBase {
 // hard rows 1.8 x, whole batches 2.0-2.3 x.  The same experiment showed K2 at three waves per SIMD, spill-free, no faster than at two.)
 template <int CAP> __device__ __forceinline__ int park_reserve(unsigned *count, int n) {
     int base = 0;
-    if (lane_id_now() == 0) {
-        // a reservation that does not fit is taken back at once; while it stands the count exceeds CAP, so nobody else's succeeds
-        // and the list never has a hole
-        const unsigned old = atomicAdd(count, static_cast<unsigned>(n));
-        base = old + static_cast<unsigned>(n) <= static_cast<unsigned>(CAP) ? static_cast<int>(old) : -1;
-        if (base < 0) atomicSub(count, static_cast<unsigned>(n));
-    }
+    if (lane_id_now() == 0)
+        base = park_reserve_protocol(count, static_cast<unsigned>(n), static_cast<unsigned>(CAP),
+                                     [](unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); },
+                                     [](unsigned *p, unsigned expected, unsigned desired) { return atomicCAS(p, expected, desired); });
     return __builtin_amdgcn_readfirstlane(base);
 }
 // How many hard rows the round holds (wave-uniform), and the list entry of each hard lane-half given the round's first entry.
@@ -627,7 +674,7 @@ __device__ __forceinline__ typename Tr<T>::mask project_or_park(const T (&m)[9],
     const int asked = ctx.dense;                     // 1: the question was asked and the answer was no -- a batch of ties, say: not again in this wave
     const typename R::mask hard = quat_rotation<T, false>(m, r);     // no early way out (SKIP): at three waves per SIMD K1 has no registers to spare for it
     ctx.dense = 0;
-    if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+    if (__builtin_expect(R::wave_any(hard), 0)) {
         bool dense;
         const int base = park_hard_rows<T, NPL, CAP>(ctx, hard, &dense);
         ctx.dense = dense ? (asked != 0 ? 2 : 1) : 0;
@@ -703,7 +750,7 @@ struct OpProjectBwd : OpBase {
         h.hard = quat_rotation<T>(rows.a, r, &h.prescale);
         h.any = false;
         int base = -1;
-        if (__builtin_expect(wave_any(R::any(h.hard)), 0)) {
+        if (__builtin_expect(R::wave_any(h.hard), 0)) {
             base = park_hard_rows<T, NPL, kParkCap>(ctx, h.hard);
             if (base >= 0) {
                 park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, h.hard, 0, rows.a);
@@ -747,7 +794,7 @@ struct OpFrobHead : OpBase {
         h.hard = quat_rotation<T>(m, r, WANT_DM ? &h.prescale : nullptr);
         h.any = false;
         int base = -1;
-        if (__builtin_expect(wave_any(R::any(h.hard)), 0)) {
+        if (__builtin_expect(R::wave_any(h.hard), 0)) {
             base = park_hard_rows<T, NPL, kParkCap>(ctx, h.hard);
             if (base >= 0) {
                 park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, h.hard, 0, m);
@@ -999,7 +1046,7 @@ struct OpProjectAngle : OpBase {
         T r[9];
         const typename R::mask hard = quat_rotation<T>(rows.a, r);
         int base = -1;
-        if (__builtin_expect(wave_any(R::any(hard)), 0)) {
+        if (__builtin_expect(R::wave_any(hard), 0)) {
             base = park_hard_rows<T, NPL, kParkCap>(ctx, hard);
             if (base >= 0) {
                 park_words<T, NPL, kParkCap, kParkWords, true, 9>(ctx, base, hard, 0, rows.a);
