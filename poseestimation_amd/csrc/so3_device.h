@@ -537,7 +537,10 @@ template <class T> struct Sym4 {        // symmetric 4x4, upper triangle
 };
 
 // The largest column of adj(lam I - K) and the trace of the adjugate.
-template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T> &k, T lam, T (&q)[4], T &trace) {
+template <class T> struct Quat {        // (w, x, y, z), unnormalised.  Four named members, not T[4]: the compiler made ONE 256-bit value of the array,
+    T w, x, y, z;                       // and where the rare refinement branch rejoins the round it then copied all of it, whichever path had been taken
+};
+template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T> &k, T lam, Quat<T> &q, T &trace) {
     typedef Tr<T> R;
     const T n00 = lam - k.a00, n11 = lam - k.a11, n22 = lam - k.a22, n33 = lam - k.a33;
     const T n01 = -k.a01, n02 = -k.a02, n03 = -k.a03, n12 = -k.a12, n13 = -k.a13, n23 = -k.a23;
@@ -563,19 +566,22 @@ template <class T> __device__ __forceinline__ void dominant_column(const Sym4<T>
     const T a0 = R::sel(m01, b00, b01), a1 = R::sel(m01, b01, b11), a2 = R::sel(m01, b02, b12), a3 = R::sel(m01, b03, b13);
     const T e0 = R::sel(m23, b02, b03), e1 = R::sel(m23, b12, b13), e2 = R::sel(m23, b22, b23), e3 = R::sel(m23, b23, b33);
     const typename R::mask mab = R::ge(da, db);
-    q[0] = R::sel(mab, a0, e0); q[1] = R::sel(mab, a1, e1); q[2] = R::sel(mab, a2, e2); q[3] = R::sel(mab, a3, e3);
+    q.w = R::sel(mab, a0, e0); q.x = R::sel(mab, a1, e1); q.y = R::sel(mab, a2, e2); q.z = R::sel(mab, a3, e3);
 }
 
 // Rayleigh quotient lambda = q^T K q / q^T q; inv_n = 1 / q^T q (R(q) needs it again).
-template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const T (&q)[4], T &inv_n) {
+template <class T> __device__ __forceinline__ T norm2(const Quat<T> &q) {
     typedef Tr<T> R;
-    const T kq0 = R::fma(k.a03, q[3], R::fma(k.a02, q[2], R::fma(k.a01, q[1], k.a00 * q[0])));
-    const T kq1 = R::fma(k.a13, q[3], R::fma(k.a12, q[2], R::fma(k.a11, q[1], k.a01 * q[0])));
-    const T kq2 = R::fma(k.a23, q[3], R::fma(k.a22, q[2], R::fma(k.a12, q[1], k.a02 * q[0])));
-    const T kq3 = R::fma(k.a33, q[3], R::fma(k.a23, q[2], R::fma(k.a13, q[1], k.a03 * q[0])));
-    const T num = R::fma(q[3], kq3, R::fma(q[2], kq2, R::fma(q[1], kq1, q[0] * kq0)));
-    const T den = R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0])));
-    inv_n = R::rcp(den);
+    return R::fma(q.z, q.z, R::fma(q.y, q.y, R::fma(q.x, q.x, q.w * q.w)));
+}
+template <class T> __device__ __forceinline__ T rayleigh(const Sym4<T> &k, const Quat<T> &q, T &inv_n) {
+    typedef Tr<T> R;
+    const T kq0 = R::fma(k.a03, q.z, R::fma(k.a02, q.y, R::fma(k.a01, q.x, k.a00 * q.w)));
+    const T kq1 = R::fma(k.a13, q.z, R::fma(k.a12, q.y, R::fma(k.a11, q.x, k.a01 * q.w)));
+    const T kq2 = R::fma(k.a23, q.z, R::fma(k.a22, q.y, R::fma(k.a12, q.x, k.a02 * q.w)));
+    const T kq3 = R::fma(k.a33, q.z, R::fma(k.a23, q.y, R::fma(k.a13, q.x, k.a03 * q.w)));
+    const T num = R::fma(q.z, kq3, R::fma(q.y, kq2, R::fma(q.x, kq1, q.w * kq0)));
+    inv_n = R::rcp(norm2<T>(q));
     return num * inv_n;
 }
 
@@ -720,7 +726,8 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // being second-order accurate, MEASURES delta: a row whose quotient lies within kQuatClose of its shift, and which is settled
     // (quat_settled above), keeps its first vector.  (Rounds 2-4 asked the residual |K q - lam2 q| instead: 13 packed instructions per
     // pair for the same decision -- what else the residual sees, the adjugate's own round-off, a second vector has too.)
-    T q[4], trace, inv_n, move;
+    Quat<T> q;
+    T trace, inv_n, move;
     dominant_column<T>(k, lam, q, trace);
     const T lam2 = rayleigh<T>(k, q, inv_n);
     typename R::mask settled = quat_settled<T>(lam, lam2, trace, twoc2, f, move);
@@ -746,25 +753,25 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
         T shift = lam, quot = lam2;              // the shift the current q was computed at, and q's Rayleigh quotient
 #pragma unroll 1
         for (int extra = 0;; ++extra) {
-            T qn[4], tracen, unused;
+            Quat<T> qn;
+            T tracen, unused;
 #ifdef SO3_HOST_MODEL
             ++host_counters().refinements;
 #endif
             dominant_column<T>(k, quot, qn, tracen);
             const typename R::mask good = quat_settled<T>(shift, quot, tracen, twoc2, f, unused);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q[i] = R::sel(frozen, q[i], qn[i]);
+            q.w = R::sel(frozen, q.w, qn.w); q.x = R::sel(frozen, q.x, qn.x); q.y = R::sel(frozen, q.y, qn.y); q.z = R::sel(frozen, q.z, qn.z);
             shift = R::sel(frozen, shift, quot);
             settled = settled | (good & R::mnot(frozen));
             frozen = settled | hopeless;
             if (extra + 1 >= kQuatExtra || !R::wave_any(R::mnot(frozen))) break;
             quot = rayleigh<T>(k, q, inv_n);
         }
-        inv_n = R::rcp(R::fma(q[3], q[3], R::fma(q[2], q[2], R::fma(q[1], q[1], q[0] * q[0]))));
+        inv_n = R::rcp(norm2<T>(q));
     }
     // 7. R(q), q = (w, x, y, z) unnormalised
     const T s2 = inv_n + inv_n;
-    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    const T w = q.w, x = q.x, y = q.y, z = q.z;
     const T xs = x * s2, ys = y * s2, zs = z * s2;
     const T wx = w * xs, wy = w * ys, wz = w * zs;
     const T one = R::splat(S(1));

@@ -351,10 +351,13 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     if (STAMP) { t_real0 = __builtin_amdgcn_s_memrealtime(); t_mem0 = __builtin_amdgcn_s_memtime(); }
     const int lane = threadIdx.x & 63;
     const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // SGPR: unit indices stay scalar
-    const int64_t nrounds = (nunits + NPL - 1) / NPL;
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kWaves;
-    const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
-    int64_t t = wave_id;
+    // Round numbers are 32-bit: the scalar unit has no 64-bit ordered compare, and as int64 the loop's "any rounds left", "how many units
+    // of this round exist" went through v_cmp_*_i64 on the vector unit every round.  (2^31 rounds of 128 rows are 10 TB of float32 rows;
+    // the host refuses a batch beyond that, stream_units.)  Units and rows stay 64-bit where they become addresses.
+    const int nrounds = static_cast<int>((nunits + NPL - 1) / NPL);
+    const int stride = static_cast<int>(gridDim.x) * kWaves;
+    const int wave_id = static_cast<int>(blockIdx.x) * kWaves + wave_in_block;
+    int t = wave_id;
     RowCtx<NPL> ctx;
     ctx.lane = lane;
     ctx.acc = 0.0;
@@ -371,9 +374,10 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     ctx.n_half = 0;
     ctx.n_pi = 0;
     if (t < nrounds) {
-        auto units_of = [&](int64_t tr) -> int {            // how many of round tr's NPL units exist (0 past the end)
-            const int64_t left = nunits - tr * NPL;
-            return tr < nrounds ? static_cast<int>(left < NPL ? left : NPL) : 0;
+        const int nunits32 = static_cast<int>(nunits);
+        auto units_of = [&](int tr) -> int {                // how many of round tr's NPL units exist (0 past the end)
+            const int left = nunits32 - tr * NPL;
+            return tr < nrounds ? (left < NPL ? left : NPL) : 0;
         };
         // STAMP builds: wall-clock (100 MHz) begin / end of the arithmetic of the wave's first four rounds
         auto phase = [&](int ph) {
@@ -381,7 +385,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                 if (rounds_done < 4 && lane == 0)
-                    stamps[6 * static_cast<int64_t>(gridDim.x) * kWaves + 40 * wave_id + 10 * rounds_done + ph] = now;
+                    stamps[6 * static_cast<int64_t>(gridDim.x) * kWaves + 40 * static_cast<int64_t>(wave_id) + 10 * rounds_done + ph] = now;
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -390,7 +394,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 ctx.unit[k] = t * NPL + k;
-                ctx.exists[k] = ctx.unit[k] < nunits;   // wave-uniform; false only for the phantom unit of an odd tail, whose lanes
+                ctx.exists[k] = t * NPL + k < nunits32; // wave-uniform; false only for the phantom unit of an odd tail, whose lanes
             }                                           // work on the zeros the range check returned for it (results dropped)
             I0::template read_rows<T>(img, lane, rows.a);
             if constexpr (Op::kIn1 != 0 && !Op::kLateIn1) I1::template read_rows<T>(img + kIn0B, lane, rows.b);
@@ -410,8 +414,8 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                 if constexpr (Op::kOut1 != 0) O1::from_lds(v1, img + kOut0B, lane);
                 wave_lds_fence();
                 const int cnt = units_of(t);            // an odd tail's phantom unit is cut off by the descriptor
-                if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, t * NPL, cnt), v0, lane);
-                if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, t * NPL, cnt), v1, lane);
+                if constexpr (Op::kOut0 != 0) O0::store(O0::rsrc(op.out0, static_cast<int64_t>(t) * NPL, cnt), v0, lane);
+                if constexpr (Op::kOut1 != 0) O1::store(O1::rsrc(op.out1, static_cast<int64_t>(t) * NPL, cnt), v1, lane);
             }
         };
         {
@@ -420,9 +424,9 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             ctx.slot = slot;
             // One round is in flight in registers behind the round that sits in LDS.
             f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
-            auto issue = [&](int64_t tr) {                  // past the last round the descriptors are empty: the loads
+            auto issue = [&](int tr) {                      // past the last round the descriptors are empty: the loads
                 const int cnt = units_of(tr);               // return 0 and cost no traffic
-                const int64_t u = cnt > 0 ? tr * NPL : 0;
+                const int64_t u = cnt > 0 ? static_cast<int64_t>(tr) * NPL : 0;
                 I0::fetch(in0, I0::rsrc(op.in0, u, cnt), lane);
                 if constexpr (Op::kIn1 != 0) I1::fetch(in1, I1::rsrc(op.in1, u, cnt), lane);
                 if constexpr (Op::kIn2 != 0) I2::fetch(in2, I2::rsrc(op.in2, u, cnt), lane);
@@ -434,7 +438,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             };
             issue(t);
             land();
-            int64_t held = t + stride;                      // the round the registers hold (>= nrounds: none, empty loads)
+            int held = t + stride;                          // the round the registers hold (>= nrounds: none, empty loads)
             issue(held);
             while (true) {
                 wave_lds_fence();
@@ -500,6 +504,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     if (STAMP && wave_id < nrounds) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
+            const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
             stamps[6 * wave_id + 0] = t_real0;
             stamps[6 * wave_id + 1] = __builtin_amdgcn_s_memrealtime();
             stamps[6 * wave_id + 2] = t_mem0;

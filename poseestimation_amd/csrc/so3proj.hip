@@ -1677,6 +1677,7 @@ inline bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3
 inline int64_t stream_units(int64_t B, std::initializer_list<const void *> ptrs) {
     for (const void *p : ptrs)
         if (p != nullptr && !aligned4(p)) return 0;
+    if (B / so3::kUnitRows > 0x7fffffff - 4096) return 0;      // the engine numbers its rounds in 32 bits (1.3e11 rows: 5 TB of float32 input)
     return B / so3::kUnitRows;
 }
 
