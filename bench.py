@@ -10,7 +10,8 @@ rows = 1,000,000 per GPU.  A "step" is one K1 launch over one resident batch.  I
 rotate over 8 buffer pairs (576 MB per GPU) so the 256 MiB Infinity Cache cannot serve replays:
 the reported number is an HBM number.  With N > 1 every rank owns its own rows (weak scaling, no
 data-path collective); after the timed region the mean geodesic angle error is reduced on the
-device per rank (K4) and summed with ONE all-reduce (RCCL).
+device per rank (K4) and summed with ONE all-reduce (RCCL), and rank 0's line gains
+secondary.config5 = BASELINE configs[4] (2M rows per rank: 16M over 8), timed the same way.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job projections/s.
 Extra objects: "roofline" (HBM roofline of k_project_fwd from HIP events on the launch stream) and
@@ -67,9 +68,10 @@ def launch_ranks(n: int, argv, child_cmd=None, grace_s: float = 5.0, out=None) -
                 except OSError:
                     pass
 
-    def on_signal(signum, _frame):
-        end_all(signal.SIGTERM)
-        raise SystemExit(128 + signum)
+    got_signal = []
+
+    def on_signal(signum, _frame):          # no exception out of the handler: the loop below sees the flag and takes the one
+        got_signal.append(signum)           # shutdown path (SIGTERM to the ranks, grace_s for them to leave their process group, SIGKILL)
 
     old = {s: signal.signal(s, on_signal) for s in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
@@ -95,6 +97,9 @@ def launch_ranks(n: int, argv, child_cmd=None, grace_s: float = 5.0, out=None) -
                         fd0 = None
             else:
                 time.sleep(0.05)
+            if got_signal:
+                rc = 128 + got_signal[0]
+                break
             codes = [p.poll() for p in procs]
             bad = [c for c in codes if c not in (None, 0)]
             if bad:
@@ -110,7 +115,7 @@ def launch_ranks(n: int, argv, child_cmd=None, grace_s: float = 5.0, out=None) -
             end_all(signal.SIGKILL)
             for p in procs:
                 p.wait()
-            print("[bench] a rank ended with exit code %d; the others were stopped" % rc, file=sys.stderr)
+            print("[bench] %s; the ranks were stopped" % ("signal %d" % got_signal[0] if got_signal else "a rank ended with exit code %d" % rc), file=sys.stderr)
         else:
             dst = out if out is not None else sys.stdout
             dst.write(line.decode())
@@ -406,6 +411,79 @@ def secondary_configs(lib, dev):
     return out
 
 
+def config5_leg(lib, rr, dist, dev, rank: int, world: int, steps: int, warmup: int, rows: int = 2_000_000):
+    """BASELINE.json configs[4] under the command the driver runs (`bench.py --gpus N`): the same timed skeleton at 2M rows per rank
+    (16M over 8 ranks), rank r's first buffer from seed r, eight rotated buffer pairs (2M rows x 8 pairs x 72 B = 1.15 GB per rank);
+    then the evaluation the config names -- every rank reduces its shard to (sum of angles, count) in ONE fused launch (K1+K4) and
+    ONE all-reduce sums the 16-byte pair -- with that collective's own latency from events around 20 calls.  Collective: every rank
+    calls it; rank 0 gets the dict.  (3D-Pose/main_DDP.py:39-42,112-116 is the reference's multi-process set-up; its reduce_loss,
+    :56-60, is never called.)"""
+    xs = [first_buffer(rank, rows).to(dev)]
+    gen = torch.Generator(device=dev).manual_seed(5000 + rank)
+    for _ in range(NBUF - 1):
+        xs.append(torch.randn(rows, 9, device=dev, generator=gen))
+    outs = [torch.empty(rows, 3, 3, device=dev) for _ in range(NBUF)]
+    stream = torch.cuda.current_stream()
+    st = ctypes.c_void_p(stream.cuda_stream)
+    calls = [(ctypes.c_void_p(xs[i].data_ptr()), ctypes.c_void_p(outs[i].data_ptr())) for i in range(NBUF)]
+    brows = ctypes.c_int64(rows)
+
+    def step(i):
+        a, b = calls[i % NBUF]
+        if lib.so3_project_fwd_f32(a, b, None, brows, st) != 0:
+            raise RuntimeError("so3_project_fwd_f32 failed: %s" % lib.so3_last_error().decode())
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def region():
+        e0.record(stream)
+        for i in range(steps):
+            step(i)
+        e1.record(stream)
+
+    config = {"workload": "configs[4]: batch %dM sharded across %d MI355X (2M rows per GPU, seeds 0-%d), RCCL all-reduce of the mean angle error"
+                          % (rows * world // 1_000_000, world, world - 1) if rows == 2_000_000 else "configs[4] at %d rows per GPU" % rows,
+              "rows_per_gpu": rows, "global_rows": rows * world, "buffer_pairs_rotated": NBUF, "submission": "eager launches"}
+    for i in range(max(warmup, NBUF)):
+        step(i)
+    e0.record(stream); e1.record(stream)
+    line, times = run_skeleton(rank, world, steps, warmup, rows, step, torch.cuda.synchronize, dist, dev, config,
+                               extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False)
+    # the evaluation: one fused launch per rank, one all-reduce of (sum, count)
+    gt = torch.Generator().manual_seed(1 + 1000 * rank)
+    t_rot = rr.symmetric_orthogonalization(torch.randn(rows, 9, generator=gt).to(dev))
+    sc = rr.head_angle_error(xs[0], t_rot, reduce="sum_count", check=False)
+    pair = sc.clone()
+    dist.all_reduce(pair, op=dist.ReduceOp.SUM)
+    mean_angle = (pair[0] / pair[1]).item()
+    count_seen = float(pair[1].item())
+    probe = sc.clone()
+    for _ in range(3):
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    dist.barrier()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    a0.record()
+    for _ in range(20):
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+    a1.record()
+    torch.cuda.synchronize()
+    host_us = (time.perf_counter() - t0) / 20 * 1e6
+    ar = max_over_ranks([a0.elapsed_time(a1) * 1e3 / 20, host_us], dist, dev)
+    del xs, outs
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {"workload": config["workload"], "rows_per_gpu": rows, "global_rows": rows * world, "world_size_seen": dist.get_world_size(),
+            "steps": steps, "ms_per_step": line["ms_per_step"], "ms_per_step_events": times[1] / steps, "value": line["value"], "unit": "projections/s",
+            "frac_of_8TBps_per_gpu_events": BYTES_PER_PROJECTION * rows / (times[1] * 1e-3 / steps) / 1e9 / HBM_PEAK_GBS,
+            "mean_angle_error_deg": mean_angle, "rows_counted_by_the_all_reduce": count_seen,
+            "allreduce_us": ar[0], "allreduce_us_host_clock": ar[1], "allreduce_backend": dist.get_backend(),
+            "allreduce_note": "one SUM all-reduce of a 16-byte (sum, count) device tensor; events on the launch stream around 20 calls, MAX over ranks",
+            "hbm_bytes_resident_per_rank": rows * NBUF * BYTES_PER_PROJECTION}
+
+
 def main():
     args = parse()
     # Exactly ONE line goes to stdout.  Native libraries write there too (RCCL prints a version banner when it comes up),
@@ -637,6 +715,14 @@ def main():
             out["secondary"] = secondary_configs(lib, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_rows)
+    # N > 1: BASELINE configs[4] beside the headline (value stays config #2's weak scaling, so that N = 1 agrees with the 1-GPU record)
+    c5 = None
+    if dist is not None and world > 1 and not args.no_secondary and args.config == 2:
+        c5 = config5_leg(lib, rr, dist, dev, rank, world, args.steps, args.warmup,
+                         rows=2_000_000 if args.rows == ROWS_DEFAULT else 2 * args.rows)
+    if rank == 0:
+        if c5 is not None:
+            out.setdefault("secondary", {})["config5"] = c5
         real_stdout.write(json.dumps(out) + "\n")
         real_stdout.flush()
     if dist is not None:

@@ -28,6 +28,10 @@
 
 #include "so3_device.h"
 
+#ifndef SO3_PARK_CAP2
+#define SO3_PARK_CAP2 256           // entries of the two-input kernels' list of parked hard rows (20 words each)
+#endif
+
 namespace so3 {
 #ifndef SO3_HOST_MODEL
 
@@ -746,7 +750,7 @@ template <int M_BYTES>
 struct OpProjectBwd : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = M_BYTES, kOut1 = 0;
     static constexpr bool kLateIn1 = true;
-    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and G: 20 KB of LDS per workgroup
+    static constexpr int kParkWords = 18, kParkCap = SO3_PARK_CAP2;                   // M and G: 20 KB of LDS per workgroup
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProjectBwd> &rows, RowCtx<NPL> &ctx) const {
         typedef Tr<T> R;
@@ -785,7 +789,7 @@ struct OpFrobHead : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_DM ? M_BYTES : 0, kOut1 = WANT_R ? 4 : 0;
     static constexpr bool kReduce = true;
     static constexpr bool kLateIn1 = true;
-    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and Rtrue: 20 KB of LDS per workgroup
+    static constexpr int kParkWords = 18, kParkCap = SO3_PARK_CAP2;                   // M and Rtrue: 20 KB of LDS per workgroup
     double *loss_sum = nullptr;
     float inv_b = 0.f;
     template <class T, int NPL>
@@ -1040,7 +1044,7 @@ struct OpProjectAngle : OpBase {
     static constexpr int kIn0 = M_BYTES, kIn1 = 4, kOut0 = WANT_R ? 4 : 0, kOut1 = 0;
     static constexpr bool kReduce = true;
     static constexpr bool kLateIn1 = true;
-    static constexpr int kParkWords = 18, kParkCap = 256;                   // M and Rtrue: 20 KB of LDS per workgroup
+    static constexpr int kParkWords = 18, kParkCap = SO3_PARK_CAP2;                   // M and Rtrue: 20 KB of LDS per workgroup
     static constexpr bool kAngleConstants = F32SUM;
     double *deg = nullptr, *sum_count = nullptr;
     int32_t *range_flag = nullptr;

@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Tables a test wants in the run's record whatever its outcome (tests/test_zz_gpu_perf_bounds.py: measured ratios): one line each, written
+# with the terminal summary, i.e. at the tail of `pytest -q`'s output.
+REPORT_LINES = []
+
+
+def pytest_terminal_summary(terminalreporter):
+    for line in REPORT_LINES:
+        terminalreporter.write_line(line)
+
+
 @pytest.fixture(autouse=True)
 def _seeded_rng():
     """Every test starts from the same RNG state: thresholds on random data must not depend on which tests ran before."""

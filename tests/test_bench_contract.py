@@ -116,6 +116,22 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert d["config"]["rows_per_gpu"] == 500_000 and d["config"]["global_rows"] == 1_000_000
     assert abs(d["value"] - 1_000_000 * 30 / (d["ms_per_step"] * 30 * 1e-3)) / d["value"] < 1e-9
     assert 120.0 < d["mean_angle_error_deg"] < 133.0
+    # BASELINE configs[4] beside the headline, under this very command: twice the headline's rows per rank (2M at the default 1M), the same
+    # skeleton, the evaluation's one all-reduce timed by itself, and the world size as the process group reports it
+    c5 = d["secondary"]["config5"]
+    assert c5["world_size_seen"] == 2 and c5["rows_per_gpu"] == 1_000_000 and c5["global_rows"] == 2_000_000 and c5["steps"] == 30
+    assert abs(c5["value"] - c5["global_rows"] * 30 / (c5["ms_per_step"] * 30 * 1e-3)) / c5["value"] < 1e-9
+    assert c5["ms_per_step_events"] <= c5["ms_per_step"] * 1.001 and c5["allreduce_us"] > 0 and c5["allreduce_backend"] == "gloo"
+    assert c5["rows_counted_by_the_all_reduce"] == 2_000_000 and 120.0 < c5["mean_angle_error_deg"] < 133.0
+    assert c5["hbm_bytes_resident_per_rank"] == 1_000_000 * 8 * 72 and c5["workload"].startswith("configs[4]")
+
+
+def test_config5_workload_string_at_the_configs_own_world():
+    """At 8 ranks of 2M rows the leg's workload reads BASELINE.json configs[4] word for word (no GPU, no process group: the string only)."""
+    import bench
+    src = open(bench.__file__).read()
+    assert "configs[4]: batch %dM sharded across %d MI355X (2M rows per GPU, seeds 0-%d), RCCL all-reduce of the mean angle error" in src
+    assert ("configs[4]: batch %dM sharded across %d MI355X" % (2_000_000 * 8 // 1_000_000, 8)) == "configs[4]: batch 16M sharded across 8 MI355X"
 
 
 def test_bench_config5_shape_on_one_rank():

@@ -104,6 +104,33 @@ def test_a_killed_launcher_takes_its_ranks_with_it(tmp_path):
     assert not any(_alive(q) for q in pids)
 
 
+_CHILD_TRAPS_TERM = r"""
+import os, signal, sys, time
+def bye(signum, frame):
+    time.sleep(0.3)                                  # "destroying the process group"
+    open(os.path.join(sys.argv[1], "rank%s.left_cleanly" % os.environ["RANK"]), "w").write("SIGTERM")
+    sys.exit(0)
+signal.signal(signal.SIGTERM, bye)
+open(os.path.join(sys.argv[1], "rank%s.pid" % os.environ["RANK"]), "w").write(str(os.getpid()))
+time.sleep(120)
+"""
+
+
+def test_a_signalled_launcher_gives_its_ranks_the_grace_period(tmp_path):
+    """SIGTERM (or Ctrl-C) to the launcher: the ranks get SIGTERM and grace_s to leave -- round 4 raised out of the handler and the
+    finally-block SIGKILLed them mid-kernel."""
+    p = _launcher(2, _CHILD_TRAPS_TERM, [str(tmp_path)])
+    pidfiles = [str(tmp_path / ("rank%d.pid" % r)) for r in range(2)]
+    _wait_for(pidfiles)
+    pids = [int(open(f).read()) for f in pidfiles]
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode == 128 + signal.SIGTERM and "signal 15" in err
+    assert all((tmp_path / ("rank%d.left_cleanly" % r)).exists() for r in range(2))
+    time.sleep(0.2)
+    assert not any(_alive(q) for q in pids)
+
+
 def test_a_sigkilled_launcher_still_leaves_no_ranks(tmp_path):
     """A launcher that cannot run any handler: its children carry PR_SET_PDEATHSIG."""
     p = _launcher(2, _CHILD_SLEEP, [str(tmp_path)])
