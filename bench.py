@@ -315,7 +315,7 @@ def secondary_configs(lib, dev):
     r4 = torch.empty(b, 9, device=dev)
     d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
     ls = torch.empty(1, dtype=torch.float64, device=dev)
-    us = timed(lambda i: lib.so3_frob_fwd_bwd_bf16(P(x4.data_ptr()), P(t4.data_ptr()), P(r4.data_ptr()), P(d4.data_ptr()), P(ls.data_ptr()), b, st), 300, 10)
+    us = timed(lambda i: lib.so3_frob_fwd_bwd_v2_bf16(P(x4.data_ptr()), P(t4.data_ptr()), P(r4.data_ptr()), P(d4.data_ptr()), P(ls.data_ptr()), None, None, 0, b, st), 300, 10)
     out["config4_head_loss_backward_b512_bf16"] = {"us_per_fused_call": us, "note": "launch-latency-bound (9 KB); ONE launch (the one-workgroup kernel writes the loss itself)"}
     # the same step as a user calls it: through the Python mirror with autograd, and as a recorded hipGraph step
     from poseestimation_amd import rotation_representation as rr

@@ -1,7 +1,7 @@
 /* c_abi_demo.c -- libso3proj.so from plain C: no Python, no torch.
  *
  * Projects a batch of 3x3 matrices onto SO(3) (so3_project_fwd_f32), measures the geodesic angle to a second batch
- * (so3_angle_error with the fused (sum, count) reduction) and checks on the host that every output is a rotation.
+ * (so3_angle_error_v2 with the fused (sum, count) reduction) and checks on the host that every output is a rotation.
  *
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_demo.c -Lposeestimation_amd -lso3proj \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,$PWD/poseestimation_amd -Wl,-rpath,/opt/rocm/lib -o c_abi_demo
@@ -47,10 +47,14 @@ int main(int argc, char **argv) {
     HIP_OK(hipMemcpyAsync(dM, hM, bytes, hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(dT, hT, bytes, hipMemcpyHostToDevice, stream));
 
+    if (so3_version() != SO3PROJ_VERSION) {                         /* argument lists changed between versions without new names for every symbol */
+        fprintf(stderr, "libso3proj.so is version %d, this program was compiled against %d\n", so3_version(), SO3PROJ_VERSION);
+        return 4;
+    }
     printf("libso3proj version %d, %lld rows\n", so3_version(), (long long)B);
     SO3_OK(so3_project_fwd_f32(dM, dR, dflip, B, stream));          /* R = proj(M), flip = det(M) < 0 */
     SO3_OK(so3_project_fwd_f32(dT, dTR, NULL, B, stream));          /* a second batch of rotations */
-    SO3_OK(so3_angle_error(dR, dTR, NULL, dsum, dflag, 0, B, stream));
+    SO3_OK(so3_angle_error_v2(dR, dTR, NULL, dsum, dflag, NULL, 0u, B, stream));   /* degrees; no workspace: the call zeroes (sum, count) itself */
 
     double sum_count[2];
     int32_t flag;

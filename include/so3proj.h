@@ -34,10 +34,13 @@
 extern "C" {
 #endif
 
-#define SO3PROJ_VERSION 100          /* 0.1.0 */
+#define SO3PROJ_VERSION 200          /* 0.2.0: the reducing entry points exist once (*_v2: workspace nullable, a flags word), the float64 ones
+                                        included (so3_angle_error_v2_f64, so3_frob_loss_v2_f64: round 4 had changed their arguments under the old
+                                        names); so3_angle_stats's workspace is zero-filled once by the caller.  A binding checks so3_version(). */
 #define SO3_ERR_INVALID (-1)
 
-/* Library version (SO3PROJ_VERSION the library was built with). */
+/* Library version (SO3PROJ_VERSION the library was built with).  A caller compiled against another version of this header must not
+ * call the library: argument lists changed between 100 and 200 without new symbol names for every function. */
 int so3_version(void);
 
 /* Thread-local description of the last non-zero return on this thread ("" if none). */
@@ -78,8 +81,7 @@ int so3_project_bwd_f64(const double *M, const double *G, double *dM, int64_t B,
 
 /* ---- the reducing entry points: K3, K3', K4, K1+K4 ----------------------------------------------------------------
  * Each reduces over the batch (loss_sum; sum_count, range_flag) and exists ONCE; how the reduction is finished is chosen by
- * `workspace` and `flags` (round 3 exported three spellings of each -- plain, _ws, _acc; they are inline wrappers at the end of
- * this header now):
+ * `workspace` and `flags`:
  *   workspace  NULL, or so3_reduce_workspace_bytes() bytes of device memory owned by the caller, ZERO-FILLED ONCE before its
  *              first use (every call leaves it zeroed), used by ONE stream at a time.  With it every workgroup parks its
  *              partial in a slot of its own and the last one to finish (a ticket) sums the slots in a fixed order and writes
@@ -166,15 +168,15 @@ int so3_scale_bf16(const void *src, const float *factor, void *dst, int64_t n, v
 
 /* float64 arguments (the reference's metric and loss functions accept double tensors; rotation_representation.py:232-233 even
  * casts to double itself): the same quantities from float64 data in float64 arithmetic, one row per thread and trip.
- * so3_geodesic_f64 returns float64 radians, so3_frob_loss_f64's dRpred and loss_mean are float64 (loss_mean = loss_sum / B),
+ * so3_geodesic_f64 returns float64 radians, so3_frob_loss_v2_f64's dRpred and loss_mean are float64 (loss_mean = loss_sum / B),
  * everything else as in the float32 functions.  `workspace` (nullable) as for the float32 reductions: with it -- and for any batch
  * of <= 1024 rows -- a call is ONE launch whose last workgroup writes sum, count, flag / loss and mean; without it the
- * accumulators are zeroed by a launch in front of the kernel (and the mean written by one behind it). */
-int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                        void *workspace, int64_t B, void *stream);
+ * accumulators are zeroed by a launch in front of the kernel (and the mean written by one behind it).  flags: SO3_RADIANS. */
+int so3_angle_error_v2_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, void *workspace,
+                           unsigned flags, int64_t B, void *stream);
 int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t B, void *stream);
-int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace,
-                      int64_t B, void *stream);
+int so3_frob_loss_v2_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace,
+                         unsigned flags, int64_t B, void *stream);
 
 /* Float32 radians variant: tr(m1 m2^T), hard clamp to [-1,1], no range check.
  * Replaces rotation_representation.py:209-227 (compute_geodesic_distance_from_two_matrices; copy at
@@ -283,10 +285,11 @@ int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const floa
  *   stats     out ncls x 8 doubles: count, mean, std (population, as np.std), max, median (EXACT: radix select
  *                 on the float64 bits, the two middle elements averaged as np.median does), acc<30, acc<15, acc<7.5
  *   workspace     caller-owned scratch of so3_angle_stats_workspace_bytes() bytes (~10 MB: histograms and a buffer for the
- *                 candidates of the medians; contents undefined before/after)
+ *                 candidates of the medians), ZERO-FILLED ONCE before its first use -- every call leaves it zeroed --, used by ONE
+ *                 stream at a time (re-zero it after a call that returned an error)
  * ncls <= 64.  A class containing a NaN angle reports NaN for mean/std/max/median, as numpy does.
- * Four launches (a zero kernel, a histogram pass, a pass that compacts the rows of the medians' 1/16-octave bins, one workgroup
- * per class to select among them): two passes over the rows; 45 us per 1M angles in 10 classes.
+ * Two launches, two passes over the rows: a histogram pass, and a pass that compacts the rows of the medians' 1/16-octave bins and
+ * then, one workgroup per class behind a ticket, selects among them.
  */
 size_t so3_angle_stats_workspace_bytes(void);
 int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double *stats, void *workspace,
@@ -317,60 +320,6 @@ int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B
 int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream);
 int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t seed, float *R, float *H,
                          int64_t B, int32_t N, void *stream);
-
-/* ---- round-3 spellings of the reducing entry points, kept for one round as inline wrappers (not exported) -----------------
- * plain: the call zeroes the accumulators itself; _ws: caller-owned workspace and the kernel-written mean; _acc: accumulators the
- * caller has zeroed.  New code calls the *_v2 functions above. */
-#ifndef SO3_NO_LEGACY_WRAPPERS
-static inline int so3_frob_fwd_bwd_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, int64_t B, void *stream) {
-    return so3_frob_fwd_bwd_v2_f32(M, Rtrue, R, dM, loss_sum, NULL, NULL, 0u, B, stream);
-}
-static inline int so3_frob_fwd_bwd_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, int64_t B, void *stream) {
-    return so3_frob_fwd_bwd_v2_bf16(M, Rtrue, R, dM, loss_sum, NULL, NULL, 0u, B, stream);
-}
-static inline int so3_frob_fwd_bwd_ws_f32(const float *M, const float *Rtrue, float *R, float *dM, double *loss_sum, float *loss_mean,
-                                          void *workspace, int64_t B, void *stream) {
-    return so3_frob_fwd_bwd_v2_f32(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, 0u, B, stream);
-}
-static inline int so3_frob_fwd_bwd_ws_bf16(const void *M, const float *Rtrue, float *R, void *dM, double *loss_sum, float *loss_mean,
-                                           void *workspace, int64_t B, void *stream) {
-    return so3_frob_fwd_bwd_v2_bf16(M, Rtrue, R, dM, loss_sum, loss_mean, workspace, 0u, B, stream);
-}
-static inline int so3_frob_loss_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, int64_t B, void *stream) {
-    return so3_frob_loss_v2_f32(Rpred, Rtrue, dRpred, loss_sum, NULL, NULL, 0u, B, stream);
-}
-static inline int so3_frob_loss_ws_f32(const float *Rpred, const float *Rtrue, float *dRpred, double *loss_sum, float *loss_mean,
-                                       void *workspace, int64_t B, void *stream) {
-    return so3_frob_loss_v2_f32(Rpred, Rtrue, dRpred, loss_sum, loss_mean, workspace, 0u, B, stream);
-}
-static inline int so3_angle_error(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                                  int64_t B, void *stream) {
-    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, NULL, radians ? SO3_RADIANS : 0u, B, stream);
-}
-static inline int so3_angle_error_ws(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                                     void *workspace, int64_t B, void *stream) {
-    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, workspace, radians ? SO3_RADIANS : 0u, B, stream);
-}
-static inline int so3_angle_error_acc(const float *R1, const float *R2, double *deg, double *sum_count, int32_t *range_flag, int radians,
-                                      int64_t B, void *stream) {
-    return so3_angle_error_v2(R1, R2, deg, sum_count, range_flag, NULL, (radians ? SO3_RADIANS : 0u) | SO3_PREZEROED, B, stream);
-}
-/* (the round-3 fused evaluation was float64 on every row: the wrappers keep that) */
-static inline int so3_project_angle_error_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                              int32_t *range_flag, int radians, int64_t B, void *stream) {
-    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, NULL, (radians ? SO3_RADIANS : 0u) | SO3_EXACT_F64, B, stream);
-}
-static inline int so3_project_angle_error_ws_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                                 int32_t *range_flag, int radians, void *workspace, int64_t B, void *stream) {
-    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, workspace, (radians ? SO3_RADIANS : 0u) | SO3_EXACT_F64, B,
-                                          stream);
-}
-static inline int so3_project_angle_error_acc_f32(const float *M, const float *Rtrue, float *R, double *deg, double *sum_count,
-                                                  int32_t *range_flag, int radians, int64_t B, void *stream) {
-    return so3_project_angle_error_v2_f32(M, Rtrue, R, deg, sum_count, range_flag, NULL,
-                                          (radians ? SO3_RADIANS : 0u) | SO3_PREZEROED | SO3_EXACT_F64, B, stream);
-}
-#endif /* SO3_NO_LEGACY_WRAPPERS */
 
 #ifdef __cplusplus
 }

@@ -33,9 +33,9 @@ SYMBOLS = {
     "so3_project_angle_error_v2_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_geodesic_eps_f32": (_INT, [_P, _P, _P, _P, _P, _INT, ctypes.c_float, _P, _I64, _P]),
-    "so3_angle_error_f64": (_INT, [_P, _P, _P, _P, _P, _INT, _P, _I64, _P]),
+    "so3_angle_error_v2_f64": (_INT, [_P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_geodesic_f64": (_INT, [_P, _P, _P, _I64, _P]),
-    "so3_frob_loss_f64": (_INT, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "so3_frob_loss_v2_f64": (_INT, [_P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_project_fwd_diag_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_scale_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_scale_bf16": (_INT, [_P, _P, _P, _I64, _P]),
@@ -57,34 +57,7 @@ SYMBOLS = {
     "so3_kabsch_synth_f32": (_INT, [_P, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _I64, _I32, _P]),
 }
 
-def _install_legacy(lib) -> None:
-    """The round-3 spellings of the reducing entry points -- `static inline` wrappers in include/so3proj.h, not exports -- as
-    attributes of the loaded library, argument for argument like the header's, so that scripts written against them keep
-    running for this round.  The mirror itself calls the *_v2 functions."""
-    rad = lambda r: RADIANS if r else 0
-    f32, bf16, loss, ang, pang = (lib.so3_frob_fwd_bwd_v2_f32, lib.so3_frob_fwd_bwd_v2_bf16, lib.so3_frob_loss_v2_f32, lib.so3_angle_error_v2,
-                                  lib.so3_project_angle_error_v2_f32)
-    legacy = {
-        "so3_frob_fwd_bwd_f32": lambda m, t, r, dm, ls, b, st: f32(m, t, r, dm, ls, None, None, 0, b, st),
-        "so3_frob_fwd_bwd_bf16": lambda m, t, r, dm, ls, b, st: bf16(m, t, r, dm, ls, None, None, 0, b, st),
-        "so3_frob_fwd_bwd_ws_f32": lambda m, t, r, dm, ls, lm, ws, b, st: f32(m, t, r, dm, ls, lm, ws, 0, b, st),
-        "so3_frob_fwd_bwd_ws_bf16": lambda m, t, r, dm, ls, lm, ws, b, st: bf16(m, t, r, dm, ls, lm, ws, 0, b, st),
-        "so3_frob_loss_f32": lambda p, t, g, ls, b, st: loss(p, t, g, ls, None, None, 0, b, st),
-        "so3_frob_loss_ws_f32": lambda p, t, g, ls, lm, ws, b, st: loss(p, t, g, ls, lm, ws, 0, b, st),
-        "so3_angle_error": lambda a, b_, d, sc, fl, r, b, st: ang(a, b_, d, sc, fl, None, rad(r), b, st),
-        "so3_angle_error_ws": lambda a, b_, d, sc, fl, r, ws, b, st: ang(a, b_, d, sc, fl, ws, rad(r), b, st),
-        "so3_angle_error_acc": lambda a, b_, d, sc, fl, r, b, st: ang(a, b_, d, sc, fl, None, rad(r) | PREZEROED, b, st),
-        "so3_project_angle_error_f32": lambda m, t, r_, d, sc, fl, r, b, st: pang(m, t, r_, d, sc, fl, None, rad(r) | EXACT_F64, b, st),
-        "so3_project_angle_error_ws_f32": lambda m, t, r_, d, sc, fl, r, ws, b, st: pang(m, t, r_, d, sc, fl, ws, rad(r) | EXACT_F64, b, st),
-        "so3_project_angle_error_acc_f32": lambda m, t, r_, d, sc, fl, r, b, st: pang(m, t, r_, d, sc, fl, None, rad(r) | PREZEROED | EXACT_F64, b, st),
-    }
-    for name, fn in legacy.items():
-        setattr(lib, name, fn)
-
-
-LEGACY_INLINE = ("so3_frob_fwd_bwd_f32", "so3_frob_fwd_bwd_bf16", "so3_frob_fwd_bwd_ws_f32", "so3_frob_fwd_bwd_ws_bf16", "so3_frob_loss_f32",
-                 "so3_frob_loss_ws_f32", "so3_angle_error", "so3_angle_error_ws", "so3_angle_error_acc", "so3_project_angle_error_f32",
-                 "so3_project_angle_error_ws_f32", "so3_project_angle_error_acc_f32")
+ABI_VERSION = 200                                 # include/so3proj.h: SO3PROJ_VERSION this binding's argument lists belong to
 
 _lock = threading.Lock()
 _lib = None
@@ -111,7 +84,10 @@ def load():
                 fn = getattr(lib, name)      # AttributeError here = header/library mismatch
                 fn.restype = res
                 fn.argtypes = args
-            _install_legacy(lib)
+            built = lib.so3_version()
+            if built != ABI_VERSION:      # a stale in-tree build: its argument lists are not the ones declared above
+                raise ImportError(f"{LIB_PATH} reports ABI version {built}, this binding was written for {ABI_VERSION}: "
+                                  "rebuild with `python -m poseestimation_amd.build --force`")
             _lib = lib
     return _lib
 

@@ -982,7 +982,7 @@ struct OpAngle : OpBase {
 // 1e-7 of round-off beyond 1e-4 rad there) the row takes the reference's float64 arithmetic as before, under a wave-uniform
 // branch (Haar-distributed pairs: one round of 128 rows in twelve) and per row: a row's contribution does not depend on its
 // wave-mates.  Outside that band a row's angle differs from the float64 one by at most 2e-7 / sin(theta) rad, without bias
-// (round-to-nearest), 3e-8 degrees in the mean of 1M Haar pairs.  The range test (cos outside [-1.1, 1.1]) runs on the float32 cosine.
+// (round-to-nearest), 3e-8 degrees in the mean of 1M Haar pairs.  The range test (cos outside [-1.1, 1.1]) runs on the float64 cosine, inside the band.
 // `skip`: rows that do not count here (the fast path's hard rows: their angle comes from the redo pass).
 template <class T, int NPL>
 __device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], typename Tr<T>::mask skip, RowCtx<NPL> &ctx) {
@@ -1006,15 +1006,13 @@ __device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], 
     // theta = pi/2 - r (small) | 2 r (c > 1/2) | pi - 2 r (c < -1/2): r times -1 / 2 / -2 here, the constants by count
     const typename R::mask neg = R::gt(R::splat(0.f), c);
     const T rm = r * R::sel(small, R::splat(-1.f), R::sel(neg, R::splat(-2.f), R::splat(2.f)));
-    const typename R::mask out = R::gt(ac, R::splat(1.1f));            // the reference's range test (rotation_representation.py:236-239)
-    const typename R::mask band = R::gt(ac, R::splat(0.9999995f));     // cosine within 5e-7 of +-1 (or clamped): float64 for this row
+    const typename R::mask band = R::gt(ac, R::splat(0.9999995f));     // cosine within 5e-7 of +-1 (or beyond): float64 for this row
     bool any_band = false;
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         if (!ctx.exists[k]) continue;                                   // wave-uniform: the phantom unit of an odd tail
         const bool counts = !R::lane_of(skip, k);
         ctx.acc += counts ? static_cast<double>(R::get(rm, k)) : 0.0;
-        ctx.flag |= counts && R::lane_of(out, k);
         ctx.n_half += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counts && R::lane_of(small, k)));
         ctx.n_pi += __builtin_popcountll(__builtin_amdgcn_ballot_w64(counts && !R::lane_of(small, k) && R::lane_of(neg, k)));
         any_band |= wave_any(counts && R::lane_of(band, k));
@@ -1025,7 +1023,11 @@ __device__ __forceinline__ void angle_sum_f32(const T (&a)[9], const T (&b)[9], 
             double t64 = 0.0;
 #pragma unroll
             for (int i = 0; i < 9; ++i) t64 = fma(static_cast<double>(R::get(a[i], k)), static_cast<double>(R::get(b[i], k)), t64);
-            const double c64 = fmin(fmax((t64 - 1.0) * 0.5, -1.0), 1.0);       // (a band row's cosine is finite)
+            const double c_raw = (t64 - 1.0) * 0.5;
+            // the reference's range test (rotation_representation.py:236-239), on the float64 cosine like the reference's: every row it can
+            // fire for lies inside the band (round 4 tested the float32 cosine: a row at 1.1 +- 1e-7 could raise or not raise differently)
+            if (ctx.exists[k] && R::lane_of(band, k) && !R::lane_of(skip, k)) ctx.flag |= (c_raw < -1.1 || c_raw > 1.1);
+            const double c64 = fmin(fmax(c_raw, -1.0), 1.0);                   // (a band row's cosine is finite)
             // what the row has contributed above is K + rm with K = 0 or pi: replace it by the float64 angle
             const double base = R::lane_of(neg, k) ? 3.14159265358979323846 : 0.0;
             const double corr = acos_f64(c64) - base - static_cast<double>(R::get(rm, k));

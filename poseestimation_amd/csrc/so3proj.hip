@@ -1203,8 +1203,7 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 
 // ---- next row f3: per-class evaluation statistics of K4's angles (3D-Pose/test_per_class.py:174-216) ----------
 // Count, mean, std, max, three accuracy thresholds and an EXACT median (the two middle elements averaged, as np.median) with TWO
-// passes over the rows (round 2 / 3: a radix select of eight launches, 8 bits each, every one a pass over all rows, a ticket and two
-// release fences per workgroup and launch: 152 us per 1M rows):
+// passes over the rows in TWO launches (rounds 2 / 3: a radix select of eight launches, 152 us per 1M rows; round 4: four launches, 41 us):
 //   1. k_stats_window (all rows): per class the sum, the sum of squares, the maximum, and a histogram of the angles over a WINDOW of
 //      512 bins -- the top 16 bits of the float64 pattern (non-negative doubles order like their bits): sixteen bins per octave from
 //      2^-23 to 2^9 degrees, one bin below and one above.  The thresholds 7.5, 15 and 30 are bin edges (1.875 x 2^k), so the three
@@ -1213,14 +1212,19 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 //      itself, from the L2-resident histograms); then the rows of those bins (1/16 octave: a few per cent of a class) are compacted:
 //      staged in LDS (a cursor: no global atomic, no barrier in the loop), grouped by class, and appended to the class's stretch of
 //      the candidate buffer -- the histogram says exactly how long each stretch is; one atomic per workgroup and class takes a share.
-//   3. k_stats_finish (one workgroup per class): the class's candidates -- a contiguous list -- go into LDS (when more than 16 384:
-//      after the first digit has thinned them out) and both middle elements are radix-selected at once on the remaining 48 bits;
-//      then the class's row of the result.
-// Launch boundaries order everything: no ticket, no fence (measured: the two release fences per workgroup were 4-9 us per launch,
-// three float64 LDS atomics per row 11 us, the histogram and its flush nothing; profiles/r04_angle_stats_experiments.txt).
+//      Then the workgroup draws a ticket, and workgroup c (c < ncls; further classes wrap around) FINISHES class c once every ticket
+//      is drawn: the class's candidates -- a contiguous list -- go into LDS (when more than 16 384: after the first digit has thinned
+//      them out), both middle elements are radix-selected at once on the remaining 48 bits, and the class's row of the result is
+//      written.  What crosses workgroups inside the launch -- the candidates -- is written with agent-scope stores (performed past the
+//      XCDs' L2s before the ticket is drawn: no release fence, which round 4 measured at 4-9 us per launch) and read with agent-scope
+//      loads.  The wait is bounded: a finishing workgroup whose launch-mates do not all arrive in time (they can only be queued behind
+//      another kernel: the finishers hold ncls of the device's CUs, not all) selects over the rows of its class themselves -- slow, never
+//      wrong, and no wave ever waits on a condition that cannot come.
+// The workspace is ZERO-FILLED ONCE by the caller and every call leaves it zeroed (the finishers clear what their class used): round
+// 4's zero-fill launch in front of every call is gone.
 // Exact for every input: an edge bin (zeros, denormals, angles above 512 degrees) is selected on all 64 bits, and if a workgroup's
 // staging overflows (more than 4096 of its rows inside the selected bins: e.g. a million equal angles) the finishing workgroups
-// select over the rows themselves (two sweeps, then from LDS) -- slow, never wrong.
+// select over the rows themselves (two sweeps, then from LDS).
 constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
 constexpr int kMaxClasses = 64;
 constexpr int kWinBase = 0x3E80;                   // (bits >> 48) of 2^-23
@@ -1229,17 +1233,14 @@ constexpr int kHistBins = kWinBins + 2;            // [0]: below the window, [kH
 constexpr unsigned int kCandCap = 1u << 20;
 constexpr int kStatMaxWgs = 1024;
 constexpr int kStatLdsKeys = 16384;                // candidates of one class that k_stats_finish keeps in LDS (128 KB + 16 KB of tags)
-struct StatWork {                                  // layout of the caller's workspace; the call zeroes it up to the classes' histograms
+struct StatWork {                                  // layout of the caller's workspace: zero-filled once, left zeroed by every call (up to `hist` included)
     double acc[kMaxClasses][4];                    // sum, sumsq, max (bits), nan_count
-    unsigned int overflow, pad;
+    unsigned int overflow, ticket;                 // some collecting workgroup's staging overflowed; collecting workgroups that have published their candidates
+    unsigned int done, pad;                        // classes finished (the last one clears the three words)
     unsigned int class_cursor[kMaxClasses];        // k_stats_collect: how much of class c's stretch of the candidate buffer is taken
-    unsigned int hist[kMaxClasses][kHistBins];     // (zeroed up to here for the classes in use)
-    double count[kMaxClasses], below[3][kMaxClasses];      // rows of the class (NaN included), non-NaN rows below 30 / 15 / 7.5
-    int sel_bin[2][kMaxClasses];                   // the window bin of the lower / upper middle element (-1: empty class)
-    long long krem[2][kMaxClasses];                // its rank inside that bin
-    unsigned int cand_base[kMaxClasses], cand_count[kMaxClasses];   // class c's candidates: cand[base, base + count) -- the rows of its selected bins, counted by the histogram
+    unsigned int hist[kMaxClasses][kHistBins];
     unsigned char tag[kCandCap];                   // bit 0: counts for the lower middle element, bit 1: for the upper
-    unsigned long long cand[kCandCap];
+    unsigned long long cand[kCandCap];             // class c's candidates: the rows of its selected bins, in a stretch whose place and length the histogram gives
 };
 constexpr unsigned int kStatRegion = 4096;         // candidates one workgroup of k_stats_collect can stage in LDS (48 KB)
 static_assert(kStatRegion * 256u <= kCandCap, "what 256 workgroups can stage fits the buffer");
@@ -1261,9 +1262,9 @@ template <class F>
 __device__ __forceinline__ void stats_rows(const double *__restrict__ deg, const int32_t *__restrict__ cls, int64_t B, int mode, F &&body) {
     const int64_t head = mode == 1 ? 1 : 0;
     const int64_t pairs = B > head ? (B - head) / 2 : 0;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kStatBlock + threadIdx.x; i < pairs; i += static_cast<int64_t>(gridDim.x) * kStatBlock) {
-        double2 a;
-        int2 c = make_int2(0, 0);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kStatBlock;
+    auto fetch = [&](int64_t i, double2 &a, int2 &c) {
+        c = make_int2(0, 0);
         if (mode == 2) {
             a.x = deg[2 * i]; a.y = deg[2 * i + 1];
             if (cls) { c.x = cls[2 * i]; c.y = cls[2 * i + 1]; }
@@ -1271,18 +1272,23 @@ __device__ __forceinline__ void stats_rows(const double *__restrict__ deg, const
             a = reinterpret_cast<const double2 *>(deg + head)[i];
             if (cls) c = reinterpret_cast<const int2 *>(cls + head)[i];
         }
-        body(a.x, c.x);
-        body(a.y, c.y);
+    };
+    // two trips' loads in flight per thread: a million rows are two trips of the grid, and one at a time the second trip's loads waited
+    // for the first one's LDS atomics (the launch is a few microseconds long: a memory round trip is a quarter of it)
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kStatBlock + threadIdx.x; i < pairs; i += 2 * stride) {
+        double2 a0, a1 = make_double2(0.0, 0.0);
+        int2 c0, c1 = make_int2(-1, -1);
+        const bool second = i + stride < pairs;
+        fetch(i, a0, c0);
+        if (second) fetch(i + stride, a1, c1);
+        body(a0.x, c0.x);
+        body(a0.y, c0.y);
+        if (second) { body(a1.x, c1.x); body(a1.y, c1.y); }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (head == 1 && B > 0) body(deg[0], cls ? cls[0] : 0);
         if (B > head && ((B - head) & 1)) body(deg[B - 1], cls ? cls[B - 1] : 0);
     }
-}
-
-__global__ __launch_bounds__(kStatBlock) void k_stats_zero(unsigned int *p, unsigned int n) {
-    const unsigned int i = blockIdx.x * kStatBlock + threadIdx.x;
-    if (i < n) p[i] = 0u;
 }
 
 // LCLS = how many classes the workgroup's histograms hold: 16 (33 KB of counters) or all 64 the interface allows (132 KB of the CU's
@@ -1327,10 +1333,18 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_window(const double *__res
     }
 }
 
-// A wave per (selection, class): the bin holding the middle element and its rank inside the bin; the counts that are sums over
-// bins.  Runs as the prologue of EVERY workgroup of k_stats_collect (a launch of its own cost 4.8 us for 2 us of work: the
-// histograms are 20 KB per ten classes, L2-resident); every workgroup keeps the bins in LDS, workgroup 0 also writes the workspace.
-__device__ __forceinline__ void stats_select(int ncls, StatWork *w, int (*sbin)[kMaxClasses], bool publish) {
+// What every workgroup of k_stats_collect derives for itself from the histograms (20 KB per ten classes, L2-resident): per class the
+// window bins of the lower / upper middle element and the rank inside, the counts that are sums over bins, the class's stretch of
+// the candidate buffer.
+struct StatSel {
+    int bin[2][kMaxClasses];                       // the window bin of the lower / upper middle element (-1: empty class)
+    long long krem[2][kMaxClasses];                // its rank inside that bin
+    double count[kMaxClasses];                     // rows of the class (NaN included)
+    unsigned int below[3][kMaxClasses];            // non-NaN rows below 30 / 15 / 7.5
+    unsigned int base[kMaxClasses], total[kMaxClasses];   // class c's candidates: cand[base, base + total)
+};
+// A wave per (selection, class).
+__device__ __forceinline__ void stats_select(int ncls, const StatWork *w, StatSel &sel) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int kPerLane = (kHistBins + 63) / 64;                         // 9 bins per lane
     for (int pair = wave; pair < 2 * ncls; pair += kStatBlock / 64) {
@@ -1357,114 +1371,57 @@ __device__ __forceinline__ void stats_select(int ncls, StatWork *w, int (*sbin)[
             long long kk = k - before;
             int d = 0;
             for (; d < kPerLane - 1; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; }
-            sbin[t][c] = kPerLane * lane + d;
-            if (publish) { w->sel_bin[t][c] = kPerLane * lane + d; w->krem[t][c] = kk; }
+            sel.bin[t][c] = kPerLane * lane + d;
+            sel.krem[t][c] = kk;
         }
-        if (n <= 0 && lane == 0) {
-            sbin[t][c] = -1;
-            if (publish) { w->sel_bin[t][c] = -1; w->krem[t][c] = 0; }
-        }
-        if (t == 0 && publish) {
+        if (n <= 0 && lane == 0) { sel.bin[t][c] = -1; sel.krem[t][c] = 0; }
+        if (t == 0) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { b30 += __shfl_xor(b30, off, 64); b15 += __shfl_xor(b15, off, 64); b7 += __shfl_xor(b7, off, 64); }
             if (lane == 0) {
-                w->count[c] = static_cast<double>(n) + w->acc[c][3];
-                w->below[0][c] = b30; w->below[1][c] = b15; w->below[2][c] = b7;
+                sel.count[c] = static_cast<double>(n) + w->acc[c][3];
+                sel.below[0][c] = b30; sel.below[1][c] = b15; sel.below[2][c] = b7;
             }
         }
     }
 }
 
-// The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
-// counting sort in LDS -- and appended to the class's stretch of the candidate buffer.  The stretches are exact: the histogram says how
-// many rows each class has in its selected bins, every workgroup derives the same offsets from it, and a workgroup takes its share of
-// a stretch with ONE atomic per class it holds; a finishing workgroup then reads a contiguous list (round 4's first build gave every
-// workgroup a region of its own and a table of (start, count) per class: the finishing workgroup found entry i by bisection over 256
-// prefix sums -- with one class of a million rows, 44 000 entries, two sweeps of 18 us each).
-__global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
-                                                              int64_t B, int mode) {
-    __shared__ unsigned long long skey[kStatRegion];
-    __shared__ unsigned short stag[kStatRegion];
-    __shared__ int sbin[2][kMaxClasses];
-    __shared__ unsigned int ccount[kMaxClasses], cstart[kMaxClasses], ccur[kMaxClasses], cbase[kMaxClasses], gbase[kMaxClasses];
-    __shared__ unsigned int cur;
-    stats_select(ncls, w, sbin, blockIdx.x == 0);
-    for (int i = threadIdx.x; i < ncls; i += kStatBlock) ccount[i] = 0;
-    if (threadIdx.x == 0) cur = 0;
-    __syncthreads();
-    if (threadIdx.x < static_cast<unsigned>(ncls)) {                  // how many candidates class c has in all: the rows of its one or two selected bins
-        const int c = threadIdx.x, b0 = sbin[0][c], b1 = sbin[1][c];
-        cbase[c] = (b0 >= 0 ? w->hist[c][b0] : 0u) + (b1 >= 0 && b1 != b0 ? w->hist[c][b1] : 0u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int at = 0;
-        for (int c = 0; c < ncls; ++c) {
-            const unsigned int k = cbase[c];
-            if (blockIdx.x == 0) { w->cand_base[c] = at; w->cand_count[c] = k; }
-            cbase[c] = at;
-            at = at + k < at ? 0xFFFFFFFFu : at + k;                    // (saturating: beyond the buffer nothing is written anyway)
-        }
-    }
-    stats_rows(deg, cls, B, mode, [&](double a, int c) {
-        if (c < 0 || c >= ncls || a != a) return;
-        const unsigned long long key = angle_key(a);
-        const int bin = window_bin(key);
-        const unsigned int t0 = bin == sbin[0][c] ? 1u : 0u, t1 = bin == sbin[1][c] ? 1u : 0u;
-        if (t0 | t1) {
-            const unsigned int at = atomicAdd(&cur, 1u);
-            if (at < kStatRegion) { skey[at] = key; stag[at] = static_cast<unsigned short>(c | t0 << 8 | t1 << 9); }
-        }
-    });
-    __syncthreads();
-    const unsigned int n = cur < kStatRegion ? cur : kStatRegion;
-    if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);     // (the finishing workgroups then select over the rows themselves)
-    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) atomicAdd(&ccount[stag[i] & 0xFF], 1u);
-    __syncthreads();
-    if (threadIdx.x < static_cast<unsigned>(ncls)) {
-        const int c = threadIdx.x;
-        gbase[c] = ccount[c] ? cbase[c] + atomicAdd(&w->class_cursor[c], ccount[c]) : 0u;
-    }
-    if (threadIdx.x == 0) {
-        unsigned int at = 0;
-        for (int c = 0; c < ncls; ++c) { cstart[c] = at; ccur[c] = at; at += ccount[c]; }
-    }
-    __syncthreads();
-    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) {
-        const int c = stag[i] & 0xFF;
-        const unsigned int at = gbase[c] + (atomicAdd(&ccur[c], 1u) - cstart[c]);
-        if (at < kCandCap) {                                            // (past the buffer only after some workgroup has overflowed)
-            w->cand[at] = skey[i];
-            w->tag[at] = static_cast<unsigned char>(stag[i] >> 8);
-        }
-    }
+// agent-scope accesses to the candidate buffer: written and read inside ONE launch by workgroups on different XCDs
+__device__ __forceinline__ void put_candidate(StatWork *w, unsigned int at, unsigned long long key, unsigned char tag) {
+    __hip_atomic_store(&w->cand[at], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&w->tag[at], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned long long get_candidate(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int get_tag(const unsigned char *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// One workgroup per class: the class's candidates (a contiguous stretch of the buffer; into LDS when they fit), both middle elements by
-// ONE radix select of 8-bit digits -- two (prefix, rank) states side by side, they part where the two elements differ -- then the
-// class's row of the result (np.mean / np.std / np.max / np.median / the thresholds).
-__global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__restrict__ deg, const int32_t *__restrict__ cls, StatWork *w, int64_t B,
-                                                             double *__restrict__ stats) {
-    __shared__ unsigned long long lkey[kStatLdsKeys];
-    __shared__ unsigned char ltag[kStatLdsKeys];
-    __shared__ unsigned int hh[2][256];
+constexpr unsigned int kStatSpins = 16384;         // x ~0.6 us: how long a finishing workgroup waits for its launch-mates' tickets before it helps itself
+
+// One class, by the whole workgroup: the class's candidates (a contiguous stretch of the buffer; into LDS when they fit), both middle
+// elements by ONE radix select of 8-bit digits -- two (prefix, rank) states side by side, they part where the two elements differ --
+// then the class's row of the result (np.mean / np.std / np.max / np.median / the thresholds), and the class's part of the workspace
+// back to zero.  `overflow`: the candidate buffer is not to be trusted (a staging overflow somewhere, or launch-mates that did not
+// arrive): select over the rows of the class themselves.
+__device__ __forceinline__ void stats_finish_class(int c, const double *__restrict__ deg, const int32_t *__restrict__ cls, StatWork *w, int64_t B,
+                                                   double *__restrict__ stats, const StatSel &sel, bool overflow_in, unsigned long long *lkey,
+                                                   unsigned char *ltag, unsigned int (*hh)[256]) {
     __shared__ unsigned long long s_prefix[2];
     __shared__ long long s_k[2];
-    const int c = blockIdx.x;
-    const double n = w->count[c], nan = w->acc[c][3], m = n - nan;
-    const int bins[2] = {w->sel_bin[0][c], w->sel_bin[1][c]};
-    const unsigned int total = w->cand_count[c];                        // the class's candidates
-    const unsigned long long *cand = w->cand + w->cand_base[c];
-    const unsigned char *ctag = w->tag + w->cand_base[c];
+    __shared__ unsigned int s_rem[2], s_cur, s_nsurv[2];
+    __shared__ unsigned long long s_surv[2][64];
+    const double n = sel.count[c], nan = w->acc[c][3], m = n - nan;
+    const int bins[2] = {sel.bin[0][c], sel.bin[1][c]};
+    const unsigned int total = sel.total[c];                            // the class's candidates
+    const unsigned long long *cand = w->cand + sel.base[c];
+    const unsigned char *ctag = w->tag + sel.base[c];
     // (a stretch that would leave the buffer can only belong to a call in which some workgroup overflowed; the flag is set then)
-    const bool overflow = w->overflow != 0u || static_cast<unsigned long long>(w->cand_base[c]) + total > kCandCap;
+    const bool overflow = overflow_in || static_cast<unsigned long long>(sel.base[c]) + total > kCandCap;
     constexpr int kAhead = 8;                                           // loads in flight per thread: the workgroup is alone on its CU
-    __shared__ unsigned int s_rem[2], s_cur;
     bool cached = m > 0 && !overflow && total <= static_cast<unsigned int>(kStatLdsKeys);      // (workgroup-uniform throughout)
     unsigned int held = total;                                                                // how many candidates LDS holds once cached
+    __syncthreads();                                                    // (LDS of the previous phase / class is free from here)
     if (cached) {
 #pragma unroll 4
-        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) { lkey[i] = cand[i]; ltag[i] = ctag[i]; }
+        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) { lkey[i] = get_candidate(cand + i); ltag[i] = static_cast<unsigned char>(get_tag(ctag + i)); }
         __syncthreads();
     }
     double middle[2] = {0.0, 0.0};
@@ -1473,7 +1430,7 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
         if (threadIdx.x < 2) {
             const int t = threadIdx.x;
             s_prefix[t] = edge[t] ? 0ull : static_cast<unsigned long long>(kWinBase + bins[t] - 1);
-            s_k[t] = w->krem[t][c];
+            s_k[t] = sel.krem[t][c];
         }
         __syncthreads();
         // digits from bit 56 down when an edge bin is involved (it does not fix the top 16 bits), else from bit 40; a selection whose
@@ -1499,8 +1456,8 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
 #pragma unroll
                         for (int j = 0; j < kAhead; ++j) {
                             const unsigned int i = i0 + j * kStatBlock;
-                            key[j] = cand[i < total ? i : i0];
-                            which[j] = i < total ? static_cast<unsigned int>(ctag[i]) : 0u;
+                            key[j] = get_candidate(cand + (i < total ? i : i0));
+                            which[j] = i < total ? get_tag(ctag + i) : 0u;
                         }
 #pragma unroll
                         for (int j = 0; j < kAhead; ++j)
@@ -1555,7 +1512,35 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
                 }
             }
             if (threadIdx.x == 0) s_cur = 0;
+            if (threadIdx.x < 2) s_nsurv[threadIdx.x] = 0;
             __syncthreads();
+            // Few enough left (a digit of 4 400 candidates leaves ~17): the candidates that share the digits chosen so far -- at most 64 per
+            // selection -- are gathered, and ONE wave per selection ranks them directly (a lane per survivor, 64 comparisons each): the
+            // remaining four or five digit passes, a microsecond each, are not run.
+            if (cached && shift > 0 && active[0] && active[1] && s_rem[0] <= 64u && s_rem[1] <= 64u) {
+                const unsigned long long np[2] = {s_prefix[0], s_prefix[1]};
+                for (unsigned int i = threadIdx.x; i < held; i += kStatBlock) {
+                    const unsigned long long key = lkey[i];
+                    const unsigned int which = ltag[i];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if ((which >> t & 1u) && (key >> shift) == np[t]) s_surv[t][atomicAdd(&s_nsurv[t], 1u)] = key;     // (<= s_rem[t] <= 64 of them)
+                }
+                __syncthreads();
+                if (threadIdx.x < 128) {
+                    const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                    const unsigned int cnt = s_nsurv[t];
+                    const unsigned long long mine = lane < static_cast<int>(cnt) ? s_surv[t][lane] : ~0ull;
+                    long long rank = 0;
+                    for (unsigned int j = 0; j < cnt; ++j) {
+                        const unsigned long long other = s_surv[t][j];
+                        rank += (other < mine || (other == mine && static_cast<int>(j) < lane)) ? 1 : 0;
+                    }
+                    if (lane < static_cast<int>(cnt) && rank == s_k[t]) s_prefix[t] = mine;       // exactly one lane: the ranks are a permutation of 0 .. cnt-1
+                }
+                __syncthreads();
+                break;                                                  // s_prefix holds both elements, all 64 bits
+            }
             // Candidates that did not fit LDS (one class of a million rows: 44 000 in its middle bin; or the rows themselves after an
             // overflow): once the digits chosen so far leave few enough, those move into LDS and the remaining digits are read there --
             // two passes over the far candidates instead of six (eight).
@@ -1587,7 +1572,109 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_finish(const double *__res
         o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
         o[3] = nan > 0 ? o[1] : w->acc[c][2];
         o[4] = (nan > 0 || m <= 0) ? qnan : 0.5 * (middle[0] + middle[1]);
-        o[5] = w->below[0][c] / n; o[6] = w->below[1][c] / n; o[7] = w->below[2][c] / n;   // (x < t).sum() / len(x)
+        o[5] = sel.below[0][c] / n; o[6] = sel.below[1][c] / n; o[7] = sel.below[2][c] / n;   // (x < t).sum() / len(x)
+    }
+    __syncthreads();
+    // the class's part of the workspace back to zero (the next call's launches come later on the stream: plain stores)
+    for (int i = threadIdx.x; i < kHistBins; i += kStatBlock) w->hist[c][i] = 0u;
+    if (threadIdx.x < 4) w->acc[c][threadIdx.x] = 0.0;
+    if (threadIdx.x == 4) w->class_cursor[c] = 0u;
+}
+
+// The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
+// counting sort in LDS -- and appended to the class's stretch of the candidate buffer.  The stretches are exact: the histogram says how
+// many rows each class has in its selected bins, every workgroup derives the same offsets from it, and a workgroup takes its share of
+// a stretch with ONE atomic per class it holds; a finishing workgroup then reads a contiguous list.  Then the ticket, and the
+// finishing of the classes this workgroup answers for (see the head of this section).
+__global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
+                                                              int64_t B, int mode, double *__restrict__ stats) {
+    // the finishing phase's candidates (128 KB + 16 KB); the collecting phase stages its own rows in the front of the same arrays
+    __shared__ unsigned long long lkey[kStatLdsKeys];
+    __shared__ __attribute__((aligned(8))) unsigned char ltag[kStatLdsKeys];
+    __shared__ unsigned int hh[2][256];
+    __shared__ StatSel sel;
+    __shared__ unsigned int ccount[kMaxClasses], cstart[kMaxClasses], ccur[kMaxClasses], gbase[kMaxClasses];
+    __shared__ unsigned int cur, s_state;
+    static_assert(kStatRegion <= kStatLdsKeys && kStatRegion * 2 <= kStatLdsKeys, "the staging area fits the finishing phase's arrays");
+    unsigned long long *skey = lkey;
+    unsigned short *stag = reinterpret_cast<unsigned short *>(ltag);
+    stats_select(ncls, w, sel);
+    for (int i = threadIdx.x; i < ncls; i += kStatBlock) ccount[i] = 0;
+    if (threadIdx.x == 0) cur = 0;
+    __syncthreads();
+    if (threadIdx.x < static_cast<unsigned>(ncls)) {                  // how many candidates class c has in all: the rows of its one or two selected bins
+        const int c = threadIdx.x, b0 = sel.bin[0][c], b1 = sel.bin[1][c];
+        sel.total[c] = (b0 >= 0 ? w->hist[c][b0] : 0u) + (b1 >= 0 && b1 != b0 ? w->hist[c][b1] : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int at = 0;
+        for (int c = 0; c < ncls; ++c) {
+            sel.base[c] = at;
+            at = at + sel.total[c] < at ? 0xFFFFFFFFu : at + sel.total[c];      // (saturating: beyond the buffer nothing is written anyway)
+        }
+    }
+    stats_rows(deg, cls, B, mode, [&](double a, int c) {
+        if (c < 0 || c >= ncls || a != a) return;
+        const unsigned long long key = angle_key(a);
+        const int bin = window_bin(key);
+        const unsigned int t0 = bin == sel.bin[0][c] ? 1u : 0u, t1 = bin == sel.bin[1][c] ? 1u : 0u;
+        if (t0 | t1) {
+            const unsigned int at = atomicAdd(&cur, 1u);
+            if (at < kStatRegion) { skey[at] = key; stag[at] = static_cast<unsigned short>(c | t0 << 8 | t1 << 9); }
+        }
+    });
+    __syncthreads();
+    const unsigned int n = cur < kStatRegion ? cur : kStatRegion;
+    if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);     // (the finishing workgroups then select over the rows themselves)
+    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) atomicAdd(&ccount[stag[i] & 0xFF], 1u);
+    __syncthreads();
+    if (threadIdx.x < static_cast<unsigned>(ncls)) {
+        const int c = threadIdx.x;
+        gbase[c] = ccount[c] ? sel.base[c] + atomicAdd(&w->class_cursor[c], ccount[c]) : 0u;
+    }
+    if (threadIdx.x == 0) {
+        unsigned int at = 0;
+        for (int c = 0; c < ncls; ++c) { cstart[c] = at; ccur[c] = at; at += ccount[c]; }
+    }
+    __syncthreads();
+    for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) {
+        const int c = stag[i] & 0xFF;
+        const unsigned int at = gbase[c] + (atomicAdd(&ccur[c], 1u) - cstart[c]);
+        if (at < kCandCap) put_candidate(w, at, skey[i], static_cast<unsigned char>(stag[i] >> 8));     // (past the buffer only after some workgroup has overflowed)
+    }
+    // every store of this workgroup has been performed (agent scope: past the L2) before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (static_cast<int>(blockIdx.x) >= ncls) {                          // not a finishing workgroup: ticket and out
+        if (threadIdx.x == 0) atomicAdd(&w->ticket, 1u);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&w->ticket, 1u);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(&w->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && spins < kStatSpins) {
+            __builtin_amdgcn_s_sleep(4);
+            ++spins;
+        }
+        const bool all_in = __hip_atomic_load(&w->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x;
+        const bool spilled = __hip_atomic_load(&w->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        s_state = (all_in ? 0u : 1u) | (spilled ? 2u : 0u);
+    }
+    __syncthreads();
+    const bool overflow = s_state != 0u;
+    for (int c = blockIdx.x; c < ncls; c += gridDim.x) {
+        stats_finish_class(c, deg, cls, w, B, stats, sel, overflow, lkey, ltag, hh);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // the last class to be finished puts the launch's three words back to zero (every finishing workgroup has read them by then)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (atomicAdd(&w->done, 1u) == static_cast<unsigned int>(ncls) - 1u) {
+                __hip_atomic_store(&w->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&w->overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&w->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -2060,22 +2147,23 @@ static int reduce_how(void *workspace, int64_t B, unsigned *grid) {
     return B <= kSmallBatch ? 1 : (workspace != nullptr ? 2 : 0);
 }
 
-int so3_angle_error_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, int radians, void *workspace,
-                        int64_t B, void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error_f64: B");
+int so3_angle_error_v2_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, void *workspace,
+                           unsigned flags, int64_t B, void *stream) {
+    const bool radians = (flags & SO3_RADIANS) != 0;
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error_v2_f64: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned grid = 1;
     const int how = B > 0 ? reduce_how(workspace, B, &grid) : 0;
     if (how == 0 && (sum_count || range_flag)) k_angle_init<<<1, 1, 0, s>>>(sum_count, range_flag, static_cast<double>(B));
-    if (B == 0) return check_launch("so3_angle_error_f64");
-    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error_f64: null pointer");
+    if (B == 0) return check_launch("so3_angle_error_v2_f64");
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr, "so3_angle_error_v2_f64: null pointer");
     const double unit = radians ? 1.0 : 57.295779513082320876798154814105;
     const dim3 block(kBlock);
     so3::ReduceWs *ws = static_cast<so3::ReduceWs *>(workspace);
 #define LAUNCH(WD, WS) hipLaunchKernelGGL((k_angle_f64<0, WD, WS>), dim3(grid), block, 0, s, R1, R2, deg, sum_count, range_flag, unit, B, ws, how)
     if (deg && sum_count) LAUNCH(true, true); else if (deg) LAUNCH(true, false); else if (sum_count) LAUNCH(false, true); else LAUNCH(false, false);
 #undef LAUNCH
-    return check_launch("so3_angle_error_f64");
+    return check_launch("so3_angle_error_v2_f64");
 }
 
 int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t B, void *stream) {
@@ -2088,29 +2176,30 @@ int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t 
     return check_launch("so3_geodesic_f64");
 }
 
-int so3_frob_loss_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace, int64_t B,
-                      void *stream) {
-    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_f64: B");
-    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_f64: loss_sum is null");
+int so3_frob_loss_v2_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace,
+                         unsigned flags, int64_t B, void *stream) {
+    (void)flags;
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_v2_f64: B");
+    SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_v2_f64: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
     unsigned grid = 1;
     const int how = B > 0 ? reduce_how(workspace, B, &grid) : 0;
     if (how == 0) {
         hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), s);
-        if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset");
+        if (e != hipSuccess) return fail((int)e, "so3_frob_loss_v2_f64: memset");
         if (B == 0) {
-            if (loss_mean != nullptr) { e = hipMemsetAsync(loss_mean, 0, sizeof(double), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_f64: memset"); }
+            if (loss_mean != nullptr) { e = hipMemsetAsync(loss_mean, 0, sizeof(double), s); if (e != hipSuccess) return fail((int)e, "so3_frob_loss_v2_f64: memset"); }
             return 0;
         }
     }
-    SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_f64: null pointer");
+    SO3_CHECK_ARGS(Rpred != nullptr && Rtrue != nullptr, "so3_frob_loss_v2_f64: null pointer");
     const double inv_b = 1.0 / static_cast<double>(B);
     const dim3 block(kBlock);
     so3::ReduceWs *ws = static_cast<so3::ReduceWs *>(workspace);
     if (dRpred) hipLaunchKernelGGL((k_frob_loss_f64<true>), dim3(grid), block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, B, inv_b, ws, how);
     else hipLaunchKernelGGL((k_frob_loss_f64<false>), dim3(grid), block, 0, s, Rpred, Rtrue, dRpred, loss_sum, loss_mean, B, inv_b, ws, how);
     if (how == 0 && loss_mean != nullptr) k_mean_from_sum_f64<<<1, 1, 0, s>>>(loss_sum, loss_mean, inv_b);
-    return check_launch("so3_frob_loss_f64");
+    return check_launch("so3_frob_loss_v2_f64");
 }
 
 static int geodesic_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps, void *workspace, int64_t B,
@@ -2278,8 +2367,6 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     hipStream_t s = static_cast<hipStream_t>(stream);
     StatWork *w = static_cast<StatWork *>(workspace);
     // (the sums, the overflow flag and the histograms of the classes in use; a memset node of this size costs two fill kernels, ~5 us each)
-    const unsigned int zwords = static_cast<unsigned int>((offsetof(StatWork, hist) + sizeof(unsigned int) * kHistBins * static_cast<size_t>(ncls)) / 4);
-    k_stats_zero<<<(zwords + kStatBlock - 1) / kStatBlock, kStatBlock, 0, s>>>(reinterpret_cast<unsigned int *>(w), zwords);
     // 16-byte loads of deg and 8-byte loads of cls from row 0 (mode 0) or row 1 (mode 1) on, wherever both arrays are aligned there
     auto vec_ok = [&](int64_t head) {
         return (reinterpret_cast<uintptr_t>(deg + head) & 15u) == 0 && (cls == nullptr || (reinterpret_cast<uintptr_t>(cls + head) & 7u) == 0);
@@ -2292,8 +2379,7 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));
     if (ncls <= kStatLdsClasses) k_stats_window<kStatLdsClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
     else k_stats_window<kMaxClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
-    k_stats_collect<<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
-    k_stats_finish<<<static_cast<unsigned>(ncls), kStatBlock, 0, s>>>(deg, cls, w, B, stats);
+    k_stats_collect<<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode, stats);
     return check_launch("so3_angle_stats");
 }
 

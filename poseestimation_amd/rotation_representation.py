@@ -408,8 +408,8 @@ def _angle_call_f64(r1, r2, want_rows, want_sum, radians=False, geodesic=False):
         else:
             st = _stream(dev)
             ws = _workspace(dev, st) if n > _SMALL_BATCH else None          # one launch either way (above 1024 rows: the ticket finish)
-            _check(_libh().so3_angle_error_f64(a.data_ptr(), b_.data_ptr(), _ptr(rows), _ptr(sc), flag.data_ptr(), 1 if radians else 0, _ptr(ws), n,
-                                               st), "so3_angle_error_f64")
+            _check(_libh().so3_angle_error_v2_f64(a.data_ptr(), b_.data_ptr(), _ptr(rows), _ptr(sc), flag.data_ptr(), _ptr(ws),
+                                                  _lib.RADIANS if radians else 0, n, st), "so3_angle_error_v2_f64")
     return rows, sc, flag
 
 
@@ -421,7 +421,7 @@ def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> t
     `check=False` skips the read (and the raise) for benchmarking / graph capture.
 
     float64 arguments (the reference casts to float64 before the product, :232-233): K4 reads float32 data, so
-    double tensors go to its float64 twin (so3_angle_error_f64) instead of being rounded.
+    double tensors go to its float64 twin (so3_angle_error_v2_f64) instead of being rounded.
     """
     if _is_f64(t_R1, t_R2):
         deg, _, flag = _angle_call_f64(t_R1, t_R2, True, False)
@@ -546,8 +546,8 @@ class _LossFrobenius(torch.autograd.Function):
             st = _stream(dev)
             if f64:
                 ws = _workspace(dev, st) if b > _SMALL_BATCH else None
-                _check(_libh().so3_frob_loss_f64(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), b, st),
-                       "so3_frob_loss_f64")
+                _check(_libh().so3_frob_loss_v2_f64(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), 0, b, st),
+                       "so3_frob_loss_v2_f64")
             else:
                 ws = _workspace(dev, st) if b > _SMALL_BATCH else None
                 _check(_fn("so3_frob_loss_v2_f32")(p.data_ptr(), t.data_ptr(), _ptr(g), loss_sum.data_ptr(), loss.data_ptr(), _ptr(ws), 0, b, st),
@@ -575,7 +575,7 @@ def loss_frobenius(R_pred: torch.Tensor, R_true: torch.Tensor) -> torch.Tensor:
     A training step should use `frobenius_head`, which fuses head, loss and backward into one launch.
 
     Returns the arguments' dtype as the reference (3D-Pose/loss.py:7-11): float32 through K3'; if either argument is
-    float64 (e.g. the float64 head's output) its float64 twin, so3_frob_loss_f64."""
+    float64 (e.g. the float64 head's output) its float64 twin, so3_frob_loss_v2_f64."""
     node = _node()
     if node is not None and type(R_pred) is torch.Tensor and type(R_true) is torch.Tensor and R_pred.is_cuda:
         dev = R_pred.device
@@ -978,6 +978,7 @@ def compute_disentangled_ADD_L1_loss(T_CO_pred: torch.Tensor, T_CO_gt: torch.Ten
 # next row f3: per-class evaluation statistics
 # --------------------------------------------------------------------------------------------
 STAT_FIELDS = ("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")
+_STAT_WORKSPACES = {}
 
 
 def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None, num_classes: int = 1) -> dict:
@@ -996,9 +997,17 @@ def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None,
             raise RuntimeError("angle_error_statistics: angles and class_ids differ in length")
     lib = _libh()
     stats = torch.empty((num_classes, len(STAT_FIELDS)), dtype=torch.float64, device=dev)
-    work = torch.empty((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
     with _on_device(dev):
-        _check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), _stream(dev)), "so3_angle_stats")
+        st = _stream(dev)
+        # the statistics' workspace of (device, stream): zero-filled once, every call leaves it zeroed (include/so3proj.h) -- 10 MB kept
+        # per stream that ever asked; a fresh zero-filled one while the stream is being captured (a replay may run beside eager calls)
+        key = (dev.index, st)
+        work = None if _capturing(dev) else _STAT_WORKSPACES.get(key)
+        if work is None:
+            work = torch.zeros((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
+            if not _capturing(dev):
+                _STAT_WORKSPACES[key] = work
+        _check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), st), "so3_angle_stats")
     return {name: stats[:, i] for i, name in enumerate(STAT_FIELDS)}
 
 

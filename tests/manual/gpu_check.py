@@ -108,10 +108,7 @@ def time_k4():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for name, dptr, sptr in (("sum only", None, sc), ("deg only", deg, None), ("deg+sum", deg, sc)):
         def go(i):
-            lib.so3_angle_error(ctypes.c_void_p(a[i % 4].data_ptr()), ctypes.c_void_p(b[i % 4].data_ptr()),
-                                ctypes.c_void_p(dptr.data_ptr()) if dptr is not None else None,
-                                ctypes.c_void_p(sptr.data_ptr()) if sptr is not None else None,
-                                ctypes.c_void_p(fl.data_ptr()), 0, n, st)
+            lib.so3_angle_error_v2(ctypes.c_void_p(a[i % 4].data_ptr()), ctypes.c_void_p(b[i % 4].data_ptr()), ctypes.c_void_p(dptr.data_ptr()) if dptr is not None else None, ctypes.c_void_p(sptr.data_ptr()) if sptr is not None else None, ctypes.c_void_p(fl.data_ptr()), None, 0, n, st)
         for i in range(3): go(i)
         torch.cuda.synchronize(); e0.record()
         for i in range(20): go(i)
@@ -133,8 +130,7 @@ def time_config4():
     ls = torch.empty(1, dtype=torch.float64, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     def go():
-        lib.so3_frob_fwd_bwd_bf16(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(rt.data_ptr()), ctypes.c_void_p(r.data_ptr()),
-                                  ctypes.c_void_p(dm.data_ptr()), ctypes.c_void_p(ls.data_ptr()), b, st)
+        lib.so3_frob_fwd_bwd_v2_bf16(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(rt.data_ptr()), ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(dm.data_ptr()), ctypes.c_void_p(ls.data_ptr()), None, None, 0, b, st)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(10): go()
     torch.cuda.synchronize(); e0.record()

@@ -10,20 +10,11 @@ import torch
 from conftest import ROOT
 
 
-def _header_parts():
-    """(declarations, legacy block): the exported prototypes, and the `static inline` wrappers kept for one round."""
+def header_symbols():
     text = open(os.path.join(ROOT, "include", "so3proj.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    a, b = text.index("#ifndef SO3_NO_LEGACY_WRAPPERS"), text.index("#endif", text.index("#ifndef SO3_NO_LEGACY_WRAPPERS"))
-    return text[:a] + text[b:], text[a:b]
-
-
-def header_symbols():
-    return sorted(set(re.findall(r"\b(so3_[a-z0-9_]+)\s*\(", _header_parts()[0])))
-
-
-def legacy_wrappers():
-    return sorted(set(re.findall(r"static inline int (so3_[a-z0-9_]+)\s*\(", _header_parts()[1])))
+    assert "static inline" not in text                  # round 4's one-round wrappers of the round-3 spellings are gone
+    return sorted(set(re.findall(r"\b(so3_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(built_library):
@@ -35,27 +26,36 @@ def test_library_exports_every_declared_symbol(built_library):
 
 
 def test_reducing_entry_points_exist_once(built_library):
-    """Round 3 exported every reducing entry three times (plain, _ws, _acc); now one export each (workspace nullable, a flags
-    word) and the old names are inline wrappers in the header -- present there, absent from the library."""
+    """One export per reducing entry point (workspace nullable, a flags word), the float64 ones included; the library exports exactly
+    what the header declares, and none of the spellings of rounds 3 and 4."""
     import subprocess
-    from poseestimation_amd import _lib
-    wrappers = legacy_wrappers()
-    assert wrappers == sorted(_lib.LEGACY_INLINE) and len(wrappers) == 12
     exported = subprocess.run(["nm", "-D", "--defined-only", built_library], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r"\b(so3_[a-z0-9_]+)\b", exported))
-    assert not (exported & set(wrappers)), exported & set(wrappers)
     assert exported == set(header_symbols())                      # nothing undeclared is exported either
-    for name in ("so3_frob_fwd_bwd_v2_f32", "so3_frob_fwd_bwd_v2_bf16", "so3_frob_loss_v2_f32", "so3_angle_error_v2", "so3_project_angle_error_v2_f32"):
+    for name in ("so3_frob_fwd_bwd_v2_f32", "so3_frob_fwd_bwd_v2_bf16", "so3_frob_loss_v2_f32", "so3_angle_error_v2", "so3_project_angle_error_v2_f32",
+                 "so3_angle_error_v2_f64", "so3_frob_loss_v2_f64"):
         assert name in exported
-    lib = _lib.load()                                             # the Python side mirrors the header's wrappers for this round
-    assert all(callable(getattr(lib, w)) for w in wrappers)
+    for gone in ("so3_frob_fwd_bwd_f32", "so3_frob_fwd_bwd_ws_f32", "so3_frob_loss_f32", "so3_angle_error", "so3_angle_error_ws", "so3_angle_error_acc",
+                 "so3_project_angle_error_f32", "so3_angle_error_f64", "so3_frob_loss_f64"):
+        assert gone not in exported
+
+
+def test_a_library_of_another_abi_version_is_refused(built_library, monkeypatch):
+    """The binding checks so3_version() when it loads (advisor, round 4: argument lists had changed under unchanged names)."""
+    from poseestimation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 100)
+    with pytest.raises(ImportError, match="ABI version 200"):
+        _lib.load()
+    monkeypatch.setattr(_lib, "ABI_VERSION", 200)
+    assert _lib.load().so3_version() == 200
 
 
 def test_binding_table_matches_header(built_library):
     from poseestimation_amd import _lib
     assert sorted(_lib.SYMBOLS) == header_symbols()
     lib = _lib.load()
-    assert lib.so3_version() == 100
+    assert lib.so3_version() == 200 == _lib.ABI_VERSION
     assert lib.so3_last_error() == b""
 
 
@@ -181,8 +181,8 @@ def test_fastcall_module_reaches_the_library_without_a_gpu():
     from poseestimation_amd import _so3fast
     lib = _lib.load()
     addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
-    assert _so3fast.call(addr("so3_version")) == lib.so3_version() == 100
-    assert _so3fast.call(addr("so3_version"), 1, None, 2 ** 63 + 5, -1) == 100          # extra integer arguments are ignored
+    assert _so3fast.call(addr("so3_version")) == lib.so3_version() == 200
+    assert _so3fast.call(addr("so3_version"), 1, None, 2 ** 63 + 5, -1) == 200          # extra integer arguments are ignored
     assert _so3fast.call(addr("so3_scale_f32"), None, None, None, 5, None) != 0          # null pointers: SO3_ERR_INVALID
     assert b"so3_scale_f32" in lib.so3_last_error()
     assert _so3fast.call(addr("so3_project_fwd_f32"), None, None, None, 0, None) == 0     # B = 0: nothing to do, no launch

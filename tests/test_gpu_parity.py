@@ -1170,9 +1170,7 @@ def test_c_abi_direct_on_side_stream(pa, c_oracle):
     sc = torch.full((2,), 123.0, dtype=torch.float64, device=DEV)
     fl = torch.full((1,), 7, dtype=torch.int32, device=DEV)
     for _ in range(2):
-        rc = lib.so3_angle_error(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None,
-                                 ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(fl.data_ptr()), 0, 10_000,
-                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = lib.so3_angle_error_v2(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None, ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(fl.data_ptr()), None, 0, 10_000, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
     torch.cuda.synchronize()
     assert sc[1].item() == 10_000 and fl.item() == 0 and sc[0].item() / 10_000 < 0.2
@@ -1198,11 +1196,11 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
 
     # K3: fused head + loss + backward
     ls0, r0, dm0 = f64(1), torch.empty_like(r), torch.empty_like(dm)
-    assert lib.so3_frob_fwd_bwd_f32(p(x), p(t), p(r0), p(dm0), p(ls0), n, st) == 0
+    assert lib.so3_frob_fwd_bwd_v2_f32(p(x), p(t), p(r0), p(dm0), p(ls0), None, None, 0, n, st) == 0
     runs = []
     for _ in range(3):
         ls, mean = f64(1), torch.full((), -1.0, device=DEV)
-        assert lib.so3_frob_fwd_bwd_ws_f32(p(x), p(t), p(r), p(dm), p(ls), p(mean), p(ws), n, st) == 0
+        assert lib.so3_frob_fwd_bwd_v2_f32(p(x), p(t), p(r), p(dm), p(ls), p(mean), p(ws), 0, n, st) == 0
         runs.append((ls.item(), mean.item()))
         assert torch.equal(r, r0) and torch.equal(dm, dm0)
     assert runs[0] == runs[1] == runs[2]
@@ -1210,16 +1208,16 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
     assert runs[0][1] == float(np.float32(runs[0][0] * (1.0 / n)))
     # ... and without a workspace the mean comes from the finishing launch
     ls, mean = f64(1), torch.full((), -1.0, device=DEV)
-    assert lib.so3_frob_fwd_bwd_ws_f32(p(x), p(t), None, p(dm), p(ls), p(mean), None, n, st) == 0
+    assert lib.so3_frob_fwd_bwd_v2_f32(p(x), p(t), None, p(dm), p(ls), p(mean), None, 0, n, st) == 0
     assert mean.item() == float(np.float32(ls.item() * (1.0 / n))) and abs(ls.item() - ls0.item()) <= 1e-12 * ls0.item()
 
     # K3': stand-alone loss
     ls0 = f64(1)
-    assert lib.so3_frob_loss_f32(p(r0), p(t), p(dm0), p(ls0), n, st) == 0
+    assert lib.so3_frob_loss_v2_f32(p(r0), p(t), p(dm0), p(ls0), None, None, 0, n, st) == 0
     runs = []
     for _ in range(2):
         ls, mean = f64(1), torch.full((), -1.0, device=DEV)
-        assert lib.so3_frob_loss_ws_f32(p(r0), p(t), p(dm), p(ls), p(mean), p(ws), n, st) == 0
+        assert lib.so3_frob_loss_v2_f32(p(r0), p(t), p(dm), p(ls), p(mean), p(ws), 0, n, st) == 0
         runs.append((ls.item(), mean.item()))
         assert torch.equal(dm, dm0)
     assert runs[0] == runs[1] and abs(runs[0][0] - ls0.item()) <= 1e-12 * ls0.item()
@@ -1227,42 +1225,42 @@ def test_workspace_reductions_match_the_atomic_path_and_repeat_bit_for_bit(rr, n
 
     # K4 and K1+K4: (sum, count), the flag, per-row angles untouched by the way the sum is formed
     sc0, fl0, deg0 = f64(2), torch.full((1,), 9, dtype=torch.int32, device=DEV), f64(n)
-    assert lib.so3_angle_error(p(r0), p(t), p(deg0), p(sc0), p(fl0), 0, n, st) == 0
+    assert lib.so3_angle_error_v2(p(r0), p(t), p(deg0), p(sc0), p(fl0), None, 0, n, st) == 0
     for fused in (False, True):
         runs = []
         for _ in range(2):
             sc, fl, deg = f64(2), torch.full((1,), 9, dtype=torch.int32, device=DEV), f64(n)
             if fused:
-                assert lib.so3_project_angle_error_ws_f32(p(x), p(t), p(r), p(deg), p(sc), p(fl), 0, p(ws), n, st) == 0
+                assert lib.so3_project_angle_error_v2_f32(p(x), p(t), p(r), p(deg), p(sc), p(fl), p(ws), 4, n, st) == 0
             else:
-                assert lib.so3_angle_error_ws(p(r0), p(t), p(deg), p(sc), p(fl), 0, p(ws), n, st) == 0
+                assert lib.so3_angle_error_v2(p(r0), p(t), p(deg), p(sc), p(fl), p(ws), 0, n, st) == 0
             runs.append(sc.tolist())
             assert torch.equal(deg, deg0) and fl.item() == 0 and sc[1].item() == n
         assert runs[0] == runs[1] and abs(runs[0][0] - sc0[0].item()) <= 1e-12 * sc0[0].item()
         # sum only, flag only
         sc = f64(2)
         if fused:
-            assert lib.so3_project_angle_error_ws_f32(p(x), p(t), p(r), None, p(sc), None, 0, p(ws), n, st) == 0
+            assert lib.so3_project_angle_error_v2_f32(p(x), p(t), p(r), None, p(sc), None, p(ws), 4, n, st) == 0
         else:
-            assert lib.so3_angle_error_ws(p(r0), p(t), None, p(sc), None, 0, p(ws), n, st) == 0
+            assert lib.so3_angle_error_v2(p(r0), p(t), None, p(sc), None, p(ws), 0, n, st) == 0
         assert sc.tolist() == runs[0]
     # accumulators zeroed by the caller (so3_*_acc): one launch, the same numbers up to the order of the atomics
     for fused in (False, True):
         sc, fl = torch.zeros(2, dtype=torch.float64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
         if fused:
-            assert lib.so3_project_angle_error_acc_f32(p(x), p(t), p(r), None, p(sc), p(fl), 0, n, st) == 0
+            assert lib.so3_project_angle_error_v2_f32(p(x), p(t), p(r), None, p(sc), p(fl), None, 6, n, st) == 0
         else:
-            assert lib.so3_angle_error_acc(p(r0), p(t), None, p(sc), p(fl), 0, n, st) == 0
+            assert lib.so3_angle_error_v2(p(r0), p(t), None, p(sc), p(fl), None, 2, n, st) == 0
         assert sc[1].item() == n and fl.item() == 0 and abs(sc[0].item() - sc0[0].item()) <= 1e-12 * sc0[0].item()
     bad = t.clone()
     bad[n - 3] = 3.0 * r0[n - 3]                                 # a row of the remainder when there is one: tr = 9, cosine 4
     bad[5] = 3.0 * r0[5]
     for rows in (bad, t):                                         # raised, then cleared again by the next call
         fl = torch.full((1,), 9, dtype=torch.int32, device=DEV)
-        assert lib.so3_angle_error_ws(p(r0), p(rows), None, None, p(fl), 0, p(ws), n, st) == 0
+        assert lib.so3_angle_error_v2(p(r0), p(rows), None, None, p(fl), p(ws), 0, n, st) == 0
         assert fl.item() == (1 if rows is bad else 0)
         fl = torch.zeros(1, dtype=torch.int32, device=DEV)
-        assert lib.so3_angle_error_acc(p(r0), p(rows), None, None, p(fl), 0, n, st) == 0
+        assert lib.so3_angle_error_v2(p(r0), p(rows), None, None, p(fl), None, 2, n, st) == 0
         assert fl.item() == (1 if rows is bad else 0)
     torch.cuda.synchronize()
     assert int(torch.count_nonzero(ws).item()) == 0              # slots, flag and ticket are left as they were found
@@ -1280,8 +1278,7 @@ def test_graph_capture_of_the_head(pa):
     with torch.cuda.graph(graph):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         assert lib.so3_project_fwd_f32(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(r.data_ptr()), None, 4096, st) == 0
-        assert lib.so3_angle_error(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None,
-                                   ctypes.c_void_p(sc.data_ptr()), None, 0, 4096, st) == 0
+        assert lib.so3_angle_error_v2(ctypes.c_void_p(r.data_ptr()), ctypes.c_void_p(r.data_ptr()), None, ctypes.c_void_p(sc.data_ptr()), None, None, 0, 4096, st) == 0
     x.normal_()
     graph.replay()
     torch.cuda.synchronize()

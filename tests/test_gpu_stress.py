@@ -159,11 +159,11 @@ def test_no_entry_point_writes_outside_its_outputs(b, offset):
     dm = out(b * 9)
     assert lib.so3_project_bwd_f32(p(m), p(g), p(dm), b, st) == 0
     r2 = out(b * 9); dm2 = out(b * 9); ls = out(1, torch.float64)
-    assert lib.so3_frob_fwd_bwd_f32(p(m), p(rt), p(r2), p(dm2), p(ls), b, st) == 0
+    assert lib.so3_frob_fwd_bwd_v2_f32(p(m), p(rt), p(r2), p(dm2), p(ls), None, None, 0, b, st) == 0
     mb = m.bfloat16(); dmb = out(b * 9, torch.bfloat16); r3 = out(b * 9)
-    assert lib.so3_frob_fwd_bwd_bf16(p(mb), p(rt), p(r3), p(dmb), p(ls), b, st) == 0
+    assert lib.so3_frob_fwd_bwd_v2_bf16(p(mb), p(rt), p(r3), p(dmb), p(ls), None, None, 0, b, st) == 0
     deg = out(b, torch.float64); sc = out(2, torch.float64); fl = out(1, torch.int32)
-    assert lib.so3_angle_error(p(rt), p(rt), p(deg), p(sc), p(fl), 0, b, st) == 0
+    assert lib.so3_angle_error_v2(p(rt), p(rt), p(deg), p(sc), p(fl), None, 0, b, st) == 0
     th = out(b)
     assert lib.so3_geodesic_f32(p(rt), p(rt), p(th), b, st) == 0
     for name, w in (("quat", 4), ("euler", 3), ("ortho5d", 5), ("expmap", 3), ("ortho6d", 6)):
@@ -256,8 +256,8 @@ def test_every_entry_point_is_graph_capturable():
         rc |= lib.so3_se3_update_f32(p(out12), p(t_init), p(bufs["tp"]), fx, fx, b, st)
         rc |= lib.so3_add_l1_disentangled_f32(p(bufs["tp"]), p(t_gt), p(pts), p(bufs["l3"]), p(bufs["dt"]), ctypes.c_float(1.0 / b), b, npts, st)
         rc |= lib.so3_se3_update_bwd_f32(p(out12), p(t_init), p(bufs["dt"]), p(bufs["do"]), fx, fx, b, st)
-        rc |= lib.so3_project_angle_error_f32(p(pts), p(pts), p(bufs["r"]), None, p(bufs["sc"]), p(bufs["fl"]), 0, b, st)   # first 9 floats of each cloud row as M
-        rc |= lib.so3_frob_loss_f32(p(bufs["r"]), p(bufs["r"]), p(bufs["dm"]), p(bufs["ls"]), b, st)
+        rc |= lib.so3_project_angle_error_v2_f32(p(pts), p(pts), p(bufs["r"]), None, p(bufs["sc"]), p(bufs["fl"]), None, 4, b, st)   # first 9 floats of each cloud row as M
+        rc |= lib.so3_frob_loss_v2_f32(p(bufs["r"]), p(bufs["r"]), p(bufs["dm"]), p(bufs["ls"]), None, None, 0, b, st)
         rc |= lib.so3_rotate_clouds_f32(p(pts), p(bufs["r"]), p(bufs["q"]), 0, b, npts, st)
         rc |= lib.so3_kabsch_f32(p(pts), p(bufs["q"]), p(bufs["rk"]), None, b, npts, st)
         rc |= lib.so3_quat_fwd_f32(p(bufs["tp"]), p(bufs["rq"]), b, st)                                 # first 4 floats of every T row as a quaternion

@@ -87,10 +87,10 @@ def main():
     r64 = [t.double() for t in rt[:2]]
     g64 = torch.empty(n, 9, dtype=torch.float64, device=dev)
     lm64 = torch.empty((), dtype=torch.float64, device=dev)
-    timeit("K4 f64 so3_angle_error_f64 (sum,count, workspace: one launch)", lambda i: lib.so3_angle_error_f64(p(r64[i % 2]), p(r64[1 - i % 2]), None, p(sc), p(fl), 0, p(ws), n, st), 144 * n)
-    timeit("K4 f64 so3_angle_error_f64 (sum,count, no workspace: init + kernel)", lambda i: lib.so3_angle_error_f64(p(r64[i % 2]), p(r64[1 - i % 2]), None, p(sc), p(fl), 0, None, n, st), 144 * n)
-    timeit("K4 f64 so3_angle_error_f64 (per-row deg)", lambda i: lib.so3_angle_error_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(deg), None, p(fl), 0, p(ws), n, st), 152 * n)
-    timeit("K3' f64 so3_frob_loss_f64 (loss + dRpred, workspace: one launch)", lambda i: lib.so3_frob_loss_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(g64), p(ls), p(lm64), p(ws), n, st), 216 * n)
+    timeit("K4 f64 so3_angle_error_v2_f64 (sum,count, workspace: one launch)", lambda i: lib.so3_angle_error_v2_f64(p(r64[i % 2]), p(r64[1 - i % 2]), None, p(sc), p(fl), p(ws), 0, n, st), 144 * n)
+    timeit("K4 f64 so3_angle_error_v2_f64 (sum,count, no workspace: init + kernel)", lambda i: lib.so3_angle_error_v2_f64(p(r64[i % 2]), p(r64[1 - i % 2]), None, p(sc), p(fl), None, 0, n, st), 144 * n)
+    timeit("K4 f64 so3_angle_error_v2_f64 (per-row deg)", lambda i: lib.so3_angle_error_v2_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(deg), None, p(fl), p(ws), 0, n, st), 152 * n)
+    timeit("K3' f64 so3_frob_loss_v2_f64 (loss + dRpred, workspace: one launch)", lambda i: lib.so3_frob_loss_v2_f64(p(r64[i % 2]), p(r64[1 - i % 2]), p(g64), p(ls), p(lm64), p(ws), 0, n, st), 216 * n)
     timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (workspace: one launch)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), p(ws), n, st), 72 * n)
     timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (no workspace: memset + kernel + mean)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), None, n, st), 72 * n)
     del r64, g64
@@ -116,9 +116,9 @@ def main():
     timeit("f1 so3_se3_update_bwd_f32", lambda i: lib.so3_se3_update_bwd_f32(p(o12[i % 3]), p(ti[i % 3]), p(g16), p(do12), fx, fx, n, st), 224 * n)
     del o12, ti, tp, g16, do12
     cls = torch.randint(0, 10, (n,), device=dev, dtype=torch.int32)
-    lib.so3_angle_error(p(r[0]), p(rt[0]), p(deg), None, p(fl), 0, n, st)
+    lib.so3_angle_error_v2(p(r[0]), p(rt[0]), p(deg), None, p(fl), None, 0, n, st)
     stats = torch.empty(10, 8, dtype=torch.float64, device=dev)
-    work = torch.empty(lib.so3_angle_stats_workspace_bytes(), dtype=torch.uint8, device=dev)
+    work = torch.zeros(lib.so3_angle_stats_workspace_bytes(), dtype=torch.uint8, device=dev)     # zero-filled once
     timeit("f3 so3_angle_stats (10 classes, exact median)", lambda i: lib.so3_angle_stats(p(deg), p(cls), 10, p(stats), p(work), n, st), 12 * n, iters=20)
     timeit("f3 so3_angle_stats (one class: the whole batch's median)", lambda i: lib.so3_angle_stats(p(deg), None, 1, p(stats), p(work), n, st), 8 * n, iters=20)
     del x, xb, g, r, dm, dmb, rt
@@ -149,12 +149,12 @@ def main():
     b = 512
     x4 = torch.randn(b, 9, device=dev).bfloat16(); r4 = torch.empty(b, 9, device=dev); d4 = torch.empty(b, 9, device=dev, dtype=torch.bfloat16)
     t4 = rr.symmetric_orthogonalization(torch.randn(b, 9, device=dev))
-    timeit("K3 so3_frob_fwd_bwd_bf16 (B=512)", lambda i: lib.so3_frob_fwd_bwd_bf16(p(x4), p(t4), p(r4), p(d4), p(ls), b, st), b * (18 + 36 + 36 + 18), iters=300)
+    timeit("K3 so3_frob_fwd_bwd_bf16 (B=512)", lambda i: lib.so3_frob_fwd_bwd_v2_bf16(p(x4), p(t4), p(r4), p(d4), p(ls), None, None, 0, b, st), b * (18 + 36 + 36 + 18), iters=300)
     g4 = torch.empty(b, 9, device=dev)
-    timeit("K3' so3_frob_loss_f32 (B=512, loss + dRpred: one launch)", lambda i: lib.so3_frob_loss_f32(p(r4), p(t4), p(g4), p(ls), b, st), b * 108, iters=300)
+    timeit("K3' so3_frob_loss_f32 (B=512, loss + dRpred: one launch)", lambda i: lib.so3_frob_loss_v2_f32(p(r4), p(t4), p(g4), p(ls), None, None, 0, b, st), b * 108, iters=300)
     x4f = x4.float(); sc4 = torch.empty(2, dtype=torch.float64, device=dev); fl4 = torch.zeros(1, dtype=torch.int32, device=dev)
-    timeit("K4 so3_angle_error (B=512, sum,count + flag: one launch)", lambda i: lib.so3_angle_error(p(r4), p(t4), None, p(sc4), p(fl4), 0, b, st), b * 72, iters=300)
-    timeit("K1+K4 so3_project_angle_error_f32 (B=512, sum,count + flag)", lambda i: lib.so3_project_angle_error_f32(p(x4f), p(t4), None, None, p(sc4), p(fl4), 0, b, st), b * 72, iters=300)
+    timeit("K4 so3_angle_error (B=512, sum,count + flag: one launch)", lambda i: lib.so3_angle_error_v2(p(r4), p(t4), None, p(sc4), p(fl4), None, 0, b, st), b * 72, iters=300)
+    timeit("K1+K4 so3_project_angle_error_f32 (B=512, sum,count + flag)", lambda i: lib.so3_project_angle_error_v2_f32(p(x4f), p(t4), None, None, p(sc4), p(fl4), None, 4, b, st), b * 72, iters=300)
     print("--- config #1: B = 256 ---")
     x1 = torch.randn(256, 9, device=dev); r1 = torch.empty(256, 9, device=dev)
     timeit("K1 so3_project_fwd_f32 (B=256)", lambda i: lib.so3_project_fwd_f32(p(x1), p(r1), None, 256, st), 256 * 72, iters=300)

@@ -101,8 +101,7 @@ def main():
 
     def bench(xs):
         k1 = timed(lambda i: lib.so3_project_fwd_f32(P(xs[i % nb].data_ptr()), P(out[i % nb].data_ptr()), None, n, st))
-        k3 = timed(lambda i: lib.so3_frob_fwd_bwd_f32(P(xs[i % nb].data_ptr()), P(rt.data_ptr()), P(out[i % nb].data_ptr()), P(dm[i % nb].data_ptr()),
-                                                      P(ls.data_ptr()), n, st))
+        k3 = timed(lambda i: lib.so3_frob_fwd_bwd_v2_f32(P(xs[i % nb].data_ptr()), P(rt.data_ptr()), P(out[i % nb].data_ptr()), P(dm[i % nb].data_ptr()), P(ls.data_ptr()), None, None, 0, n, st))
         return k1, k3
 
     gauss = [torch.randn(n, 9, device=dev, generator=gen) for _ in range(nb)]
