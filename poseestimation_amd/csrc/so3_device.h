@@ -746,9 +746,13 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
 #ifdef SO3_HOST_MODEL
         ++host_counters().refined_rows;          // (one "lane" per row on the host: how often the device's wave-uniform branch would be asked for)
 #endif
-        const T l22 = lam2 * lam2;
-        const typename R::mask hopeless = R::mnot(R::gt(trace, (l22 * lam2) * R::splat(S(0.5f * kQuatTau2)))
-                                                  & R::gt(R::fma(R::splat(S(12)), l22, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
+        // (judged again at every refined lambda: at a double root Newton's lambda is still 1e-3 away and the gap product looks fine there;
+        // the quotient then halves the distance per pass and never settles -- a batch of ties or rank-one rows paid all three passes)
+        auto cannot_settle = [&](T tr_, T l_) {
+            const T ll = l_ * l_;
+            return R::mnot(R::gt(tr_, (ll * l_) * R::splat(S(0.5f * kQuatTau2))) & R::gt(R::fma(R::splat(S(12)), ll, twoc2), f * R::splat(S(0.5f * kQuatCurv))));
+        };
+        typename R::mask hopeless = cannot_settle(trace, lam2) | R::mnot(usable);       // (a row that is hard by its invariants does not hold its wave either)
         typename R::mask frozen = settled | hopeless;
         T shift = lam, quot = lam2;              // the shift the current q was computed at, and q's Rayleigh quotient
 #pragma unroll 1
@@ -763,6 +767,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
             q.w = R::sel(frozen, q.w, qn.w); q.x = R::sel(frozen, q.x, qn.x); q.y = R::sel(frozen, q.y, qn.y); q.z = R::sel(frozen, q.z, qn.z);
             shift = R::sel(frozen, shift, quot);
             settled = settled | (good & R::mnot(frozen));
+            hopeless = hopeless | cannot_settle(tracen, quot);
             frozen = settled | hopeless;
             if (extra + 1 >= kQuatExtra || !R::wave_any(R::mnot(frozen))) break;
             quot = rayleigh<T>(k, q, inv_n);
