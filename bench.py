@@ -327,7 +327,7 @@ def secondary_configs(lib, dev):
     for i in range(200):                      # the autograd engine's device thread and the allocator's small pool settle over ~100 calls
         mirror(i)
     blocks = []                               # the cost is bimodal (~65 or ~110 us) with where the engine's thread is scheduled
-    for _ in range(6):                        # (tools/mirror_bisect.py): report the median block and the best one
+    for _ in range(6):                        # (docs/history/tools/mirror_bisect.py): report the median block and the best one
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(300):
@@ -563,12 +563,12 @@ def main():
             stream = side
             torch.cuda.synchronize()
             # Untimed replays: graph upload / first-touch effects, and the shader clock.  From idle the chip needs ~20 ms of
-            # load before its clock is up (tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
+            # load before its clock is up (docs/history/tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
             # fixed number of warm-up steps would time the ramp, not the kernel.  The timed graph is replayed once (upload,
             # first touch); then a SHORT graph of the same launches (<= 25 steps, so the ramp is sampled every ~0.4 ms) is
             # replayed until its time has stopped falling: the mean of the last 32 replays (10 ms) no longer beats the mean of
             # the 32 before it by 0.3 %, after at least 50 ms and at most 120 ms of load (the ramp is a staircase: one device
-            # sat on a 16.2-us step at 25 ms and reached 14.9 us by 50 ms, tools/k1_ramp_fine.py).  (`sustained` below is the same graph after
+            # sat on a 16.2-us step at 25 ms and reached 14.9 us by 50 ms, docs/history/tools/k1_ramp_fine.py).  (`sustained` below is the same graph after
             # 0.6 s: devices differ in whether that is faster -- clock still rising -- or slower -- power limit reached.)
             with torch.cuda.stream(side):
                 graph.replay()

@@ -17,7 +17,7 @@
 //
 // One-sided Jacobi works on M itself (never forms M^T M), so small singular values keep their
 // relative accuracy; measured against float64 LAPACK the result is closer than the reference's
-// own float32 LAPACK path (tools/proto_jacobi.py, DESIGN.md section "accuracy").
+// own float32 LAPACK path (docs/history/tools/proto_jacobi.py, DESIGN.md section "accuracy").
 // Rank <= 1 input (where the SVD is not unique) takes a rarely-executed divergent branch.
 //
 // The arithmetic is written once, generic over the "scalar" type T:
@@ -69,7 +69,7 @@ __device__ __forceinline__ float med3(float a, float b, float c) { return __buil
 // Sweep schedule: kSweeps fixed cyclic sweeps, then -- if any matrix held by the wave still has a relative
 // off-orthogonality of its (0,1) pair above kResidualTol (a wave-uniform branch) -- one more rotation of that pair,
 // kept by the matrices that failed.  On Gaussian input 99.93 % of the rows are below 1e-5 after three sweeps
-// (tools/proto_jacobi.py), so about one wave round in eight takes the branch.
+// (docs/history/tools/proto_jacobi.py), so about one wave round in eight takes the branch.
 constexpr int kSweeps = 3;
 constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|^2 |a_1|^2)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
@@ -497,20 +497,19 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 //   2. lambda_max = largest root of  l^4 - 2|M|^2 l^2 - 8 det(M) l + (|M|^4 - 4|cof M|^2):  started at s1 + s2 + s3' with the
 //      singular values from the closed-form roots of the cubic of M^T M (good to 5e-6 on the median row), then two Newton steps;
 //   3. q = the largest column of adj(lambda I - K) = (product of the three gaps) q q^T -- no division, no pivoting;
-//   4. lambda <- Rayleigh quotient of q (error squared); q again from the adjugate only where the residual |Kq - lambda q| asks;
+//   4. lam2 = Rayleigh quotient of q (error squared).  The quotient's distance from the shift MEASURES the shift's error: a row whose
+//      quotient stays within kQuatClose of it keeps q; the others take q again from the adjugate at the quotient, in one rare loop;
 //   5. R(q) -- orthogonal by construction.
-// About 230 packed + 130 plain VALU instructions and 30 transcendentals per PAIR of matrices, against 394 / 130 / 45 for
-// the three Jacobi sweeps and the frames above (tools/proto/qpath2.py is the numpy float32 prototype: 1M Gaussian rows
-// median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
+// Per PAIR of matrices (round 5, K1's counters): 340 vector instructions -- about 215 packed, 26 transcendental, 100 plain -- against
+// 569 (394 / 45 / 130) for the three Jacobi sweeps and the frames above (rounds 2-4: 408-431; docs/history/tools/proto/qpath2.py is the numpy float32
+// prototype: 1M Gaussian rows median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
 //
-// What the fast path cannot do it says so: a row is HARD when (a) the product of the three gaps, tr adj(lambda I - K), is
-// below kQuatTau lambda^3 (ill-conditioned, rank-deficient, ties: everything where the reference's answer is a matter of
-// LAPACK's ordering), or (b) the Rayleigh quotient moved lambda by more than kQuatConv times a lower bound of the gap
-// (the root finder had not converged: the move from the shift to the quotient bounds the error of both), or
-// (c) anything is not finite.  (b) is scaled by the larger of the two values: the first build's Laguerre iterate could only
-// be a little above the root, a Newton iterate thrown off near a critical point can be far above the whole spectrum, where
-// the adjugate is huge and looks healthy.  Hard rows (1e-4 of Gaussian input) are redone by the Jacobi path above, one row at a
-// time, by the caller (project_rotation) -- a row's result never depends on its wave-mates.
+// What the fast path cannot do it says so: a row is HARD when (a) the Rayleigh quotient moved lambda by more than kQuatConv times a lower
+// bound of the gap (the root finder had not converged, or the gap product tr adj(lambda I - K) is too small for the adjugate's column to
+// be signal: with the 2-ulp floor on the move the same test says tr adj >= 1.2e-3 lambda^3 -- ill-conditioned, rank-deficient, ties:
+// everything where the reference's answer is a matter of LAPACK's ordering), or (b) lambda is not certified as the LARGEST root
+// (quat_settled), or (c) it is hard by its invariants or anything is not finite.  Hard rows (1e-6 of Gaussian input) are redone by the
+// Jacobi path above, one row at a time, by the caller -- a row's result never depends on its wave-mates.
 constexpr float kQuatTau2 = 1e-5f;      // a gap product below half of this (times lambda^3) cannot be helped by refining lambda (see `hopeless`)
 constexpr int kQuatExtra = 3;           // how many refinements of (lambda, q) a row may take
 constexpr float kQuatConv = 4e-4f;
