@@ -515,9 +515,9 @@ constexpr int kQuatExtra = 3;           // how many refinements of (lambda, q) a
 constexpr float kQuatConv = 4e-4f;
 constexpr float kQuatUlps = 1.2e-7f;    // 2 ulp: the round-off of a float32 Rayleigh quotient, added to every measured move of lambda
 #ifndef SO3_QUAT_CLOSE
-#define SO3_QUAT_CLOSE 8e-7f
+#define SO3_QUAT_CLOSE 0.9e-6f
 #endif
-constexpr float kQuatClose = SO3_QUAT_CLOSE;     // a first eigenvector whose Rayleigh quotient lies within this of its shift (relative) is final
+constexpr float kQuatClose = SO3_QUAT_CLOSE;     // a first eigenvector whose Rayleigh quotient lies within this times s1 of its shift is final
 constexpr float kQuatWindowLo = 3.7252903e-9f, kQuatWindowHi = 17179869184.0f;   // 2^-28 <= |M|_F^2 <= 2^34 (see quat_rotation, step 1)
 constexpr float kQuatCurv = 0.5f;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
 
@@ -694,7 +694,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // of a cancellation, but they weigh little in the sum).  Two Newton steps on the quartic finish it; the start is
     // raised by 1e-3 so that they come from above.  (Laguerre from the bound sqrt(3)|M|_F needed four steps and a Newton
     // step for the same roots: 68 packed instructions and 20 transcendentals against 40 and 26.)
-    T lam;
+    T lam, s1_start;       // s1_start: the largest singular value as the closed form gives it (1e-5 or better: a scale, see step 5)
     {
         const T p = head.p, x = head.x;
         const T ax = R::abs(x);
@@ -710,7 +710,9 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
         const T mu3 = R::fma(two_sp, R::cos_rev(th + third), third);
         const T mu2 = (R::splat(S(1)) - mu1) - mu3;
         const T s3 = R::copysign(R::sqrt(R::abs(mu3)), det);
-        lam = ((R::sqrt(R::abs(mu1)) + R::sqrt(R::abs(mu2))) + s3) * (R::sqrt(f) * R::splat(S(1.001)));
+        const T r1 = R::sqrt(R::abs(mu1)), rf = R::sqrt(f);
+        s1_start = r1 * rf;
+        lam = ((r1 + R::sqrt(R::abs(mu2))) + s3) * (rf * R::splat(S(1.001)));
     }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -722,15 +724,21 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // 5. eigenvector and its Rayleigh quotient lam2.  On Gaussian input the root is good to an ulp or two for all but 2e-3 of the
     // rows, and then the first vector is as good as a second one would be: with delta = lam - lambda the vector carries
     // eps = delta / g2 of its neighbour, the error of R in the measure it is judged by (|dR| gap / s1) is delta / s1, and the quotient,
-    // being second-order accurate, MEASURES delta: a row whose quotient lies within kQuatClose of its shift, and which is settled
-    // (quat_settled above), keeps its first vector.  (Rounds 2-4 asked the residual |K q - lam2 q| instead: 13 packed instructions per
-    // pair for the same decision -- what else the residual sees, the adjugate's own round-off, a second vector has too.)
+    // being second-order accurate, MEASURES delta: a row whose quotient lies within kQuatClose s1 of its shift, and which is settled
+    // (quat_settled above), keeps its first vector.  The quotient's own round-off, 2 ulp of LAMBDA, is charged to the move, so that the
+    // bar means the same whatever lambda / s1 is (1 to 3).  What the bar buys, measured: 1.6e-3 of Gaussian rows refine (one round of 128
+    // in five or six) and the device search (tests/test_gpu_certificate_search.py, 2e7 bred rows) finds a worst accepted |dR| gap / s1
+    // of 1.6e-6 against its bound of 2e-6 (round 4's residual test: 1.7e-3 and 1.25e-6; a bar of 1.1e-6: 1.0e-3 and 1.7e-6).  Where the
+    // error of the first vector comes from is not Newton -- a third step changed nothing -- but the quartic's float32 coefficients,
+    // which move its root by eps lambda^4 / tr adj: 1e-6 lambda where the gap product is a third of lambda^3.
+    // (Rounds 2-4 asked the residual |K q - lam2 q| instead: 13 packed instructions per pair for the same decision -- what else the
+    // residual sees, the adjugate's own round-off, a second vector has too.)
     Quat<T> q;
     T trace, inv_n, move;
     dominant_column<T>(k, lam, q, trace);
     const T lam2 = rayleigh<T>(k, q, inv_n);
     typename R::mask settled = quat_settled<T>(lam, lam2, trace, twoc2, f, move);
-    settled = settled & R::le(move, lam2 * R::splat(S(kQuatClose)));
+    settled = settled & R::le(R::fma(lam2, R::splat(S(kQuatUlps)), move), s1_start * R::splat(S(kQuatClose)));
     // 6. rows this did not settle (every comparison is written so that NaN makes the row unsettled) are refined -- q again from the
     // adjugate at the quotient, which squares the error -- under ONE wave-uniform branch (one round of 128 rows in five on Gaussian
     // input), in a loop that its own rows keep running (a second pass one round in sixty, a third one in five hundred): a refined

@@ -333,11 +333,11 @@ def test_park_reservations_tile_the_list_under_interleaving(km):
 
 def test_first_eigenvector_is_final_on_all_but_a_few_gaussian_rows(km):
     """How often the fast path's rare branch is asked for, counted on the host (one "lane" per row): a wave of the device takes the branch
-    when ANY of its 128 rows asks, so 1.3e-3 of the rows is one round in seven -- round 4's residual test asked for one in five.  A
+    when ANY of its 128 rows asks, so 1.6e-3 of the rows is one round in five or six -- round 4's residual test asked for one in five.  A
     threshold or a start that drifts shows here before it shows as microseconds."""
     rng = np.random.default_rng(17)
     n = 400_000
     km.fast_path_counters()
     km.project_quat(rng.standard_normal((n, 9)).astype(np.float32))
     rows, adjugates = km.fast_path_counters()
-    assert rows / n < 1.7e-3 and adjugates < 1.2 * rows, (rows / n, adjugates)           # 1.3e-3, 1.05 measured
+    assert rows / n < 2.0e-3 and adjugates < 1.2 * rows, (rows / n, adjugates)           # 1.6e-3, 1.04 measured
