@@ -28,6 +28,9 @@
 
 #include "so3_device.h"
 
+#ifndef SO3_PARK_CAP1
+#define SO3_PARK_CAP1 512           // entries of K1's list of parked hard rows (11 words each)
+#endif
 #ifndef SO3_PARK_CAP2
 #define SO3_PARK_CAP2 256           // entries of the two-input kernels' list of parked hard rows (20 words each)
 #endif
@@ -715,7 +718,7 @@ __device__ __forceinline__ typename Tr<T>::mask project_or_park(const T (&m)[9],
 template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
-    static constexpr int kParkWords = 9, kParkCap = 512;                    // 22 KB of LDS per workgroup
+    static constexpr int kParkWords = 9, kParkCap = SO3_PARK_CAP1;          // 512 entries: 22 KB of LDS per workgroup
     uint8_t *flip = nullptr;
     template <class T, int NPL>
     __device__ __forceinline__ void compute(Rows<T, OpProject> &rows, RowCtx<NPL> &ctx) const {

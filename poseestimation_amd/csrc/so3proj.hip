@@ -1687,6 +1687,9 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
 #ifndef SO3_BLOCK_K1
 #define SO3_BLOCK_K1 256
 #endif
+#ifndef SO3_WPS_K1
+#define SO3_WPS_K1 3
+#endif
 #ifndef SO3_BLOCK_K3
 #define SO3_BLOCK_K3 256
 #endif
@@ -1801,8 +1804,8 @@ int project_fwd(const void *M, float *R, uint8_t *flip, int64_t B, void *stream)
     if (nunits > 0) {
         // two matrices per lane, three waves per SIMD: against one matrix per lane at four / five / six / eight waves (round 3, the fast
         // path, one device): 14.6-14.9 us against 15.6 / 14.9 / 16.6 (spills) / 18.4
-        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, 3, SO3_BLOCK_K1>(op, nunits, s); }
-        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, 3, SO3_BLOCK_K1>(op, nunits, s); }
+        if (flip) { so3::OpProject<EB, true> op; op.in0 = M; op.out0 = R; op.flip = flip; launch_rows<2, SO3_WPS_K1, SO3_BLOCK_K1>(op, nunits, s); }
+        else { so3::OpProject<EB, false> op; op.in0 = M; op.out0 = R; launch_rows<2, SO3_WPS_K1, SO3_BLOCK_K1>(op, nunits, s); }
     }
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
