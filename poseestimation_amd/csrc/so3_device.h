@@ -749,7 +749,9 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // two): it is FROZEN -- it takes no refinement and does not hold its wave in the loop -- and goes to the Jacobi path, so that
     // batches of ties, reflections and rank-deficient rows pay the fast path once.  Per row, like everything here: a settled or
     // frozen row never takes a refinement that a wave-mate asked for.
-    if (__builtin_expect(R::wave_any(R::mnot(settled)), 0)) {
+    // (rows that are hard whatever happens -- outside the window, hard by their invariants -- do not ask for it: with 1 % of reflections or
+    // rank-one rows in a batch every round of 128 holds one, and paid an adjugate for a row whose verdict was in already)
+    if (__builtin_expect(R::wave_any(R::mnot(settled) & usable), 0)) {
 #ifdef SO3_HOST_MODEL
         ++host_counters().refined_rows;          // (one "lane" per row on the host: how often the device's wave-uniform branch would be asked for)
 #endif
