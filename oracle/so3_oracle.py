@@ -192,19 +192,17 @@ def _mix32(x):
     return x
 
 
-def _synth_uniforms_np(seed, cloud, point, pair):
-    cloud, point = np.asarray(cloud, np.uint64), np.asarray(point, np.uint64)
-    k = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & 0xFFFFFFFF) ^ _mix32((point * 2 + pair + 0xc2b2ae35) & 0xFFFFFFFF))
-    k2 = _mix32((k + 0x27d4eb2f) & 0xFFFFFFFF)
-    return ((k >> 8).astype(np.float64) + 1.0) / 16777216.0, (k2 >> 8).astype(np.float64) / 16777216.0
-
-
 def synth_normal_np(seed, cloud, point, comp):
-    """The stateless standard normals of so3_kabsch_synth_f32 (csrc/so3proj.hip `synth_normal3`), restated:
-    per point two Box-Muller pairs; components 0,1 = r_a (cos, sin)(2 pi u_a2), component 2 = r_b cos(2 pi u_b2)."""
+    """The stateless standard normals of so3_kabsch_synth_f32 (csrc/so3proj.hip `synth_normal3`), restated: per point three 32-bit
+    mixes -> four uniforms -> two Box-Muller pairs; components 0,1 = r_a (cos, sin)(2 pi u_a2), component 2 = r_b cos(2 pi u_b2)."""
     comp = np.asarray(comp)
-    a1, a2 = _synth_uniforms_np(seed, cloud, point, 0)
-    b1, b2 = _synth_uniforms_np(seed, cloud, point, 1)
+    cloud, point = np.asarray(cloud, np.uint64), np.asarray(point, np.uint64)
+    key = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & 0xFFFFFFFF))
+    h0 = _mix32(key ^ ((point * 0x9e3779b9 + 0xc2b2ae35) & 0xFFFFFFFF))
+    h1, h2 = _mix32((h0 + 0x27d4eb2f) & 0xFFFFFFFF), _mix32(h0 ^ np.uint64(0x165667b1))
+    a1, a2 = ((h0 >> 8).astype(np.float64) + 1.0) / 16777216.0, (h1 >> 8).astype(np.float64) / 16777216.0
+    b1 = ((h2 >> 8).astype(np.float64) + 1.0) / 16777216.0
+    b2 = (((h0 & 0xFF) << 16) | ((h1 & 0xFF) << 8) | (h2 & 0xFF)).astype(np.float64) / 16777216.0
     ra, rb = np.sqrt(-2.0 * np.log(a1)), np.sqrt(-2.0 * np.log(b1))
     return np.where(comp == 0, ra * np.cos(2 * np.pi * a2), np.where(comp == 1, ra * np.sin(2 * np.pi * a2), rb * np.cos(2 * np.pi * b2)))
 

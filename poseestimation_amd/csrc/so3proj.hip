@@ -647,16 +647,17 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 }
 // Three standard normals per point from two Box-Muller pairs: (n0, n1) = r_a (cos, sin)(2 pi u_a2), n2 = r_b cos(2 pi u_b2),
 // r = sqrt(-2 ln u_1).  Hardware transcendentals: v_log_f32 (log2), v_cos_f32 / v_sin_f32 (argument in turns).
-__device__ __forceinline__ void synth_uniforms(unsigned seed, unsigned cloud, unsigned point, unsigned pair, float &u1, float &u2) {
-    const unsigned k = mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu) ^ mix32(point * 2u + pair + 0xc2b2ae35u));
-    const unsigned k2 = mix32(k + 0x27d4eb2fu);
-    u1 = (static_cast<float>(k >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-    u2 = static_cast<float>(k2 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
-}
-__device__ __forceinline__ void synth_normal3(unsigned seed, unsigned cloud, unsigned point, float &n0, float &n1, float &n2) {
-    float a1, a2, b1, b2;
-    synth_uniforms(seed, cloud, point, 0u, a1, a2);
-    synth_uniforms(seed, cloud, point, 1u, b1, b2);
+// The four uniforms come from THREE 32-bit mixes per point (round 5; rounds 2-4: six -- the integer multiplies of the hashing, not the
+// seven transcendentals, were the larger half of the generator's 80 us per 65 536 x 1024 points): h0 = mix(cloud's key ^ point's
+// counter), h1 = mix(h0 + c), h2 = mix(h0 ^ c'); 24 high bits each for u_a1, u_a2, u_b1 and the three low bytes together for u_b2.
+__device__ __forceinline__ unsigned synth_cloud_key(unsigned seed, unsigned cloud) { return mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu)); }
+__device__ __forceinline__ void synth_normal3(unsigned cloud_key, unsigned point, float &n0, float &n1, float &n2) {
+    const unsigned h0 = mix32(cloud_key ^ (point * 0x9e3779b9u + 0xc2b2ae35u));
+    const unsigned h1 = mix32(h0 + 0x27d4eb2fu), h2 = mix32(h0 ^ 0x165667b1u);
+    const float a1 = (static_cast<float>(h0 >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float a2 = static_cast<float>(h1 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
+    const float b1 = (static_cast<float>(h2 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float b2 = static_cast<float>((h0 & 0xFFu) << 16 | (h1 & 0xFFu) << 8 | (h2 & 0xFFu)) * (1.0f / 16777216.0f);
     const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a1));     // -2 ln2 log2(u)
     const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(b1));
     n0 = ra * __builtin_amdgcn_cosf(a2);
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
         float acc[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) acc[i] = 0.f;
+        const unsigned cloud_key = synth_cloud_key(seed, static_cast<unsigned>(c0 + j));      // wave-uniform: the scalar unit's
         for (int i0 = 0; i0 < N; i0 += 64 * kKabschUnroll) {
             u32x3 pp[kKabschUnroll];
 #pragma unroll
@@ -716,9 +718,8 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
                 float qy = fmaf(g[5], pz, fmaf(g[4], py, g[3] * px));
                 float qz = fmaf(g[8], pz, fmaf(g[7], py, g[6] * px));
                 if (sigma != 0.f && pt < N) {                                       // padded lanes must stay exactly zero
-                    const unsigned cl = static_cast<unsigned>(c0 + j), up = static_cast<unsigned>(pt);
                     float n0, n1, n2;
-                    synth_normal3(seed, cl, up, n0, n1, n2);
+                    synth_normal3(cloud_key, static_cast<unsigned>(pt), n0, n1, n2);
                     qx = fmaf(sigma, n0, qx);
                     qy = fmaf(sigma, n1, qy);
                     qz = fmaf(sigma, n2, qz);

@@ -262,7 +262,13 @@ def test_g9_sampler_and_synthesis_oracle():
     g = load_golden("g9_sampler.npz")
     assert np.abs(so.rotations_from_draws_np(g["theta"], g["axis"]) - g["r"]).max() < 2e-6
     z = so.synth_normal_np(3, *np.meshgrid(np.arange(50), np.arange(400), np.arange(3), indexing="ij"))
-    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs(np.corrcoef(z[:, :, 0].ravel(), z[:, :, 1].ravel())[0, 1]) < 0.02
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    flat = z.reshape(-1, 3)
+    c = np.corrcoef(flat.T)                                          # the three components of a point, and neighbouring points, do not correlate
+    assert np.abs(c - np.eye(3)).max() < 0.02 and abs(np.corrcoef(flat[:-1, 0], flat[1:, 0])[0, 1]) < 0.02
+    assert abs((flat ** 3).mean()) < 0.05 and abs((flat ** 4).mean() - 3.0) < 0.1      # skewness 0, kurtosis 3
+    z2 = so.synth_normal_np(4, *np.meshgrid(np.arange(50), np.arange(400), np.arange(3), indexing="ij"))
+    assert abs(np.corrcoef(z.ravel(), z2.ravel())[0, 1]) < 0.02     # another seed: another stream
     rng = np.random.default_rng(0)
     p = rng.random((4, 100, 3)) - 0.5
     q = so.synth_pairs_np(p, g["r"][:4], 0.0, 1)
