@@ -241,3 +241,9 @@ def test_a_missing_optional_helper_is_announced_once():
     assert "node True fast True" in out.stdout
     assert out.stderr.count("optional helper _so3node is not available") == 1 and "hidden by the test" in out.stderr
     assert "_so3fast is not available" not in out.stderr
+
+
+def test_graft_entry_build_runs_here(built_library):
+    """The driver's "does it build" check, as the driver calls it (round 5 caught build() still asserting the previous ABI version)."""
+    import __graft_entry__ as entry
+    entry.build()
