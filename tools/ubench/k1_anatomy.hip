@@ -106,6 +106,17 @@ int main(int argc, char **argv) {
     CHECK(hipDeviceSynchronize());
     g_launches = argc > 1 ? atoi(argv[1]) : 1000;
     typedef so3::OpProject<4, false> K1;
+    if (argc > 2 && argv[2][0] == 'p') {
+        // "plain": K1 with ONE matrix per lane (v_fma_f32 instead of v_pk_fma_f32: twice the instructions at half the cost each) beside the
+        // shipped packed form and the copy -- does the clock a device holds under K1 depend on the packed instructions?
+        for (int rep = 0; rep < 2; ++rep) {
+            run<K1, 2, 3>("k1", in, out, stamps);
+            run<K1, 1, 4>("k1", in, out, stamps);
+            run<K1, 1, 5>("k1", in, out, stamps);
+            run<OpCopy, 2, 3>("copy", in, out, stamps);
+        }
+        return 0;
+    }
     for (int rep = 0; rep < 3; ++rep) {
         run<K1, 2, 3>("k1", in, out, stamps);
         run<OpCopy, 2, 3>("copy", in, out, stamps);
