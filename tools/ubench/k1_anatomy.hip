@@ -16,6 +16,9 @@
 constexpr int64_t ROWS = 1000000;
 constexpr int NBUF = 8;
 static int g_launches = 40;
+static float *g_rot[NBUF];          // rotations: the second input of the two-input operations ("two" mode)
+static double *g_acc;
+static int *g_flag;
 
 __global__ void fill(float *p, int64_t n, unsigned seed) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +49,15 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     const int64_t want = (rounds + kW - 1) / kW;
     const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    auto mk = [&](int i) { Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF]; return op; };
+    // second input (operations that have one): the OTHER buffer set's outputs, i.e. rotations once main() has run K1 over them;
+    // reducing operations add onto a scratch accumulator with one atomic per workgroup (the library's no-workspace path)
+    auto mk = [&](int i) {
+        Op op; op.in0 = in[i % NBUF]; op.out0 = out[i % NBUF];
+        if constexpr (Op::kIn1 != 0) op.in1 = g_rot[(i + 1) % NBUF];
+        if constexpr (Op::kOut0 == 0) op.out0 = nullptr;
+        if constexpr (Op::kReduce) { op.sum_count = g_acc; op.range_flag = g_flag; op.unit_scale = 57.29577951308232; op.count = (double)ROWS; }
+        return op;
+    };
     for (int i = 0; i < 5; ++i)
         hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), dim3(blocks), dim3(BLOCK), 0, 0, mk(i), nunits, nullptr);
     CHECK(hipDeviceSynchronize());
@@ -93,6 +104,23 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
            what, NPL, WPS, BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
+    {   // the waves' first four rounds: arithmetic per round, period between the starts of consecutive rounds, what lies in front of the
+        // first round and behind the last stamped one (wall clock, 10 ns resolution)
+        double arith = 0, period = 0, fill = 0, tail = 0; long long na = 0, np_ = 0, nf = 0, nt = 0;
+        for (int64_t w = 0; w < nw; ++w) {
+            const int64_t nr = std::min<int64_t>((int64_t)(st6[6 * w + 4] >> 48), 4);
+            for (int64_t r = 0; r < nr; ++r) {
+                const unsigned long long b = rs[40 * w + 10 * r + 3], e = rs[40 * w + 10 * r + 4];
+                if (b && e) { arith += (double)(e - b); ++na; }
+                if (r + 1 < nr && b && rs[40 * w + 10 * (r + 1) + 3]) { period += (double)(rs[40 * w + 10 * (r + 1) + 3] - b); ++np_; }
+            }
+            if (nr > 0 && rs[40 * w + 3]) { fill += (double)(rs[40 * w + 3] - st6[6 * w]); ++nf; }
+            if (nr > 0 && nr < 4 && rs[40 * w + 10 * (nr - 1) + 4]) { tail += (double)(st6[6 * w + 1] - rs[40 * w + 10 * (nr - 1) + 4]); ++nt; }
+        }
+        printf("         per wave: start -> first round's arithmetic %.2f us | arithmetic of a round %.2f us | start of a round -> start of the next %.2f us | "
+               "end of the last round's arithmetic -> wave end %.2f us (waves with < 4 rounds)\n",
+               nf ? fill / nf * 0.01 : 0.0, na ? arith / na * 0.01 : 0.0, np_ ? period / np_ * 0.01 : 0.0, nt ? tail / nt * 0.01 : 0.0);
+    }
     fflush(stdout);
 }
 
@@ -106,6 +134,26 @@ int main(int argc, char **argv) {
     CHECK(hipDeviceSynchronize());
     g_launches = argc > 1 ? atoi(argv[1]) : 1000;
     typedef so3::OpProject<4, false> K1;
+    CHECK(hipMalloc(&g_acc, 4 * sizeof(double))); CHECK(hipMemset(g_acc, 0, 4 * sizeof(double)));
+    CHECK(hipMalloc(&g_flag, sizeof(int))); CHECK(hipMemset(g_flag, 0, sizeof(int)));
+    if (argc > 2 && argv[2][0] == 't') {
+        // "two": where a launch of the two-input kernels spends its time, beside K1 and the pure reader K4
+        for (int i = 0; i < NBUF; ++i) {          // rotations for the second input: K1 over freshly drawn rows
+            CHECK(hipMalloc(&g_rot[i], ROWS * 9 * 4));
+            float *tmp; CHECK(hipMalloc(&tmp, ROWS * 9 * 4));
+            hipLaunchKernelGGL(fill, dim3((ROWS * 9 + 255) / 256), dim3(256), 0, 0, tmp, ROWS * 9, 777u + i);
+            K1 op; op.in0 = tmp; op.out0 = g_rot[i];
+            hipLaunchKernelGGL((so3::k_rows<K1, 2, 3, 256, false>), dim3(768), dim3(256), 0, 0, op, ROWS / 64, nullptr);
+            CHECK(hipDeviceSynchronize()); CHECK(hipFree(tmp));
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            run<K1, 2, 3>("k1", in, out, stamps);
+            run<so3::OpProjectAngle<4, false, false, true, true>, 2, 2>("k1+k4", in, out, stamps);
+            run<so3::OpProjectBwd<4>, 2, 2>("k2", in, out, stamps);
+            run<so3::OpAngle<false, true>, 1, 4, 1024>("k4", g_rot, out, stamps);
+        }
+        return 0;
+    }
     if (argc > 2 && argv[2][0] == 'p') {
         // "plain": K1 with ONE matrix per lane (v_fma_f32 instead of v_pk_fma_f32: twice the instructions at half the cost each) beside the
         // shipped packed form and the copy -- does the clock a device holds under K1 depend on the packed instructions?
