@@ -314,7 +314,8 @@ int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B
  *       q_bi = Rgt_b p_bi + sigma * n(seed, b, i)        (pairing rule point_cloud/main.py:173-181, plus noise)
  *   so only P (12 B per point) is read from HBM instead of P and Q.  n is a stateless counter-based standard
  *   normal (32-bit mix -> two Box-Muller pairs per point, csrc/so3proj.hip `synth_normal3`; restated by the
- *   test oracle, oracle/ `synth_normal_np`).
+ *   test oracle, oracle/ `synth_normal_np`).  The stream a seed names belongs to the library's build, not to this
+ *   ABI: it is the same on every device and launch shape, and it changed between rounds of this library.
  *   sigma = 0 skips the generator.  R, H as in so3_kabsch_f32.
  */
 int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream);

@@ -192,17 +192,27 @@ def _mix32(x):
     return x
 
 
-def synth_normal_np(seed, cloud, point, comp):
-    """The stateless standard normals of so3_kabsch_synth_f32 (csrc/so3proj.hip `synth_normal3`), restated: per point three 32-bit
-    mixes -> four uniforms -> two Box-Muller pairs; components 0,1 = r_a (cos, sin)(2 pi u_a2), component 2 = r_b cos(2 pi u_b2)."""
-    comp = np.asarray(comp)
+def synth_uniforms_np(seed, cloud, point):
+    """The four uniforms per point behind synth_normal_np (csrc/so3proj.hip `synth_normal3`): one full 32-bit mix of (seed, cloud, point),
+    two single-multiply rounds of it, 23 bits each -- radii u_a1, u_b1 in (0, 1], angles u_a2, u_b2 in [0, 1) turns."""
     cloud, point = np.asarray(cloud, np.uint64), np.asarray(point, np.uint64)
-    key = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & 0xFFFFFFFF))
-    h0 = _mix32(key ^ ((point * 0x9e3779b9 + 0xc2b2ae35) & 0xFFFFFFFF))
-    h1, h2 = _mix32((h0 + 0x27d4eb2f) & 0xFFFFFFFF), _mix32(h0 ^ np.uint64(0x165667b1))
-    a1, a2 = ((h0 >> 8).astype(np.float64) + 1.0) / 16777216.0, (h1 >> 8).astype(np.float64) / 16777216.0
-    b1 = ((h2 >> 8).astype(np.float64) + 1.0) / 16777216.0
-    b2 = (((h0 & 0xFF) << 16) | ((h1 & 0xFF) << 8) | (h2 & 0xFF)).astype(np.float64) / 16777216.0
+    m = np.uint64(0xFFFFFFFF)
+    key = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & m))
+    h0 = _mix32(key ^ ((point * 0x9e3779b9 + 0xc2b2ae35) & m))
+    h1 = (h0 + 0x27d4eb2f) & m
+    h1 ^= h1 >> 16; h1 = (h1 * 0x7feb352d) & m; h1 ^= h1 >> 15
+    h2 = h0 ^ np.uint64(0x165667b1)
+    h2 ^= h2 >> 15; h2 = (h2 * 0x2c1b3c6d) & m; h2 ^= h2 >> 16
+    unit = lambda h: (h >> 9).astype(np.float64) / 8388608.0                     # the device's float in [1, 2), minus one
+    x = (((h2 << 8) & m) + (((h0 & 0xFF) << 24) | ((h1 & 0xFF) << 16))) & m
+    return 1.0 - unit(h0), unit(h1), 1.0 - unit(h2), unit(x)
+
+
+def synth_normal_np(seed, cloud, point, comp):
+    """The stateless standard normals of so3_kabsch_synth_f32, restated: two Box-Muller pairs per point; components 0,1 =
+    r_a (cos, sin)(2 pi u_a2), component 2 = r_b cos(2 pi u_b2)."""
+    comp = np.asarray(comp)
+    a1, a2, b1, b2 = synth_uniforms_np(seed, cloud, point)
     ra, rb = np.sqrt(-2.0 * np.log(a1)), np.sqrt(-2.0 * np.log(b1))
     return np.where(comp == 0, ra * np.cos(2 * np.pi * a2), np.where(comp == 1, ra * np.sin(2 * np.pi * a2), rb * np.cos(2 * np.pi * b2)))
 

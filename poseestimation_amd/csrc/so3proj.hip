@@ -647,17 +647,27 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 }
 // Three standard normals per point from two Box-Muller pairs: (n0, n1) = r_a (cos, sin)(2 pi u_a2), n2 = r_b cos(2 pi u_b2),
 // r = sqrt(-2 ln u_1).  Hardware transcendentals: v_log_f32 (log2), v_cos_f32 / v_sin_f32 (argument in turns).
-// The four uniforms come from THREE 32-bit mixes per point (round 5; rounds 2-4: six -- the integer multiplies of the hashing, not the
-// seven transcendentals, were the larger half of the generator's 80 us per 65 536 x 1024 points): h0 = mix(cloud's key ^ point's
-// counter), h1 = mix(h0 + c), h2 = mix(h0 ^ c'); 24 high bits each for u_a1, u_a2, u_b1 and the three low bytes together for u_b2.
+// The integer side is what the generator costs (rounds 2-4: six full mixes per point, 80 us of the kernel's 223 per 65 536 x 1024
+// points; the seven transcendentals were the smaller half), so:
+//   * ONE full mix per point, h0 = mix(cloud's key ^ point's counter), and two single-multiply rounds of it with different
+//     constants, h1 = round_a(h0 + c), h2 = round_b(h0 ^ c') -- pairwise 64 x 64 and 256-fold-magnified chi-square of the four
+//     uniforms, against each other and against the next point's / cloud's, stay within 3.1 sigma over 4 seeds x 4M points
+//     (tests/test_oracle_golden.py holds a reduced form; two rounds of the SAME shape fail it at 9 sigma between h1 and h2);
+//   * a uniform is 23 bits dropped into the mantissa of a float in [1, 2) by one v_alignbit_b32: the radii take 2 - x in (0, 1], the
+//     angles take x as it is (cosine and sine have period one turn);
+//   * u_a1, u_a2, u_b1 = the high 23 bits of h0, h1, h2; u_b2 = the high 23 bits of (h2 << 8) + (h0's low byte << 24 | h1's low
+//     byte << 16): its top sixteen bits are padded by two bytes nothing else uses, below them sits h2's low byte.
 __device__ __forceinline__ unsigned synth_cloud_key(unsigned seed, unsigned cloud) { return mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu)); }
+__device__ __forceinline__ float synth_unit_float(unsigned h) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, h, 9u)); }   // 0x3f800000 | h >> 9
 __device__ __forceinline__ void synth_normal3(unsigned cloud_key, unsigned point, float &n0, float &n1, float &n2) {
     const unsigned h0 = mix32(cloud_key ^ (point * 0x9e3779b9u + 0xc2b2ae35u));
-    const unsigned h1 = mix32(h0 + 0x27d4eb2fu), h2 = mix32(h0 ^ 0x165667b1u);
-    const float a1 = (static_cast<float>(h0 >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-    const float a2 = static_cast<float>(h1 >> 8) * (1.0f / 16777216.0f);              // [0, 1)
-    const float b1 = (static_cast<float>(h2 >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float b2 = static_cast<float>((h0 & 0xFFu) << 16 | (h1 & 0xFFu) << 8 | (h2 & 0xFFu)) * (1.0f / 16777216.0f);
+    unsigned h1 = h0 + 0x27d4eb2fu; h1 ^= h1 >> 16; h1 *= 0x7feb352du; h1 ^= h1 >> 15;
+    unsigned h2 = h0 ^ 0x165667b1u; h2 ^= h2 >> 15; h2 *= 0x2c1b3c6du; h2 ^= h2 >> 16;
+    const float a1 = 2.0f - synth_unit_float(h0);                                       // (0, 1]
+    const float a2 = synth_unit_float(h1);                                              // [1, 2) turns
+    const float b1 = 2.0f - synth_unit_float(h2);
+    const unsigned pad = __builtin_amdgcn_perm(h0, h1, 0x04000c0cu);                    // h0.byte0 << 24 | h1.byte0 << 16
+    const float b2 = synth_unit_float((h2 << 8) + pad);
     const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a1));     // -2 ln2 log2(u)
     const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(b1));
     n0 = ra * __builtin_amdgcn_cosf(a2);
@@ -683,6 +693,7 @@ __global__ __launch_bounds__(kBlock) void k_rotations_axis_angle(const float *__
     o[6] = 2 * xz - 2 * yw;     o[7] = 2 * yz + 2 * xw;     o[8] = 1 - 2 * xx - 2 * yy;  // :45
 }
 
+template <bool NOISE>
 __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict__ P, const float *__restrict__ Rgt, float sigma,
                                                          unsigned seed, float *__restrict__ R, float *__restrict__ H, int64_t B,
                                                          int32_t N, int clouds_per_wave) {
@@ -717,7 +728,7 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
                 float qx = fmaf(g[2], pz, fmaf(g[1], py, g[0] * px));               // q = R_gt p   (main.py:176-181)
                 float qy = fmaf(g[5], pz, fmaf(g[4], py, g[3] * px));
                 float qz = fmaf(g[8], pz, fmaf(g[7], py, g[6] * px));
-                if (sigma != 0.f && pt < N) {                                       // padded lanes must stay exactly zero
+                if constexpr (NOISE) {      // (a lane past the cloud's end draws too: its p is the range check's zero, and so is q p^T)
                     float n0, n1, n2;
                     synth_normal3(cloud_key, static_cast<unsigned>(pt), n0, n1, n2);
                     qx = fmaf(sigma, n0, qx);
@@ -2429,7 +2440,7 @@ int so3_kabsch_synth_f32(const float *P, const float *Rgt, float sigma, uint32_t
     if (cpw > 64) cpw = 64;
     const int64_t waves = (B + cpw - 1) / cpw;
     const int64_t blocks = (waves + (kBlock / 64) - 1) / (kBlock / 64);
-    hipLaunchKernelGGL(k_kabsch_synth, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, Rgt, sigma,
+    hipLaunchKernelGGL((sigma != 0.f ? k_kabsch_synth<true> : k_kabsch_synth<false>), dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), P, Rgt, sigma,
                        seed, R, H, B, N, static_cast<int>(cpw));
     return check_launch("so3_kabsch_synth_f32");
 }
