@@ -1217,17 +1217,20 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 // Count, mean, std, max, three accuracy thresholds and an EXACT median (the two middle elements averaged, as np.median) with TWO
 // passes over the rows in TWO launches (rounds 2 / 3: a radix select of eight launches, 152 us per 1M rows; round 4: four launches, 41 us):
 //   1. k_stats_window (all rows): per class the sum, the sum of squares, the maximum, and a histogram of the angles over a WINDOW of
-//      512 bins -- the top 16 bits of the float64 pattern (non-negative doubles order like their bits): sixteen bins per octave from
-//      2^-23 to 2^9 degrees, one bin below and one above.  The thresholds 7.5, 15 and 30 are bin edges (1.875 x 2^k), so the three
-//      accuracies and the count are sums over bins -- no atomics of their own.  Workgroup-private in LDS, flushed once.
-//   2. k_stats_collect (all rows): first, per class, the bins holding the lower and the upper middle element (every workgroup for
-//      itself, from the L2-resident histograms); then the rows of those bins (1/16 octave: a few per cent of a class) are compacted:
+//      bins on the top bits of the float64 pattern (non-negative doubles order like their bits): sixteen bins per octave from 2^-23 to
+//      2^9 degrees (sixty-four for at most four classes, Win<FINE>), one bin below and one above.  The thresholds 7.5, 15 and 30 are
+//      bin edges (1.875 x 2^k), so the three accuracies and the count are sums over bins -- no atomics of their own.  Workgroup-private
+//      in LDS, flushed once -- into kStatReplicas copies by the workgroup's XCD: flushing into one copy, 256 same-address atomics in a
+//      row on each of a few thousand words, was the larger half of the launch (tools/stats_anatomy.py; a same-address atomic at the
+//      memory side takes 30-80 ns).
+//   2. k_stats_collect (all rows): first the replicas' sum and, per class, the bins holding the lower and the upper middle element
+//      (every workgroup for itself); then the rows of those bins (a few per cent of a class) are compacted:
 //      staged in LDS (a cursor: no global atomic, no barrier in the loop), grouped by class, and appended to the class's stretch of
 //      the candidate buffer -- the histogram says exactly how long each stretch is; one atomic per workgroup and class takes a share.
 //      Then the workgroup draws a ticket, and workgroup c (c < ncls; further classes wrap around) FINISHES class c once every ticket
 //      is drawn: the class's candidates -- a contiguous list -- go into LDS (when more than 16 384: after the first digit has thinned
-//      them out), both middle elements are radix-selected at once on the remaining 48 bits, and the class's row of the result is
-//      written.  What crosses workgroups inside the launch -- the candidates -- is written with agent-scope stores (performed past the
+//      them out), ONE 8-bit digit is voted on, and the <= 64 candidates per selection that share it are ranked by a wave (more: further
+//      digits); the class's row of the result is written.  What crosses workgroups inside the launch -- the candidates -- is written with agent-scope stores (performed past the
 //      XCDs' L2s before the ticket is drawn: no release fence, which round 4 measured at 4-9 us per launch) and read with agent-scope
 //      loads.  The wait is bounded: a finishing workgroup whose launch-mates do not all arrive in time (they can only be queued behind
 //      another kernel: the finishers hold ncls of the device's CUs, not all) selects over the rows of its class themselves -- slow, never
@@ -1237,20 +1240,50 @@ __global__ __launch_bounds__(kBlock) void k_se3_rows(const float *__restrict__ o
 // Exact for every input: an edge bin (zeros, denormals, angles above 512 degrees) is selected on all 64 bits, and if a workgroup's
 // staging overflows (more than 4096 of its rows inside the selected bins: e.g. a million equal angles) the finishing workgroups
 // select over the rows themselves (two sweeps, then from LDS).
+// What does NOT pay (measured, tools/stats_anatomy.py): one launch for both passes with the rows kept in registers -- the two grid-wide
+// waits it needs cost what the launch boundary does (a ticket takes 3.5 us from the last workgroup's store to the first reader's
+// load); the candidates' first digit voted by the collecting workgroups into a global sub-histogram -- 74 000 same-address atomics
+// on 256 words added 24 us.
 constexpr int kStatFields = 8;                     // count, mean, std, max, median, acc<30, acc<15, acc<7.5
 constexpr int kMaxClasses = 64;
-constexpr int kWinBase = 0x3E80;                   // (bits >> 48) of 2^-23
-constexpr int kWinBins = 512;
-constexpr int kHistBins = kWinBins + 2;            // [0]: below the window, [kHistBins - 1]: above it (and +inf)
+// The window at two widths: sixteen bins per octave (the top 16 bits of the pattern) for up to kMaxClasses classes, or -- FINE, for at most
+// kFineClasses classes, whose histograms then take the same LDS -- sixty-four per octave (the top 18 bits): the rows of a selected bin are
+// the candidates every later step handles, and with ONE class of a million rows a sixteenth of an octave held 22 000-74 000 of them
+// (the class's single finishing workgroup: 30-63 us); a sixty-fourth holds a quarter of that.
+constexpr int kFineClasses = 4;
+template <bool FINE> struct Win {
+    static constexpr int kShift = FINE ? 46 : 48;
+    static constexpr int kBase = FINE ? 0x3E80 << 2 : 0x3E80;          // (bits >> kShift) of 2^-23
+    static constexpr int kBins = FINE ? 2048 : 512;
+    static constexpr int kHist = kBins + 2;                            // [0]: below the window, [kHist - 1]: above it (and +inf)
+    static constexpr int kRow = (kHist + 3) / 4 * 4;                   // (rows padded to whole 16-byte loads)
+    // bins [0, edge) hold exactly the angles below the threshold: 30, 15 and 7.5 are 1.875 x 2^k, i.e. edges of the 1/16-octave bins
+    static constexpr int kEdge30 = ((0x403E - 0x3E80) << (FINE ? 2 : 0)) + 1, kEdge15 = ((0x402E - 0x3E80) << (FINE ? 2 : 0)) + 1,
+                         kEdge7p5 = ((0x401E - 0x3E80) << (FINE ? 2 : 0)) + 1;
+    static __device__ __forceinline__ int bin(unsigned long long key) {
+        const int top = static_cast<int>(key >> kShift);
+        return top < kBase ? 0 : (top >= kBase + kBins ? kHist - 1 : top - kBase + 1);
+    }
+    static __device__ __forceinline__ unsigned long long top16(int b) { return static_cast<unsigned long long>(kBase + b - 1) >> (FINE ? 2 : 0); }   // of an inner bin
+};
+constexpr int kHistWords = kMaxClasses * Win<false>::kRow;            // one replica's histograms (either width)
+static_assert(kFineClasses * Win<true>::kRow <= kHistWords, "the fine histograms fit a replica");
 constexpr unsigned int kCandCap = 1u << 20;
 constexpr int kStatMaxWgs = 1024;
 constexpr int kStatLdsKeys = 16384;                // candidates of one class that k_stats_finish keeps in LDS (128 KB + 16 KB of tags)
+// The window pass's per-class sums and histograms exist kStatReplicas times, a workgroup adds into replica (its XCD's id) % kStatReplicas:
+// 256 workgroups flushing ~100 bins per class into ONE copy were 256 atomics in a row on every address -- the flush was issued 3.9 us
+// into the launch and performed 9-12.6 us into it, the larger half of the pass (stamps, profiles/r05_stats_anatomy.txt).
+#ifndef SO3_STAT_REPLICAS
+#define SO3_STAT_REPLICAS 4
+#endif
+constexpr int kStatReplicas = SO3_STAT_REPLICAS;
 struct StatWork {                                  // layout of the caller's workspace: zero-filled once, left zeroed by every call (up to `hist` included)
-    double acc[kMaxClasses][4];                    // sum, sumsq, max (bits), nan_count
+    double acc[kStatReplicas][kMaxClasses][4];     // sum, sumsq, max (bits), nan_count
     unsigned int overflow, ticket;                 // some collecting workgroup's staging overflowed; collecting workgroups that have published their candidates
     unsigned int done, pad;                        // classes finished (the last one clears the three words)
     unsigned int class_cursor[kMaxClasses];        // k_stats_collect: how much of class c's stretch of the candidate buffer is taken
-    unsigned int hist[kMaxClasses][kHistBins];
+    unsigned int hist[kStatReplicas][kHistWords];  // class c's bins from c * Win<FINE>::kRow on
     unsigned char tag[kCandCap];                   // bit 0: counts for the lower middle element, bit 1: for the upper
     unsigned long long cand[kCandCap];             // class c's candidates: the rows of its selected bins, in a stretch whose place and length the histogram gives
 };
@@ -1258,13 +1291,12 @@ constexpr unsigned int kStatRegion = 4096;         // candidates one workgroup o
 static_assert(kStatRegion * 256u <= kCandCap, "what 256 workgroups can stage fits the buffer");
 
 __device__ __forceinline__ unsigned long long angle_key(double a) { return static_cast<unsigned long long>(__double_as_longlong(a < 0 ? 0.0 : a)); }
-__device__ __forceinline__ int window_bin(unsigned long long key) {
-    const int top = static_cast<int>(key >> 48);
-    return top < kWinBase ? 0 : (top >= kWinBase + kWinBins ? kHistBins - 1 : top - kWinBase + 1);
-}
-// bins [0, edge) hold exactly the angles below the threshold: 30, 15 and 7.5 are 1.875 x 2^k, i.e. edges of the 1/16-octave bins
-constexpr int kEdge30 = 0x403E - kWinBase + 1, kEdge15 = 0x402E - kWinBase + 1, kEdge7p5 = 0x401E - kWinBase + 1;
 
+#ifdef SO3_STATS_STAMP
+#define STAT_STAMP(w, idx) do { if ((blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x == 0) (w)->cand[kCandCap - 64 + (blockIdx.x ? 32 : 0) + (idx)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAT_STAMP(w, idx) do { } while (0)
+#endif
 constexpr int kStatLdsClasses = 16;
 constexpr int kStatBlock = 1024;
 // Every row once: body(angle, class) -- two rows per thread and trip: one 16-byte and one 8-byte load where both arrays allow it
@@ -1303,19 +1335,28 @@ __device__ __forceinline__ void stats_rows(const double *__restrict__ deg, const
     }
 }
 
+// Which replica of the sums and histograms this workgroup adds into: the id of the XCD it runs on (a speed matter only: any spread
+// over the replicas gives the same totals).
+__device__ __forceinline__ int stat_replica() {
+    return static_cast<int>(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & (kStatReplicas - 1));        // hwreg(HW_REG_XCC_ID, 0, 4)
+}
+
 // LCLS = how many classes the workgroup's histograms hold: 16 (33 KB of counters) or all 64 the interface allows (132 KB of the CU's
 // 160 KB).  The float64 sums go to 32 (8) lane-private LDS slots per class and field, the slot index fastest: a wave's 64 lanes then
 // fall on 32 distinct bank pairs whatever their classes (sixteen slots were four-way conflicts: 11 us of a 30-us launch).
-template <int LCLS>
+template <int LCLS, bool FINE>
 __global__ __launch_bounds__(kStatBlock) void k_stats_window(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
                                                              int64_t B, int mode) {
     constexpr int kSlots = LCLS <= 16 ? 32 : 8;
+    constexpr int kHistBins = Win<FINE>::kHist;
     static_assert(sizeof(unsigned int) * LCLS * kHistBins + sizeof(double) * LCLS * 4 * kSlots + 64 <= 160 * 1024, "k_stats_window: LDS budget of a gfx950 CU");
     __shared__ unsigned int sh[LCLS][kHistBins];
     __shared__ double sacc[LCLS][4][kSlots];
+    STAT_STAMP(w, 16);
     for (int i = threadIdx.x; i < LCLS * kHistBins; i += kStatBlock) (&sh[0][0])[i] = 0;
     for (int i = threadIdx.x; i < ncls * 4 * kSlots; i += kStatBlock) (&sacc[0][0][0])[i] = 0.0;
     __syncthreads();
+    STAT_STAMP(w, 17);
     const int slot = threadIdx.x & (kSlots - 1);
     stats_rows(deg, cls, B, mode, [&](double a, int c) {
         if (c < 0 || c >= ncls) return;
@@ -1324,25 +1365,30 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_window(const double *__res
         atomicAdd(&sacc[c][1][slot], a * a);
         const unsigned long long key = angle_key(a);
         atomicMax(reinterpret_cast<unsigned long long *>(&sacc[c][2][slot]), key);
-        atomicAdd(&sh[c][window_bin(key)], 1u);
+        atomicAdd(&sh[c][Win<FINE>::bin(key)], 1u);
     });
     __syncthreads();
+    STAT_STAMP(w, 18);
+    const int rep = stat_replica();
     for (int i = threadIdx.x; i < ncls * kHistBins; i += kStatBlock) {
         const unsigned int v = sh[i / kHistBins][i % kHistBins];
-        if (v) atomicAdd(&w->hist[i / kHistBins][i % kHistBins], v);
+        if (v) atomicAdd(&w->hist[rep][i / kHistBins * Win<FINE>::kRow + i % kHistBins], v);
     }
     for (int i = threadIdx.x; i < ncls * 4; i += kStatBlock) {
         const int c = i / 4, f = i % 4;
         if (f == 2) {
             unsigned long long m = 0;
             for (int k = 0; k < kSlots; ++k) { const unsigned long long v = static_cast<unsigned long long>(__double_as_longlong(sacc[c][2][k])); m = v > m ? v : m; }
-            if (m) atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[c][2]), m);
+            if (m) atomicMax(reinterpret_cast<unsigned long long *>(&w->acc[rep][c][2]), m);
         } else {
             double v = 0.0;
             for (int k = 0; k < kSlots; ++k) v += sacc[c][f][k];
-            if (v != 0.0) atomicAdd(&w->acc[c][f], v);
+            if (v != 0.0) atomicAdd(&w->acc[rep][c][f], v);
         }
     }
+    STAT_STAMP(w, 19);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAT_STAMP(w, 20);
 }
 
 // What every workgroup of k_stats_collect derives for itself from the histograms (20 KB per ten classes, L2-resident): per class the
@@ -1352,50 +1398,104 @@ struct StatSel {
     int bin[2][kMaxClasses];                       // the window bin of the lower / upper middle element (-1: empty class)
     long long krem[2][kMaxClasses];                // its rank inside that bin
     double count[kMaxClasses];                     // rows of the class (NaN included)
+    double acc[4][kMaxClasses];                    // sum, sum of squares, maximum, NaN count: the replicas' totals
     unsigned int below[3][kMaxClasses];            // non-NaN rows below 30 / 15 / 7.5
     unsigned int base[kMaxClasses], total[kMaxClasses];   // class c's candidates: cand[base, base + total)
 };
-// A wave per (selection, class).
-__device__ __forceinline__ void stats_select(int ncls, const StatWork *w, StatSel &sel) {
+// The replicas of the histograms are added up into LDS first (`scratch`: room for kSelChunk classes), every load a wave's 256
+// consecutive bytes -- read by the lanes that scan them (nine bins apiece, 36 bytes apart, eight replicas: 72 loads of 18 cache lines
+// each per class) the selection took 15 us.  Then a wave per class: both selections from one reading of the class's summed histogram,
+// and how many candidates the class has in all (the rows of its one or two selected bins).
+constexpr int kSelChunk = 32;
+constexpr int kSelAhead = 2;
+template <bool FINE>
+__device__ __forceinline__ void stats_select(int ncls, const StatWork *w, StatSel &sel, unsigned int *scratch) {
+    constexpr int kHistBins = Win<FINE>::kHist, kHistRow = Win<FINE>::kRow, kEdge30 = Win<FINE>::kEdge30, kEdge15 = Win<FINE>::kEdge15, kEdge7p5 = Win<FINE>::kEdge7p5;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int kPerLane = (kHistBins + 63) / 64;                         // 9 bins per lane
-    for (int pair = wave; pair < 2 * ncls; pair += kStatBlock / 64) {
-        const int t = pair / ncls, c = pair % ncls;
-        unsigned int h[kPerLane];
-        unsigned int mine = 0, b30 = 0, b15 = 0, b7 = 0;
+    constexpr int kPerLane = (kHistBins + 63) / 64;                         // 9 (33) bins per lane
+    for (int c0 = 0; c0 < ncls; c0 += kSelChunk) {
+        const int nc = ncls - c0 < kSelChunk ? ncls - c0 : kSelChunk;
+        __syncthreads();
+        const int quads = nc * kHistRow / 4;
+        for (int i0 = threadIdx.x; i0 < quads; i0 += kSelAhead * kStatBlock) {        // 16 bytes per lane and load, kSelAhead x kStatReplicas loads in flight
+            uint4 v[kSelAhead][kStatReplicas];
 #pragma unroll
-        for (int j = 0; j < kPerLane; ++j) {
-            const int bin = kPerLane * lane + j;
-            h[j] = bin < kHistBins ? w->hist[c][bin] : 0u;
-            mine += h[j];
-            b30 += bin < kEdge30 ? h[j] : 0u; b15 += bin < kEdge15 ? h[j] : 0u; b7 += bin < kEdge7p5 ? h[j] : 0u;
-        }
-        unsigned int incl = mine;                                       // inclusive prefix sum over the lanes
+            for (int a = 0; a < kSelAhead; ++a) {
+                const int i = i0 + a * kStatBlock;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
+                for (int r = 0; r < kStatReplicas; ++r) v[a][r] = reinterpret_cast<const uint4 *>(&w->hist[r][c0 * kHistRow])[i < quads ? i : i0];
+            }
+#pragma unroll
+            for (int a = 0; a < kSelAhead; ++a) {
+                const int i = i0 + a * kStatBlock;
+                uint4 sum = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int r = 0; r < kStatReplicas; ++r) { sum.x += v[a][r].x; sum.y += v[a][r].y; sum.z += v[a][r].z; sum.w += v[a][r].w; }
+                if (i < quads) reinterpret_cast<uint4 *>(scratch)[i] = sum;
+            }
         }
-        const long long n = static_cast<long long>(__shfl(incl, 63, 64));   // the non-NaN rows of the class
-        const long long k = n > 0 ? (t == 0 ? (n - 1) / 2 : n / 2) : 0;
-        const long long before = static_cast<long long>(incl - mine);
-        if (n > 0 && k >= before && k < before + static_cast<long long>(mine)) {       // exactly one lane (the counts add up to n > k)
-            long long kk = k - before;
-            int d = 0;
-            for (; d < kPerLane - 1; ++d) { if (kk < static_cast<long long>(h[d])) break; kk -= h[d]; }
-            sel.bin[t][c] = kPerLane * lane + d;
-            sel.krem[t][c] = kk;
-        }
-        if (n <= 0 && lane == 0) { sel.bin[t][c] = -1; sel.krem[t][c] = 0; }
-        if (t == 0) {
+        __syncthreads();
+        for (int c = c0 + wave; c < c0 + nc; c += kStatBlock / 64) {
+            const unsigned int *hc = scratch + (c - c0) * kHistRow;
+            // (a lane's bins are read out of LDS again where it owns a selection: held in registers, the fine width's 33 spilled)
+            auto count_of = [&](int j) { const int bin = kPerLane * lane + j; return bin < kHistBins ? hc[bin] : 0u; };
+            unsigned int mine = 0, b30 = 0, b15 = 0, b7 = 0;
+#pragma unroll 3
+            for (int j = 0; j < kPerLane; ++j) {
+                const int bin = kPerLane * lane + j;
+                const unsigned int hj = count_of(j);
+                mine += hj;
+                b30 += bin < kEdge30 ? hj : 0u; b15 += bin < kEdge15 ? hj : 0u; b7 += bin < kEdge7p5 ? hj : 0u;
+            }
+            unsigned int incl = mine;                                       // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const long long n = static_cast<long long>(__shfl(incl, 63, 64));   // the non-NaN rows of the class
+            const long long before = static_cast<long long>(incl - mine);
+            int bin_of[2] = {-1, -1};
+            unsigned int rows_of[2] = {0u, 0u};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long long k = n > 0 ? (t == 0 ? (n - 1) / 2 : n / 2) : 0;
+                const bool owner = n > 0 && k >= before && k < before + static_cast<long long>(mine);   // exactly one lane (the counts add up to n > k)
+                int d = 0;
+                long long kk = k - before;
+                unsigned int hd = 0;
+                if (owner) {
+                    for (; d < kPerLane - 1; ++d) { const unsigned int v = count_of(d); if (kk < static_cast<long long>(v)) break; kk -= v; }
+                    hd = count_of(d);
+                    sel.bin[t][c] = kPerLane * lane + d;
+                    sel.krem[t][c] = kk;
+                }
+                if (n <= 0 && lane == 0) { sel.bin[t][c] = -1; sel.krem[t][c] = 0; }
+                const unsigned long long who = __builtin_amdgcn_ballot_w64(owner);
+                if (who != 0) {                                             // (wave-uniform)
+                    const int src = __builtin_ctzll(who);
+                    bin_of[t] = __shfl(kPerLane * lane + d, src, 64);
+                    rows_of[t] = __shfl(hd, src, 64);
+                }
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { b30 += __shfl_xor(b30, off, 64); b15 += __shfl_xor(b15, off, 64); b7 += __shfl_xor(b7, off, 64); }
             if (lane == 0) {
-                sel.count[c] = static_cast<double>(n) + w->acc[c][3];
+                double a0 = 0.0, a1 = 0.0, a3 = 0.0;
+                unsigned long long a2 = 0;
+                for (int r = 0; r < kStatReplicas; ++r) {
+                    a0 += w->acc[r][c][0]; a1 += w->acc[r][c][1]; a3 += w->acc[r][c][3];
+                    const unsigned long long v = static_cast<unsigned long long>(__double_as_longlong(w->acc[r][c][2]));
+                    a2 = v > a2 ? v : a2;
+                }
+                sel.acc[0][c] = a0; sel.acc[1][c] = a1; sel.acc[2][c] = __longlong_as_double(static_cast<long long>(a2)); sel.acc[3][c] = a3;
+                sel.count[c] = static_cast<double>(n) + a3;
                 sel.below[0][c] = b30; sel.below[1][c] = b15; sel.below[2][c] = b7;
+                sel.total[c] = rows_of[0] + (bin_of[1] != bin_of[0] ? rows_of[1] : 0u);
             }
         }
     }
+    __syncthreads();
 }
 
 // agent-scope accesses to the candidate buffer: written and read inside ONE launch by workgroups on different XCDs
@@ -1413,6 +1513,7 @@ constexpr unsigned int kStatSpins = 16384;         // x ~0.6 us: how long a fini
 // then the class's row of the result (np.mean / np.std / np.max / np.median / the thresholds), and the class's part of the workspace
 // back to zero.  `overflow`: the candidate buffer is not to be trusted (a staging overflow somewhere, or launch-mates that did not
 // arrive): select over the rows of the class themselves.
+template <bool FINE>
 __device__ __forceinline__ void stats_finish_class(int c, const double *__restrict__ deg, const int32_t *__restrict__ cls, StatWork *w, int64_t B,
                                                    double *__restrict__ stats, const StatSel &sel, bool overflow_in, unsigned long long *lkey,
                                                    unsigned char *ltag, unsigned int (*hh)[256]) {
@@ -1420,7 +1521,7 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
     __shared__ long long s_k[2];
     __shared__ unsigned int s_rem[2], s_cur, s_nsurv[2];
     __shared__ unsigned long long s_surv[2][64];
-    const double n = sel.count[c], nan = w->acc[c][3], m = n - nan;
+    const double n = sel.count[c], nan = sel.acc[3][c], m = n - nan;
     const int bins[2] = {sel.bin[0][c], sel.bin[1][c]};
     const unsigned int total = sel.total[c];                            // the class's candidates
     const unsigned long long *cand = w->cand + sel.base[c];
@@ -1431,17 +1532,34 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
     bool cached = m > 0 && !overflow && total <= static_cast<unsigned int>(kStatLdsKeys);      // (workgroup-uniform throughout)
     unsigned int held = total;                                                                // how many candidates LDS holds once cached
     __syncthreads();                                                    // (LDS of the previous phase / class is free from here)
+    STAT_STAMP(w, 8);
     if (cached) {
-#pragma unroll 4
-        for (unsigned int i = threadIdx.x; i < total; i += kStatBlock) { lkey[i] = get_candidate(cand + i); ltag[i] = static_cast<unsigned char>(get_tag(ctag + i)); }
+        // (eight candidates' loads in flight per thread, as in every_far_candidate below: one at a time -- each agent-scope load followed by
+        // its LDS store -- a class's 7 400 candidates took eight round trips to memory, 4.4 us)
+        for (unsigned int i0 = threadIdx.x; i0 < total; i0 += kAhead * kStatBlock) {
+            unsigned long long key[kAhead];
+            unsigned int which[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const unsigned int i = i0 + j * kStatBlock;
+                key[j] = get_candidate(cand + (i < total ? i : i0));
+                which[j] = get_tag(ctag + (i < total ? i : i0));
+            }
+#pragma unroll
+            for (int j = 0; j < kAhead; ++j) {
+                const unsigned int i = i0 + j * kStatBlock;
+                if (i < total) { lkey[i] = key[j]; ltag[i] = static_cast<unsigned char>(which[j]); }
+            }
+        }
         __syncthreads();
     }
+    STAT_STAMP(w, 9);
     double middle[2] = {0.0, 0.0};
     if (m > 0) {
-        const bool edge[2] = {bins[0] == 0 || bins[0] == kHistBins - 1, bins[1] == 0 || bins[1] == kHistBins - 1};
+        const bool edge[2] = {bins[0] == 0 || bins[0] == Win<FINE>::kHist - 1, bins[1] == 0 || bins[1] == Win<FINE>::kHist - 1};
         if (threadIdx.x < 2) {
             const int t = threadIdx.x;
-            s_prefix[t] = edge[t] ? 0ull : static_cast<unsigned long long>(kWinBase + bins[t] - 1);
+            s_prefix[t] = edge[t] ? 0ull : Win<FINE>::top16(bins[t]);     // (FINE: the candidates share two more bits; the first digit finds them out)
             s_k[t] = sel.krem[t][c];
         }
         __syncthreads();
@@ -1489,7 +1607,7 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
                         for (int j = 0; j < kAhead; ++j) {
                             if (cc[j] != c || a[j] != a[j]) continue;
                             const unsigned long long key = angle_key(a[j]);
-                            const int bin = window_bin(key);
+                            const int bin = Win<FINE>::bin(key);
                             const unsigned int which = (bin == bins[0] ? 1u : 0u) | (bin == bins[1] ? 2u : 0u);
                             if (which) f(key, which);
                         }
@@ -1502,6 +1620,7 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
                 every_far_candidate(vote);
             }
             __syncthreads();
+            if (shift == 40) STAT_STAMP(w, 10);
             if (threadIdx.x < 128) {                                    // wave t: the digit holding selection t's rank -- 256 bins, four per lane, a wave prefix sum
                 const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
                 unsigned int h[4], mine = 0;
@@ -1529,7 +1648,7 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
             // Few enough left (a digit of 4 400 candidates leaves ~17): the candidates that share the digits chosen so far -- at most 64 per
             // selection -- are gathered, and ONE wave per selection ranks them directly (a lane per survivor, 64 comparisons each): the
             // remaining four or five digit passes, a microsecond each, are not run.
-            if (cached && shift > 0 && active[0] && active[1] && s_rem[0] <= 64u && s_rem[1] <= 64u) {
+            auto rank_survivors = [&]() {
                 const unsigned long long np[2] = {s_prefix[0], s_prefix[1]};
                 for (unsigned int i = threadIdx.x; i < held; i += kStatBlock) {
                     const unsigned long long key = lkey[i];
@@ -1541,16 +1660,21 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
                 __syncthreads();
                 if (threadIdx.x < 128) {
                     const int t = threadIdx.x >> 6, lane = threadIdx.x & 63;
-                    const unsigned int cnt = s_nsurv[t];
+                    const unsigned int cnt = __builtin_amdgcn_readfirstlane(s_nsurv[t]);
                     const unsigned long long mine = lane < static_cast<int>(cnt) ? s_surv[t][lane] : ~0ull;
+                    const unsigned int mine_lo = static_cast<unsigned int>(mine), mine_hi = static_cast<unsigned int>(mine >> 32);
                     long long rank = 0;
-                    for (unsigned int j = 0; j < cnt; ++j) {
-                        const unsigned long long other = s_surv[t][j];
+                    for (unsigned int j = 0; j < cnt; ++j) {            // lane j's key through the scalar unit (out of LDS: one ~100-cycle read per step, 3 us for 30 survivors)
+                        const unsigned long long other = static_cast<unsigned long long>(static_cast<unsigned int>(__builtin_amdgcn_readlane(mine_hi, j))) << 32 |
+                                                         static_cast<unsigned int>(__builtin_amdgcn_readlane(mine_lo, j));
                         rank += (other < mine || (other == mine && static_cast<int>(j) < lane)) ? 1 : 0;
                     }
                     if (lane < static_cast<int>(cnt) && rank == s_k[t]) s_prefix[t] = mine;       // exactly one lane: the ranks are a permutation of 0 .. cnt-1
                 }
                 __syncthreads();
+            };
+            if (cached && shift > 0 && active[0] && active[1] && s_rem[0] <= 64u && s_rem[1] <= 64u) {
+                rank_survivors();
                 break;                                                  // s_prefix holds both elements, all 64 bits
             }
             // Candidates that did not fit LDS (one class of a million rows: 44 000 in its middle bin; or the rows themselves after an
@@ -1569,28 +1693,33 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
                 __syncthreads();
                 held = s_cur;
                 cached = true;
+                if (s_rem[0] <= 64u && s_rem[1] <= 64u) {
+                    rank_survivors();
+                    break;
+                }
             }
         }
+        STAT_STAMP(w, 11);
         middle[0] = __longlong_as_double(static_cast<long long>(s_prefix[0]));
         middle[1] = __longlong_as_double(static_cast<long long>(s_prefix[1]));
     }
     if (threadIdx.x == 0) {
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
         double *o = stats + c * kStatFields;
-        const double mean = w->acc[c][0] / m;
+        const double mean = sel.acc[0][c] / m;
         o[0] = n;
         o[1] = nan > 0 ? qnan : mean;
-        const double var = w->acc[c][1] / m - mean * mean;
+        const double var = sel.acc[1][c] / m - mean * mean;
         o[2] = nan > 0 ? o[1] : sqrt(var > 0 ? var : 0.0);                       // np.std: population standard deviation
-        o[3] = nan > 0 ? o[1] : w->acc[c][2];
+        o[3] = nan > 0 ? o[1] : sel.acc[2][c];
         o[4] = (nan > 0 || m <= 0) ? qnan : 0.5 * (middle[0] + middle[1]);
         o[5] = sel.below[0][c] / n; o[6] = sel.below[1][c] / n; o[7] = sel.below[2][c] / n;   // (x < t).sum() / len(x)
     }
     __syncthreads();
     // the class's part of the workspace back to zero (the next call's launches come later on the stream: plain stores)
-    for (int i = threadIdx.x; i < kHistBins; i += kStatBlock) w->hist[c][i] = 0u;
-    if (threadIdx.x < 4) w->acc[c][threadIdx.x] = 0.0;
-    if (threadIdx.x == 4) w->class_cursor[c] = 0u;
+    for (int i = threadIdx.x; i < kStatReplicas * Win<FINE>::kHist; i += kStatBlock) w->hist[i / Win<FINE>::kHist][c * Win<FINE>::kRow + i % Win<FINE>::kHist] = 0u;
+    if (threadIdx.x < 4 * kStatReplicas) w->acc[threadIdx.x >> 2][c][threadIdx.x & 3] = 0.0;
+    if (threadIdx.x == 4 * kStatReplicas) w->class_cursor[c] = 0u;
 }
 
 // The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
@@ -1598,10 +1727,11 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
 // many rows each class has in its selected bins, every workgroup derives the same offsets from it, and a workgroup takes its share of
 // a stretch with ONE atomic per class it holds; a finishing workgroup then reads a contiguous list.  Then the ticket, and the
 // finishing of the classes this workgroup answers for (see the head of this section).
+template <bool FINE>
 __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__restrict__ deg, const int32_t *__restrict__ cls, int ncls, StatWork *w,
                                                               int64_t B, int mode, double *__restrict__ stats) {
     // the finishing phase's candidates (128 KB + 16 KB); the collecting phase stages its own rows in the front of the same arrays
-    __shared__ unsigned long long lkey[kStatLdsKeys];
+    __shared__ __attribute__((aligned(16))) unsigned long long lkey[kStatLdsKeys];
     __shared__ __attribute__((aligned(8))) unsigned char ltag[kStatLdsKeys];
     __shared__ unsigned int hh[2][256];
     __shared__ StatSel sel;
@@ -1610,14 +1740,11 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
     static_assert(kStatRegion <= kStatLdsKeys && kStatRegion * 2 <= kStatLdsKeys, "the staging area fits the finishing phase's arrays");
     unsigned long long *skey = lkey;
     unsigned short *stag = reinterpret_cast<unsigned short *>(ltag);
-    stats_select(ncls, w, sel);
+    STAT_STAMP(w, 0);
+    static_assert((FINE ? kFineClasses : kSelChunk) * Win<FINE>::kRow * sizeof(unsigned int) <= sizeof(unsigned long long) * kStatLdsKeys, "the selection's scratch fits the candidates' array");
+    stats_select<FINE>(ncls, w, sel, reinterpret_cast<unsigned int *>(lkey));
     for (int i = threadIdx.x; i < ncls; i += kStatBlock) ccount[i] = 0;
     if (threadIdx.x == 0) cur = 0;
-    __syncthreads();
-    if (threadIdx.x < static_cast<unsigned>(ncls)) {                  // how many candidates class c has in all: the rows of its one or two selected bins
-        const int c = threadIdx.x, b0 = sel.bin[0][c], b1 = sel.bin[1][c];
-        sel.total[c] = (b0 >= 0 ? w->hist[c][b0] : 0u) + (b1 >= 0 && b1 != b0 ? w->hist[c][b1] : 0u);
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int at = 0;
@@ -1626,10 +1753,11 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
             at = at + sel.total[c] < at ? 0xFFFFFFFFu : at + sel.total[c];      // (saturating: beyond the buffer nothing is written anyway)
         }
     }
+    STAT_STAMP(w, 1);
     stats_rows(deg, cls, B, mode, [&](double a, int c) {
         if (c < 0 || c >= ncls || a != a) return;
         const unsigned long long key = angle_key(a);
-        const int bin = window_bin(key);
+        const int bin = Win<FINE>::bin(key);
         const unsigned int t0 = bin == sel.bin[0][c] ? 1u : 0u, t1 = bin == sel.bin[1][c] ? 1u : 0u;
         if (t0 | t1) {
             const unsigned int at = atomicAdd(&cur, 1u);
@@ -1637,6 +1765,7 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
         }
     });
     __syncthreads();
+    STAT_STAMP(w, 2);
     const unsigned int n = cur < kStatRegion ? cur : kStatRegion;
     if (threadIdx.x == 0 && cur > kStatRegion) atomicOr(&w->overflow, 1u);     // (the finishing workgroups then select over the rows themselves)
     for (unsigned int i = threadIdx.x; i < n; i += kStatBlock) atomicAdd(&ccount[stag[i] & 0xFF], 1u);
@@ -1658,6 +1787,7 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
     // every store of this workgroup has been performed (agent scope: past the L2) before its ticket is drawn
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    STAT_STAMP(w, 3);
     if (static_cast<int>(blockIdx.x) >= ncls) {                          // not a finishing workgroup: ticket and out
         if (threadIdx.x == 0) atomicAdd(&w->ticket, 1u);
         return;
@@ -1674,10 +1804,12 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
         s_state = (all_in ? 0u : 1u) | (spilled ? 2u : 0u);
     }
     __syncthreads();
+    STAT_STAMP(w, 4);
     const bool overflow = s_state != 0u;
     for (int c = blockIdx.x; c < ncls; c += gridDim.x) {
-        stats_finish_class(c, deg, cls, w, B, stats, sel, overflow, lkey, ltag, hh);
+        stats_finish_class<FINE>(c, deg, cls, w, B, stats, sel, overflow, lkey, ltag, hh);
         __syncthreads();
+        STAT_STAMP(w, 5);
         if (threadIdx.x == 0) {
             // the last class to be finished puts the launch's three words back to zero (every finishing workgroup has read them by then)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2392,9 +2524,14 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     if (cap > kStatMaxWgs) cap = kStatMaxWgs;
     const int64_t want = (B / 2 + kStatBlock - 1) / kStatBlock;
     const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));
-    if (ncls <= kStatLdsClasses) k_stats_window<kStatLdsClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
-    else k_stats_window<kMaxClasses><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
-    k_stats_collect<<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode, stats);
+    if (ncls <= kFineClasses) {                          // few classes: bins of 1/64 octave
+        k_stats_window<kFineClasses, true><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+        k_stats_collect<true><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode, stats);
+    } else {
+        if (ncls <= kStatLdsClasses) k_stats_window<kStatLdsClasses, false><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+        else k_stats_window<kMaxClasses, false><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode);
+        k_stats_collect<false><<<grid, kStatBlock, 0, s>>>(deg, cls, ncls, w, B, mode, stats);
+    }
     return check_launch("so3_angle_stats");
 }
 

@@ -15,7 +15,15 @@ class Lib:
         self.name = os.path.basename(path).replace("libso3proj_", "").replace(".so", "")
         lib = ctypes.CDLL(path)
         self.v2 = hasattr(lib, "so3_frob_fwd_bwd_v2_f32")
-        sig = lambda name, args: (setattr(getattr(lib, name), "restype", INT), setattr(getattr(lib, name), "argtypes", args))
+        def refused(rc, func, args):                # a timing of a call the library REFUSED is the host's error path, not a kernel's
+            if rc != 0:
+                why = ctypes.cast(lib.so3_last_error(), ctypes.c_char_p).value if hasattr(lib, "so3_last_error") else b"?"
+                raise RuntimeError("%s returned %d (%s)" % (func.__name__, rc, why))
+            return rc
+        if hasattr(lib, "so3_last_error"):
+            lib.so3_last_error.restype = ctypes.c_void_p
+        sig = lambda name, args: (setattr(getattr(lib, name), "restype", INT), setattr(getattr(lib, name), "argtypes", args),
+                                  setattr(getattr(lib, name), "errcheck", refused))
         sig("so3_project_fwd_f32", [P, P, P, I64, P])
         sig("so3_project_fwd_bf16", [P, P, P, I64, P])
         sig("so3_project_bwd_f32", [P, P, P, I64, P])

@@ -32,7 +32,7 @@ def timed(fn, iters=60):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-sizes = [250_000, 500_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000]
+sizes = [256_000, 512_000, 1_000_000, 2_000_000, 4_000_000, 8_000_000]
 rows = {}
 for n in sizes:
     NB = max(3, min(8, int(600e6 / (n * 36)) + 1))
