@@ -1595,6 +1595,43 @@ def test_angle_error_statistics_far_candidates_and_overflow(rr, case):
     assert np.allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-9, equal_nan=True)
 
 
+def test_angle_error_statistics_leave_their_workspace_zeroed(rr):
+    """include/so3proj.h: the caller zero-fills so3_angle_stats's workspace ONCE and every call leaves its counted part zeroed -- sums,
+    histograms (all replicas, both bin widths), cursors, ticket, overflow flag; the candidate buffer behind them is scratch.  One workspace
+    through few classes (bins of 1/64 octave), many (1/16), the 64-class histograms, NaN rows, an overflowing staging area (every row the
+    same) and back: all zeros after every call, and the answers do not depend on what ran before."""
+    from oracle import so3_oracle as so
+    from poseestimation_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    total = lib.so3_angle_stats_workspace_bytes()
+    counted = total - 9 * (1 << 20)                                    # tag (1 B) and cand (8 B) of 2^20 candidates close the layout
+    assert 0 < counted < total
+    work = torch.zeros(total, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    n = 300_000
+    cases = [(1, "normal"), (3, "nan"), (10, "normal"), (4, "same"), (40, "normal"), (64, "nan"), (2, "normal"), (10, "same"), (1, "normal")]
+    for ncls, kind in cases:
+        ang = np.minimum(np.abs(rng.standard_normal(n)) * 25.0, 180.0)
+        if kind == "same":
+            ang[:] = 12.5
+        if kind == "nan":
+            ang[rng.integers(0, n, 7)] = np.nan
+        cls = rng.integers(0, ncls, n).astype(np.int32)
+        a, c = dev(ang, torch.float64), dev(cls, torch.int32)
+        stats = torch.empty(ncls, 8, dtype=torch.float64, device=DEV)
+        assert lib.so3_angle_stats(a.data_ptr(), c.data_ptr(), ncls, stats.data_ptr(), work.data_ptr(), n, st) == 0
+        torch.cuda.synchronize()
+        assert int(torch.count_nonzero(work[:counted]).item()) == 0, (ncls, kind)
+        ref = so.angle_statistics_np(ang, cls, ncls)
+        got = stats.cpu().numpy()
+        for i, k in enumerate(("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")):
+            if k in ("mean", "std"):
+                assert np.allclose(got[:, i], ref[k], rtol=0, atol=1e-9, equal_nan=True), (ncls, kind, k)
+            else:
+                assert np.array_equal(got[:, i], ref[k], equal_nan=True), (ncls, kind, k)
+
+
 def test_angle_error_statistics_end_to_end_and_nan(rr):
     """K1 -> K4 -> statistics without leaving the device, against the oracle chain; NaN propagates like numpy."""
     from oracle import so3_oracle as so
