@@ -433,7 +433,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
             f32x4 in0[I0::kLoads], in1[I1::kLoads], in2[I2::kLoads];
             auto issue = [&](int tr) {                      // past the last round the descriptors are empty: the loads
                 const int cnt = units_of(tr);               // return 0 and cost no traffic
-                const int64_t u = cnt > 0 ? static_cast<int64_t>(tr) * NPL : 0;
+                const int64_t u = static_cast<int64_t>(tr) * NPL;      // (past the end nothing is in range, whatever the base)
                 I0::fetch(in0, I0::rsrc(op.in0, u, cnt), lane);
                 if constexpr (Op::kIn1 != 0) I1::fetch(in1, I1::rsrc(op.in1, u, cnt), lane);
                 if constexpr (Op::kIn2 != 0) I2::fetch(in2, I2::rsrc(op.in2, u, cnt), lane);
