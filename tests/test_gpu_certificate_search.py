@@ -8,6 +8,7 @@ accepted rows in the measure the kernel is judged by (|dR| gap / s1), the worst 
 relative size, blended, rotated) into the next generation, beside fresh draws from the families that found bugs in round 2
 (entries near the window's edges, exact double roots, near-reflections, rank deficiency).  The bulk reference is the float64
 device kernel; the worst candidates of every generation are re-judged against float64 LAPACK on the host (independent)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -97,11 +98,12 @@ def _lapack(m32):
     return u @ vt, s, d < 0
 
 
-def test_adversarial_search_finds_no_accepted_row_beyond_the_bound():
+@pytest.mark.parametrize("seed", [2025, 42, 31337])          # (tools/search_seeds.py: any seeds, any build; ten of them read 1.42-1.75e-6)
+def test_adversarial_search_finds_no_accepted_row_beyond_the_bound(seed):
     from poseestimation_amd import _lib
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
-    gen = torch.Generator(device=DEV).manual_seed(2025)
+    gen = torch.Generator(device=DEV).manual_seed(int(os.environ.get("SO3_SEARCH_SEED", seed)))      # (another seed: another search, same bound)
     pop = _seeds(N, gen)
     worst_overall, accepted_total, hard_total, flips_checked = 0.0, 0, 0, 0
     history = []
