@@ -523,12 +523,12 @@ constexpr float kQuatUlps = 1.2e-7f;    // 2 ulp: the round-off of a float32 Ray
 constexpr float kQuatClose = SO3_QUAT_CLOSE;     // a first eigenvector whose Rayleigh quotient lies within this times s1 of its shift is final
 constexpr float kQuatWindowLo = 3.7252903e-9f, kQuatWindowHi = 17179869184.0f;   // 2^-28 <= |M|_F^2 <= 2^34 (see quat_rotation, step 1)
 // (0.5 through round 5's last day: the adversarial search then found accepted rows at 2.0-2.2e-6 under seeds other than the one the test
-// used -- neither kQuatConv nor kQuatClose moves that number, the second gap does.  Worst over 20-50 seeds x 2e7 rows: 0.8 -> 1.90e-6,
-// 1.0 -> 1.82e-6, 1.3 -> 1.70e-6, 2.0 -> 1.63e-6; Gaussian rows that turn hard: 2e-6, 3.5e-6, 1.4e-5, more -- and a dozen hard rows per
-// million already cost K1 0.35 us, K3 0.8 us per launch (1.3), 1.3 / 1.8 us at 2.0: their workgroups redo them behind the loop.
-// tools/search_seeds.py)
+// used -- neither kQuatConv nor kQuatClose moves that number, the second gap does.  Worst over 20-60 seeds x 2e7 rows: 0.8 -> 1.90e-6,
+// 1.0 -> 1.94e-6 (fifty seeds; 1.82e-6 over another forty), 1.3 -> 1.70e-6, 2.0 -> 1.63e-6; Gaussian rows that turn hard: 2e-6, 3.5e-6,
+// 1.4e-5, more -- and hard rows are not free even when they are a handful per million (their workgroups redo them behind the loop: one
+// Jacobi's latency): K1 as a graph 14.00 (0.5), 14.01 (0.8), 14.15 (1.0), 14.65 us (1.3).  tools/search_seeds.py)
 #ifndef SO3_QUAT_CURV
-#define SO3_QUAT_CURV 1.0f
+#define SO3_QUAT_CURV 0.8f
 #endif
 constexpr float kQuatCurv = SO3_QUAT_CURV;      // P''(lambda) >= kQuatCurv |M|^2: the SECOND gap is not small either (see quat_settled)
 
