@@ -43,7 +43,7 @@ AB_ROUNDS=5 python3 tools/ab_v2.py $libs build/variants/libso3proj_$tag.so > $P/
 say "time against batch size"
 python3 tools/size_ramp.py > $P/size_ramp.txt 2>&1
 say "engine anatomy, statistics, mirror, certificate search"
-[ -x tools/ubench/k1_anatomy ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -o tools/ubench/k1_anatomy tools/ubench/k1_anatomy.hip
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -o tools/ubench/k1_anatomy tools/ubench/k1_anatomy.hip
 tools/ubench/k1_anatomy 1000 > $P/anatomy.txt 2>&1 || echo "k1_anatomy failed (see $P/anatomy.txt)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_stats -- python3 tools/stats_loop.py > $P/stats_loop.txt 2>&1
 python3 tools/mirror_modes.py > $P/mirror_modes.txt 2>&1
