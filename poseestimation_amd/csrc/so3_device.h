@@ -508,7 +508,7 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 // bound of the gap (the root finder had not converged, or the gap product tr adj(lambda I - K) is too small for the adjugate's column to
 // be signal: with the 2-ulp floor on the move the same test says tr adj >= 1.2e-3 lambda^3 -- ill-conditioned, rank-deficient, ties:
 // everything where the reference's answer is a matter of LAPACK's ordering), or (b) lambda is not certified as the LARGEST root
-// (quat_settled), or (c) it is hard by its invariants or anything is not finite.  Hard rows (1e-6 of Gaussian input) are redone by the
+// (quat_settled), or (c) it is hard by its invariants or anything is not finite.  Hard rows (2e-6 of Gaussian input) are redone by the
 // Jacobi path above, one row at a time, by the caller -- a row's result never depends on its wave-mates.
 constexpr float kQuatTau2 = 1e-5f;      // a gap product below half of this (times lambda^3) cannot be helped by refining lambda (see `hopeless`)
 constexpr int kQuatExtra = 3;           // how many refinements of (lambda, q) a row may take

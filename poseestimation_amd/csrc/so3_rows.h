@@ -562,7 +562,7 @@ struct OpBase {
 
 #ifndef SO3_HOST_MODEL   // K1..K4 write side outputs through buffer descriptors and publish reductions with atomics
 // ---- rows the fast path cannot serve ------------------------------------------------------------------------------------
-// The quaternion fast path (so3_device.h section 3a) declares a row HARD when it cannot certify its rotation: 1e-6 of Gaussian
+// The quaternion fast path (so3_device.h section 3a) declares a row HARD when it cannot certify its rotation: 2e-6 of Gaussian
 // rows, every row of a batch of reflections, ties, rank-deficient or zero matrices.  SIMT leaves no way to run the second
 // algorithm on the hard lanes alone at less than full price, so:
 //   * a round with FEW hard rows (at most 16 NPL of its 64 NPL) PARKS them -- inputs and row number, in a list the workgroup
