@@ -34,13 +34,15 @@
 extern "C" {
 #endif
 
-#define SO3PROJ_VERSION 200          /* 0.2.0: the reducing entry points exist once (*_v2: workspace nullable, a flags word), the float64 ones
+#define SO3PROJ_VERSION 210          /* 0.2.0: the reducing entry points exist once (*_v2: workspace nullable, a flags word), the float64 ones
                                         included (so3_angle_error_v2_f64, so3_frob_loss_v2_f64: round 4 had changed their arguments under the old
-                                        names); so3_angle_stats's workspace is zero-filled once by the caller.  A binding checks so3_version(). */
+                                        names); so3_angle_stats's workspace is zero-filled once by the caller.  0.2.1 (210) ADDS the metrics'
+                                        backward (so3_angle_bwd_f32 / _f64), so3_geodesic_eps_f64 and two flags; nothing of 200 changed its
+                                        arguments, but the float64 entries now reject flag bits they do not know.  A binding checks so3_version(). */
 #define SO3_ERR_INVALID (-1)
 
 /* Library version (SO3PROJ_VERSION the library was built with).  A caller compiled against another version of this header must not
- * call the library: argument lists changed between 100 and 200 without new symbol names for every function. */
+ * call the library: argument lists changed between 100 and 200 without new symbol names for every function (210 only adds to 200). */
 int so3_version(void);
 
 /* Thread-local description of the last non-zero return on this thread ("" if none). */
@@ -101,6 +103,8 @@ int so3_project_bwd_f64(const double *M, const double *G, double *dM, int64_t B,
 #define SO3_RADIANS 0x1u
 #define SO3_PREZEROED 0x2u
 #define SO3_EXACT_F64 0x4u
+#define SO3_GRAD_SCALAR 0x8u         /* so3_angle_bwd_*: `grad` is ONE element in device memory shared by every row */
+#define SO3_F64_MATH 0x10u           /* so3_angle_bwd_f32: angle_error's spelling (float64 arithmetic on float32 data, float64 `grad`) */
 size_t so3_reduce_workspace_bytes(void);
 
 /* ---- K3: fused head forward + Frobenius loss + backward (config #4) ------------------------------
@@ -195,6 +199,40 @@ int so3_geodesic_f32(const float *R1, const float *R2, float *theta, int64_t B, 
  */
 int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double *sum, float *result, int mean, float eps,
                          void *workspace, int64_t B, void *stream);
+
+/* float64 twin of so3_geodesic_eps_f32 (the reference's geodesic() computes in its arguments' dtype): theta B doubles (nullable),
+ * sum 1 double of scratch (nullable; zeroed by the call), result 1 double (nullable, needs sum): sum or sum / B.  One row per thread,
+ * memset + kernel (+ a 1-thread launch for result); not a benchmark path. */
+int so3_geodesic_eps_f64(const double *R1, const double *R2, double *theta, double *sum, double *result, int mean, double eps,
+                         int64_t B, void *stream);
+
+/* ---- K4b: backward of the metrics ----------------------------------------------------------------------------------
+ * The reference's three metric spellings are plain differentiable tensor code, and its training loops take any of them as the
+ * loss (`lossfunc`: point_cloud/main.py:194-197, UPNA/main.py:56-59; geodesic()'s eps = 1e-7 exists for this gradient,
+ * point_cloud/main.py:61-73 and the comment at :64).  With c_b = (sum_ij R1_b,ij R2_b,ij - 1)/2 and
+ * theta_b = unit * acos(clamp(c_b, -1 + eps, 1 - eps)) -- tr(R1 R2^T) = tr(R1^T R2), so one formula serves
+ * rotation_representation.py:209-227 (eps 0, radians), :230-242 (eps 0, degrees, float64 arithmetic) and geodesic (eps 1e-7) --
+ *     dR1_b = h_b R2_b,   dR2_b = h_b R1_b,   h_b = (grad_b / grad_div) * unit * (-1 / sqrt(1 - c_b^2)) / 2
+ * for rows with -1 + eps <= c_b <= 1 - eps, and 0 outside the clamp: torch.clamp's / torch.min's / torch.max's backward FILL the
+ * gradient with 0 there, the reference never multiplies by acos' infinite slope.  (Divergence: a row with c_b = +-1 EXACTLY
+ * and eps = 0 gets -+inf from the reference and 0 here.)  NaN rows give NaN.
+ *   R1, R2    in  B*9
+ *   grad      in  the upstream gradient d loss / d theta_b: B elements, or ONE element with SO3_GRAD_SCALAR (the 0-dim tensor
+ *                 autograd hands to a "mean" / "sum" reduction; a device pointer either way, no host sync).  float32 for
+ *                 so3_angle_bwd_f32, float64 with SO3_F64_MATH and for so3_angle_bwd_f64.
+ *   grad_div      every gradient element is divided by it first (B for reduction "mean": torch divides, it does not multiply
+ *                 by 1/B; 1 otherwise)
+ *   eps           the clamp is [-1 + eps, 1 - eps], evaluated in the arithmetic of the spelling (float32 unless SO3_F64_MATH)
+ *   dR1, dR2  out B*9 each; either may be NULL (not both)
+ *   flags         SO3_RADIANS (default: theta in degrees, as K4), SO3_GRAD_SCALAR, SO3_F64_MATH
+ * so3_angle_bwd_f32 without SO3_F64_MATH follows the float32 graph operation for operation (trace summed as so3_geodesic_f32
+ * sums it, 1 - c c with both roundings, rsqrt, gradient, mask, / 2, times the other rotation); with it, angle_error's: both
+ * rotations cast to float64, every step float64, ONE rounding to float32 at the end.  Streaming engine: 72 B read + 36 B (72 B with
+ * both gradients) written per row (+ 4 / 8 B of per-row gradient).  so3_angle_bwd_f64: float64 data, one row per thread. */
+int so3_angle_bwd_f32(const float *R1, const float *R2, const void *grad, double grad_div, double eps, unsigned flags,
+                      float *dR1, float *dR2, int64_t B, void *stream);
+int so3_angle_bwd_f64(const double *R1, const double *R2, const double *grad, double grad_div, double eps, unsigned flags,
+                      double *dR1, double *dR2, int64_t B, void *stream);
 
 /* ---- next row: the SE(3) pose update fused after the head ------------------------
  * Replaces calculate_T_pred, Iterative/utility.py:90-128 (the head at :105, einsum at :124, the translation

@@ -106,6 +106,29 @@ def geodesic_eps_np(r1, r2, reduction="mean", eps=1e-7):
     return None
 
 
+def metric_backward_np(r1, r2, upstream, eps=0.0, unit=1.0, divisor=1.0, clamp_dtype=np.float64):
+    """Gradient of theta_b = unit * acos(clamp(c_b, -1 + eps, 1 - eps)), c_b = (sum_ij R1_ij R2_ij - 1)/2, with respect to both
+    rotations, in float64 -- what autograd computes through geodesic (point_cloud/main.py:61-73: eps 1e-7, unit 1),
+    compute_geodesic_distance_from_two_matrices (rotation_representation.py:209-227: eps 0, unit 1) and angle_error (:230-242:
+    eps 0, unit 180/pi): tr(R1 R2^T) = tr(R1^T R2) = sum_ij R1_ij R2_ij, d acos(c)/dc = -1/sqrt(1 - c^2), and torch.clamp's /
+    torch.min's / torch.max's backward fill the gradient with 0 outside the clamp.  `upstream` = d loss / d theta per row (or one
+    number for all rows), divided by `divisor` (the mean's B).  clamp_dtype: the dtype the clamp's bounds are rounded to (float32 for
+    geodesic on float32 tensors).  Rows with c = +-1 exactly get 0 (the reference: -+inf); documented divergence.
+    Returns (dR1, dR2, c)."""
+    a = np.asarray(r1, dtype=np.float64).reshape(-1, 3, 3)
+    b = np.asarray(r2, dtype=np.float64).reshape(-1, 3, 3)
+    c = ((a * b).sum(axis=(1, 2)) - 1.0) / 2.0
+    lo = float(clamp_dtype(-1) + clamp_dtype(eps))
+    hi = float(clamp_dtype(1) - clamp_dtype(eps))
+    om = 1.0 - c * c
+    inside = (c >= lo) & (c <= hi) & (om > 0)
+    g = np.broadcast_to(np.asarray(upstream, dtype=np.float64), c.shape) / divisor
+    with np.errstate(divide="ignore", invalid="ignore"):
+        h = np.where(inside, g * unit * (-1.0 / np.sqrt(np.where(inside, om, 1.0))) / 2.0, 0.0)
+    h = np.where(np.isnan(c), np.nan, h)
+    return h[:, None, None] * b, h[:, None, None] * a, c
+
+
 def loss_frobenius_np(r_pred, r_true):
     """mean_b ||R_true - R_pred||_F, not squared (3D-Pose/loss.py:7-11)."""
     d = np.asarray(r_true, np.float64).reshape(-1, 3, 3) - np.asarray(r_pred, np.float64).reshape(-1, 3, 3)

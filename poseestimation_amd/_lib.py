@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libso3proj.so")
 
 # name -> (restype, argtypes); must list every symbol include/so3proj.h declares.
 _P, _I64, _I32, _INT, _U32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int, ctypes.c_uint32
-RADIANS, PREZEROED, EXACT_F64 = 1, 2, 4          # include/so3proj.h: SO3_RADIANS, SO3_PREZEROED, SO3_EXACT_F64
+RADIANS, PREZEROED, EXACT_F64, GRAD_SCALAR, F64_MATH = 1, 2, 4, 8, 16     # include/so3proj.h: SO3_RADIANS, SO3_PREZEROED, SO3_EXACT_F64, SO3_GRAD_SCALAR, SO3_F64_MATH
 SYMBOLS = {
     "so3_version": (_INT, []),
     "so3_last_error": (ctypes.c_char_p, []),
@@ -33,6 +33,9 @@ SYMBOLS = {
     "so3_project_angle_error_v2_f32": (_INT, [_P, _P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_geodesic_f32": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_geodesic_eps_f32": (_INT, [_P, _P, _P, _P, _P, _INT, ctypes.c_float, _P, _I64, _P]),
+    "so3_geodesic_eps_f64": (_INT, [_P, _P, _P, _P, _P, _INT, ctypes.c_double, _I64, _P]),
+    "so3_angle_bwd_f32": (_INT, [_P, _P, _P, ctypes.c_double, ctypes.c_double, _U32, _P, _P, _I64, _P]),
+    "so3_angle_bwd_f64": (_INT, [_P, _P, _P, ctypes.c_double, ctypes.c_double, _U32, _P, _P, _I64, _P]),
     "so3_angle_error_v2_f64": (_INT, [_P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
     "so3_geodesic_f64": (_INT, [_P, _P, _P, _I64, _P]),
     "so3_frob_loss_v2_f64": (_INT, [_P, _P, _P, _P, _P, _P, _U32, _I64, _P]),
@@ -57,7 +60,7 @@ SYMBOLS = {
     "so3_kabsch_synth_f32": (_INT, [_P, _P, ctypes.c_float, ctypes.c_uint32, _P, _P, _I64, _I32, _P]),
 }
 
-ABI_VERSION = 200                                 # include/so3proj.h: SO3PROJ_VERSION this binding's argument lists belong to
+ABI_VERSION = 210                                 # include/so3proj.h: SO3PROJ_VERSION this binding's argument lists belong to
 
 _lock = threading.Lock()
 _lib = None

@@ -1176,6 +1176,82 @@ struct OpGeodesic : OpBase {
     }
 };
 
+// K4b: the gradient of the three metric spellings -- what autograd computes through geodesic(R1, R2, reduction)
+// (point_cloud/main.py:61-73, whose eps = 1e-7 exists for exactly this gradient: the comment at :64), through
+// compute_geodesic_distance_from_two_matrices (rotation_representation.py:209-227) and through angle_error (:230-242) when a
+// training loop uses one of them as its `lossfunc` (point_cloud/main.py:194-197, UPNA/main.py:56-59).  With
+//     c_b = (sum_ij R1_b,ij R2_b,ij - 1) / 2,      theta_b = unit * acos(clamp(c_b, lo, hi)),
+// tr(R1 R2^T) = tr(R1^T R2) is symmetric in the two arguments:
+//     dR1_b = h_b R2_b,  dR2_b = h_b R1_b,   h_b = g_b * unit * (-1 / sqrt(1 - c_b^2)) / 2   where lo <= c_b <= hi,   0 outside
+// (torch.clamp's and torch.min / max's backward fill the gradient with 0 outside the clamp, so the reference never multiplies 0 by
+// the infinite slope of acos there; on the boundary c_b = +-1 EXACTLY the reference returns -+inf and this kernel 0).  g_b is the
+// upstream gradient: per row (GRAD 1: float32, GRAD 2: float64 as two dwords per row -- the engine's images are dwords) or ONE
+// value in device memory that every row shares (GRAD 0: the 0-dim tensor autograd hands to a "mean" / "sum"), divided by `div`
+// (the mean's B; torch divides, it does not multiply by 1/B).
+// F64MATH = angle_error's spelling: both rotations cast to float64 before the product (:232-233), every step in float64, the
+// result rounded to float32 ONCE (the backward of `.double()`); otherwise float32 throughout in the order of the float32 graph:
+// trace as OpGeodesic's, -c c + 1, rsqrt, times the upstream gradient, the clamp's mask, / 2, times the other rotation.
+// in0 = R1, in1 = R2, in2 = g (GRAD != 0); out0 = dR1, out1 = dR2 (BOTH).  One gradient alone: the host swaps R1 and R2.
+template <int GRAD, bool F64MATH, bool BOTH>
+struct OpAngleBwd : OpBase {
+    static_assert(GRAD == 0 || GRAD == (F64MATH ? 2 : 1), "the upstream gradient has the dtype of the metric's result");
+    static constexpr int kIn0 = 4, kIn1 = 4, kIn2 = GRAD != 0 ? 4 : 0, kOut0 = 4, kOut1 = BOTH ? 4 : 0;
+    static constexpr int kIn2N = GRAD == 2 ? 2 : 1;
+    const void *gscalar = nullptr;       // GRAD 0: one float32 (F64MATH: float64) in device memory
+    double lo = -1.0, hi = 1.0, unit = 1.0, div = 1.0;
+    template <class T, int NPL>
+    __device__ __forceinline__ void compute(Rows<T, OpAngleBwd> &rows, RowCtx<NPL> &) const {
+#pragma clang fp contract(off)            // the float32 graph rounds c c and 1 - c c separately
+        typedef Tr<T> R;
+        const T (&a)[9] = rows.a;
+        const T (&b)[9] = rows.b;
+        if constexpr (!F64MATH) {
+            const T d0 = R::fma(a[2], b[2], R::fma(a[1], b[1], a[0] * b[0]));       // the diagonal of m1 m2^T, as OpGeodesic sums it
+            const T d1 = R::fma(a[5], b[5], R::fma(a[4], b[4], a[3] * b[3]));
+            const T d2 = R::fma(a[8], b[8], R::fma(a[7], b[7], a[6] * b[6]));
+            const T cs = (d0 + d1 + d2 - R::splat(1.f)) * R::splat(0.5f);
+            const float lof = static_cast<float>(lo), hif = static_cast<float>(hi), divf = static_cast<float>(div), unitf = static_cast<float>(unit);
+            T h = R::splat(0.f);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const float c = R::get(cs, k);
+                float g;
+                if constexpr (GRAD == 0) g = *static_cast<const float *>(gscalar); else g = R::get(rows.c[0], k);
+                g = g / divf;
+                const float om = 1.f - c * c;
+                float s = (c >= lof && c <= hif && om > 0.f) ? g * -__builtin_amdgcn_rsqf(om) : 0.f;
+                if (c != c) s = c;                                   // NaN in -> NaN out
+                R::set(h, k, s * unitf * 0.5f);
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                rows.o0[i] = h * b[i];
+                if constexpr (BOTH) rows.o1[i] = h * a[i];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                double tr = 0.0;                                     // tr(R1^T R2) in float64, as OpAngle
+#pragma unroll
+                for (int i = 0; i < 9; ++i) tr = fma(static_cast<double>(R::get(a[i], k)), static_cast<double>(R::get(b[i], k)), tr);
+                const double c = (tr - 1.0) * 0.5;
+                double g;
+                if constexpr (GRAD == 0) g = *static_cast<const double *>(gscalar);
+                else g = __hiloint2double(__float_as_int(R::get(rows.c[1], k)), __float_as_int(R::get(rows.c[0], k)));
+                g = g / div;
+                const double om = 1.0 - c * c;
+                double h = (c >= lo && c <= hi && om > 0.0) ? (g * unit) * (-1.0 / __builtin_sqrt(om)) * 0.5 : 0.0;
+                if (c != c) h = c;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    R::set(rows.o0[i], k, static_cast<float>(h * static_cast<double>(R::get(b[i], k))));
+                    if constexpr (BOTH) R::set(rows.o1[i], k, static_cast<float>(h * static_cast<double>(R::get(a[i], k))));
+                }
+            }
+        }
+    }
+};
+
 #endif  // !SO3_HOST_MODEL
 
 // ---- next row f2: the 6D Gram-Schmidt head (rotation_representation.py:21-36) --------------------------------

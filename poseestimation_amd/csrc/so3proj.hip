@@ -546,6 +546,53 @@ __global__ __launch_bounds__(kBlock) void k_geodesic_f32(const float *__restrict
     }
 }
 
+// ---- K4b: backward of the metrics, one row per thread: the remainder (< 64 rows) and unaligned views of the streaming kernel; the
+// arithmetic is the engine operation's own (so3::OpAngleBwd::compute, one matrix per lane).  `g` = the per-row upstream gradient
+// (float32, or float64 with F64MATH) when the operation takes one.
+template <class Op>
+__global__ __launch_bounds__(kBlock) void k_angle_bwd_rows(Op op, const void *__restrict__ g, float *__restrict__ d1, float *__restrict__ d2, int64_t B) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (row >= B) return;
+    so3::RowCtx<1> ctx{};
+    so3::Rows<float, Op> rows;
+    const float *a = static_cast<const float *>(op.in0) + row * 9, *b = static_cast<const float *>(op.in1) + row * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { rows.a[i] = a[i]; rows.b[i] = b[i]; }
+    if constexpr (Op::kIn2 != 0) {
+        const float *gw = static_cast<const float *>(g) + row * Op::kIn2N;
+#pragma unroll
+        for (int i = 0; i < Op::kIn2N; ++i) rows.c[i] = gw[i];
+    }
+    op.template compute<float, 1>(rows, ctx);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        d1[row * 9 + i] = rows.o0[i];
+        if constexpr (Op::kOut1 != 0) d2[row * 9 + i] = rows.o1[i];
+    }
+}
+
+// The same gradient from float64 data (so3_angle_bwd_f64): one row per thread, grid-stride.  g: per-row, or one shared value (scalar).
+__global__ __launch_bounds__(kBlock) void k_angle_bwd_f64(const double *__restrict__ R1, const double *__restrict__ R2, const double *__restrict__ g,
+                                                          bool scalar, double div, double unit, double lo, double hi, double *__restrict__ d1,
+                                                          double *__restrict__ d2, int64_t B) {
+#pragma clang fp contract(off)
+    for (int64_t row = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; row < B; row += static_cast<int64_t>(gridDim.x) * kBlock) {
+        double a[9], b[9], tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { a[i] = R1[row * 9 + i]; b[i] = R2[row * 9 + i]; tr = fma(a[i], b[i], tr); }
+        const double c = (tr - 1.0) * 0.5;
+        const double up = (scalar ? g[0] : g[row]) / div;
+        const double om = 1.0 - c * c;
+        double h = (c >= lo && c <= hi && om > 0.0) ? (up * unit) * (-1.0 / __builtin_sqrt(om)) * 0.5 : 0.0;
+        if (c != c) h = c;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (d1 != nullptr) d1[row * 9 + i] = h * b[i];
+            if (d2 != nullptr) d2[row * 9 + i] = h * a[i];
+        }
+    }
+}
+
 // ---- K5 -------------------------------------------------------------------------------------------
 // One wave per cloud at a time; lane i takes points i, i+64, ... as 12-byte (dwordx3) loads, so each
 // wave-instruction reads 768 contiguous bytes.  The nine partial sums are reduced across the wave
@@ -1022,14 +1069,15 @@ __global__ __launch_bounds__(kBlock) void k_project_diag(const float *__restrict
 // ---- float64 arguments of the metrics and the loss (the reference's functions accept double tensors and, for the metrics,
 // cast to double themselves: rotation_representation.py:232-233) -- one row per thread straight from global memory: not a
 // benchmark path, but no ATen arithmetic either.  MODE 0: angle_error (float64, range flag, unit = 180/pi or 1);
-// MODE 1: compute_geodesic_distance_from_two_matrices (radians, hard clamp, no flag).
+// MODE 1: compute_geodesic_distance_from_two_matrices (radians, hard clamp, no flag);  MODE 2: geodesic(R1, R2, reduction)
+// (point_cloud/main.py:61-73: clamp to [lo, hi], the angles' sum added onto a zeroed accumulator).
 // Grid-stride (at most 2048 workgroups).  How the reduction is finished -- `how`: 0 = atomics onto accumulators an init launch has
 // zeroed; 1 = ONE workgroup (B <= 1024): it writes sum, count and flag itself; 2 = caller's workspace: partial per workgroup, a ticket,
 // the last one writes everything (so3_rows.h, ticket_finish).  1 and 2 are one launch per call.
 template <int MODE, bool WANT_ROWS, bool WANT_SUM>
 __global__ __launch_bounds__(kBlock) void k_angle_f64(const double *__restrict__ R1, const double *__restrict__ R2, double *__restrict__ out,
                                                       double *__restrict__ sum_count, int32_t *__restrict__ range_flag, double unit, int64_t B,
-                                                      so3::ReduceWs *ws, int how) {
+                                                      so3::ReduceWs *ws, int how, double lo = -1.0, double hi = 1.0) {
     __shared__ double red[4];
     double acc = 0.0;
     bool bad = false;
@@ -1039,7 +1087,7 @@ __global__ __launch_bounds__(kBlock) void k_angle_f64(const double *__restrict__
         for (int i = 0; i < 9; ++i) tr = fma(R1[row * 9 + i], R2[row * 9 + i], tr);
         const double c_raw = (tr - 1.0) * 0.5;
         bad |= MODE == 0 && (c_raw < -1.1 || c_raw > 1.1);
-        double c = fmin(fmax(c_raw, -1.0), 1.0);
+        double c = fmin(fmax(c_raw, lo), hi);
         if (c_raw != c_raw) c = c_raw;                          // clamp keeps NaN
         const double ang = so3::acos_f64(c) * unit;
         if (WANT_ROWS) out[row] = ang;
@@ -1047,6 +1095,7 @@ __global__ __launch_bounds__(kBlock) void k_angle_f64(const double *__restrict__
     }
     const bool any_bad = MODE == 0 && __syncthreads_or(bad ? 1 : 0) != 0;
     const double total = WANT_SUM ? block_sum(acc, red) : 0.0;
+    if (MODE == 2 && WANT_SUM && threadIdx.x == 0) atomicAdd(sum_count, total);
     if (MODE != 0) return;
     if (how == 2) {
         so3::ticket_finish<kBlock>(ws, blockIdx.x, gridDim.x, gridDim.x, total, any_bad, [&](double t, bool any) {
@@ -1278,6 +1327,7 @@ constexpr int kStatLdsKeys = 16384;                // candidates of one class th
 #define SO3_STAT_REPLICAS 4
 #endif
 constexpr int kStatReplicas = SO3_STAT_REPLICAS;
+static_assert(kStatReplicas >= 1 && kStatReplicas <= 16 && (kStatReplicas & (kStatReplicas - 1)) == 0, "SO3_STAT_REPLICAS: a power of two (stat_replica masks the XCD id with it)");
 struct StatWork {                                  // layout of the caller's workspace: zero-filled once, left zeroed by every call (up to `hist` included)
     double acc[kStatReplicas][kMaxClasses][4];     // sum, sumsq, max (bits), nan_count
     unsigned int overflow, ticket;                 // some collecting workgroup's staging overflowed; collecting workgroups that have published their candidates
@@ -2085,6 +2135,29 @@ int launch_add_l1(const float *Tgt, const float *Tpred, const float *points, flo
 }
 }  // namespace
 
+// ---- K4b: the metrics' backward (include/so3proj.h) ------------------------------------------------------------------
+namespace {
+template <int GRAD, bool F64MATH, bool BOTH>
+void angle_bwd_launch(const float *R1, const float *R2, const void *grad, double div, double unit, double lo, double hi, float *d1, float *d2,
+                      int64_t B, hipStream_t s) {
+    so3::OpAngleBwd<GRAD, F64MATH, BOTH> op;
+    op.in0 = R1; op.in1 = R2; op.out0 = d1; op.out1 = d2;
+    op.lo = lo; op.hi = hi; op.unit = unit; op.div = div;
+    if (GRAD == 0) op.gscalar = grad; else op.in2 = grad;
+    const int64_t nunits = stream_units(B, {R1, R2, GRAD != 0 ? grad : nullptr, d1, d2});
+    // light arithmetic, 108-152 B per row: two rows per lane, three waves per SIMD (11 KB of LDS per wave)
+    if (nunits > 0) launch_rows<2, 3, 256>(op, nunits, s);
+    const int64_t done = nunits * so3::kUnitRows, rest = B - done;
+    if (rest > 0) {
+        so3::OpAngleBwd<GRAD, F64MATH, BOTH> t = op;
+        t.in0 = R1 + done * 9; t.in1 = R2 + done * 9;
+        const void *g = GRAD != 0 ? advance_bytes(grad, done * (F64MATH ? 8 : 4)) : nullptr;
+        hipLaunchKernelGGL((k_angle_bwd_rows<so3::OpAngleBwd<GRAD, F64MATH, BOTH>>), dim3(grid_for(rest)), dim3(kBlock), 0, s, t, g, d1 + done * 9,
+                           advance(d2, done * 9), rest);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int so3_version(void) { return SO3PROJ_VERSION; }
@@ -2296,6 +2369,7 @@ static int reduce_how(void *workspace, int64_t B, unsigned *grid) {
 
 int so3_angle_error_v2_f64(const double *R1, const double *R2, double *deg, double *sum_count, int32_t *range_flag, void *workspace,
                            unsigned flags, int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_RADIANS)) == 0, "so3_angle_error_v2_f64: unknown flag (SO3_RADIANS only)");
     const bool radians = (flags & SO3_RADIANS) != 0;
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_error_v2_f64: B");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2325,7 +2399,7 @@ int so3_geodesic_f64(const double *R1, const double *R2, double *theta, int64_t 
 
 int so3_frob_loss_v2_f64(const double *Rpred, const double *Rtrue, double *dRpred, double *loss_sum, double *loss_mean, void *workspace,
                          unsigned flags, int64_t B, void *stream) {
-    (void)flags;
+    SO3_CHECK_ARGS(flags == 0, "so3_frob_loss_v2_f64: unknown flag (none is defined for it)");
     SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_frob_loss_v2_f64: B");
     SO3_CHECK_ARGS(loss_sum != nullptr, "so3_frob_loss_v2_f64: loss_sum is null");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -2395,6 +2469,70 @@ int so3_geodesic_eps_f32(const float *R1, const float *R2, float *theta, double 
                          void *stream) {
     SO3_CHECK_ARGS(result == nullptr || sum != nullptr, "so3_geodesic_eps_f32: result needs the float64 scratch `sum`");
     return geodesic_f32(R1, R2, theta, sum, result, mean, eps, workspace, B, stream, "so3_geodesic_eps_f32");
+}
+
+int so3_angle_bwd_f32(const float *R1, const float *R2, const void *grad, double grad_div, double eps, unsigned flags, float *dR1, float *dR2,
+                      int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_RADIANS | SO3_GRAD_SCALAR | SO3_F64_MATH)) == 0, "so3_angle_bwd_f32: unknown flag");
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_bwd_f32: B");
+    SO3_CHECK_ARGS(eps >= 0.0 && eps < 1.0 && grad_div != 0.0, "so3_angle_bwd_f32: eps / grad_div");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && grad != nullptr && (dR1 != nullptr || dR2 != nullptr), "so3_angle_bwd_f32: null pointer");
+    const bool f64 = (flags & SO3_F64_MATH) != 0, scalar = (flags & SO3_GRAD_SCALAR) != 0;
+    SO3_CHECK_ARGS((reinterpret_cast<uintptr_t>(grad) & (f64 ? 7u : 3u)) == 0, "so3_angle_bwd_f32: grad is not aligned to its element");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double unit = (flags & SO3_RADIANS) != 0 ? 1.0 : 57.295779513082320876798154814105;
+    // the clamp's bounds in the arithmetic of the spelling (torch.clamp's scalars on a float32 tensor are float32)
+    const double lo = f64 ? -1.0 + eps : static_cast<double>(-1.f + static_cast<float>(eps));
+    const double hi = f64 ? 1.0 - eps : static_cast<double>(1.f - static_cast<float>(eps));
+    // one gradient alone: tr(R1 R2^T) is symmetric in its arguments, so dR2 is dR1 of the swapped pair
+    const bool both = dR1 != nullptr && dR2 != nullptr;
+    const float *A = dR1 != nullptr ? R1 : R2, *Bm = dR1 != nullptr ? R2 : R1;
+    float *d1 = dR1 != nullptr ? dR1 : dR2, *d2 = both ? dR2 : nullptr;
+#define GO(GR, F6, BO) angle_bwd_launch<GR, F6, BO>(A, Bm, grad, grad_div, unit, lo, hi, d1, d2, B, s)
+#define PICK(F6, PER) do { if (scalar) { if (both) GO(0, F6, true); else GO(0, F6, false); } \
+                           else { if (both) GO(PER, F6, true); else GO(PER, F6, false); } } while (0)
+    if (f64) PICK(true, 2); else PICK(false, 1);
+#undef PICK
+#undef GO
+    return check_launch("so3_angle_bwd_f32");
+}
+
+int so3_angle_bwd_f64(const double *R1, const double *R2, const double *grad, double grad_div, double eps, unsigned flags, double *dR1, double *dR2,
+                      int64_t B, void *stream) {
+    SO3_CHECK_ARGS((flags & ~static_cast<unsigned>(SO3_RADIANS | SO3_GRAD_SCALAR)) == 0, "so3_angle_bwd_f64: unknown flag");
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B, "so3_angle_bwd_f64: B");
+    SO3_CHECK_ARGS(eps >= 0.0 && eps < 1.0 && grad_div != 0.0, "so3_angle_bwd_f64: eps / grad_div");
+    if (B == 0) return 0;
+    SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && grad != nullptr && (dR1 != nullptr || dR2 != nullptr), "so3_angle_bwd_f64: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double unit = (flags & SO3_RADIANS) != 0 ? 1.0 : 57.295779513082320876798154814105;
+    const unsigned want = grid_for(B);
+    hipLaunchKernelGGL(k_angle_bwd_f64, dim3(want < 2048u ? want : 2048u), dim3(kBlock), 0, s, R1, R2, grad, (flags & SO3_GRAD_SCALAR) != 0, grad_div,
+                       unit, -1.0 + eps, 1.0 - eps, dR1, dR2, B);
+    return check_launch("so3_angle_bwd_f64");
+}
+
+int so3_geodesic_eps_f64(const double *R1, const double *R2, double *theta, double *sum, double *result, int mean, double eps, int64_t B,
+                         void *stream) {
+    SO3_CHECK_ARGS(B >= 0 && B <= SO3_MAX_B && eps >= 0.0 && eps < 1.0, "so3_geodesic_eps_f64: B / eps");
+    SO3_CHECK_ARGS(result == nullptr || sum != nullptr, "so3_geodesic_eps_f64: result needs the scratch `sum`");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sum != nullptr) {
+        const hipError_t e = hipMemsetAsync(sum, 0, sizeof(double), s);
+        if (e != hipSuccess) return fail(static_cast<int>(e), "so3_geodesic_eps_f64: memset");
+    }
+    if (B > 0) {
+        SO3_CHECK_ARGS(R1 != nullptr && R2 != nullptr && (theta != nullptr || sum != nullptr), "so3_geodesic_eps_f64: null pointer");
+        const unsigned want = grid_for(B);
+        const dim3 grid(want < 2048u ? want : 2048u), block(kBlock);
+        if (theta && sum) hipLaunchKernelGGL((k_angle_f64<2, true, true>), grid, block, 0, s, R1, R2, theta, sum, nullptr, 1.0, B, nullptr, 0, -1.0 + eps, 1.0 - eps);
+        else if (theta) hipLaunchKernelGGL((k_angle_f64<2, true, false>), grid, block, 0, s, R1, R2, theta, sum, nullptr, 1.0, B, nullptr, 0, -1.0 + eps, 1.0 - eps);
+        else hipLaunchKernelGGL((k_angle_f64<2, false, true>), grid, block, 0, s, R1, R2, theta, sum, nullptr, 1.0, B, nullptr, 0, -1.0 + eps, 1.0 - eps);
+    }
+    // (torch's mean of an empty tensor is NaN, its sum 0)
+    if (result != nullptr) k_mean_from_sum_f64<<<1, 1, 0, s>>>(sum, result, mean ? 1.0 / static_cast<double>(B) : 1.0);
+    return check_launch("so3_geodesic_eps_f64");
 }
 
 int so3_ortho6d_fwd_f32(const float *X, float *R, int64_t B, void *stream) {

@@ -413,6 +413,80 @@ def _angle_call_f64(r1, r2, want_rows, want_sum, radians=False, geodesic=False):
     return rows, sc, flag
 
 
+def _wants_grad(*ts) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
+def _metric_backward(ctx, grad, eps: float, radians: bool, f64_math: bool, divisor: float):
+    """dR1, dR2 of a metric spelling for the upstream gradient `grad` (K4b, so3_angle_bwd_*): one launch writes the gradients the
+    graph needs.  An upstream gradient that autograd EXPANDED from one element (the backward of .mean() / .sum() on the per-row
+    result) travels as that one element; a 0-dim one (geodesic's own reductions) likewise -- a device pointer, no host sync."""
+    _no_double_backward(grad)
+    a, b_ = ctx.saved_tensors
+    need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    (shape1, dtype1), (shape2, dtype2) = ctx.meta
+    if not (need1 or need2):
+        return None, None
+    dev = a.device
+    n = a.shape[0]
+    data64 = a.dtype is torch.float64
+    g_dtype = torch.float64 if (data64 or f64_math) else torch.float32
+    if grad.dim() == 0 or (grad.dim() == 1 and n > 1 and grad.stride(0) == 0):
+        g = grad.reshape(-1)[:1]
+        scalar = True
+    else:
+        g = grad.reshape(-1)
+        scalar = False
+        if g.shape[0] != n:
+            raise RuntimeError(f"metric backward: {g.shape[0]} upstream gradients for {n} rows")
+    if g.dtype is not g_dtype:
+        g = g.to(g_dtype)
+    if not g.is_contiguous():
+        g = g.contiguous()
+    d1 = torch.empty_like(a) if need1 else None
+    d2 = torch.empty_like(a) if need2 else None
+    if n > 0:
+        flags = (_lib.RADIANS if radians else 0) | (_lib.GRAD_SCALAR if scalar else 0)
+        with _on_device(dev):
+            if data64:
+                _check(_libh().so3_angle_bwd_f64(a.data_ptr(), b_.data_ptr(), g.data_ptr(), divisor, eps, flags, _ptr(d1), _ptr(d2), n, _stream(dev)),
+                       "so3_angle_bwd_f64")
+            else:
+                _check(_libh().so3_angle_bwd_f32(a.data_ptr(), b_.data_ptr(), g.data_ptr(), divisor, eps, flags | (_lib.F64_MATH if f64_math else 0),
+                                                 _ptr(d1), _ptr(d2), n, _stream(dev)), "so3_angle_bwd_f32")
+    if d1 is not None:
+        d1 = (d1 if d1.dtype is dtype1 else d1.to(dtype1)).view(shape1)
+    if d2 is not None:
+        d2 = (d2 if d2.dtype is dtype2 else d2.to(dtype2)).view(shape2)
+    return d1, d2
+
+
+def _save_metric_inputs(ctx, r1, r2, f64: bool):
+    """The (B,9) blocks the backward reads (the arguments themselves when they are contiguous float32 / float64 already)."""
+    blocks = _f64_blocks if f64 else _f32_blocks
+    a, b_ = blocks(r1), blocks(r2)
+    ctx.save_for_backward(a, b_)
+    ctx.meta = ((r1.shape, r1.dtype), (r2.shape, r2.dtype))
+    return a, b_
+
+
+class _AngleError(torch.autograd.Function):
+    """angle_error as a graph node: the reference's function is plain differentiable tensor code (rotation_representation.py:230-242)."""
+
+    @staticmethod
+    def forward(ctx, r1, r2, check):
+        f64 = _is_f64(r1, r2)
+        a, b_ = _save_metric_inputs(ctx, r1, r2, f64)
+        deg, _, flag = (_angle_call_f64 if f64 else _angle_call)(a, b_, True, False)
+        if check and int(flag.item()) != 0:
+            raise ValueError(_RANGE_MSG)
+        return deg
+
+    @staticmethod
+    def backward(ctx, grad_deg):
+        return (*_metric_backward(ctx, grad_deg, 0.0, False, True, 1.0), None)
+
+
 def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> torch.Tensor:
     """Geodesic angle between rotations, float64 degrees, shape (B,).
 
@@ -422,7 +496,13 @@ def angle_error(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = True) -> t
 
     float64 arguments (the reference casts to float64 before the product, :232-233): K4 reads float32 data, so
     double tensors go to its float64 twin (so3_angle_error_v2_f64) instead of being rounded.
+
+    Differentiable with respect to both arguments, like the reference's tensor code (K4b, so3_angle_bwd_*: the float64
+    expression's gradient, rounded once to the argument's dtype; rows on the clamp get 0, as torch.clamp's backward gives).
     """
+    if _wants_grad(t_R1, t_R2):
+        _require_device(t_R1, t_R2)
+        return _AngleError.apply(t_R1, t_R2, check)
     if _is_f64(t_R1, t_R2):
         deg, _, flag = _angle_call_f64(t_R1, t_R2, True, False)
     else:
@@ -487,15 +567,10 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     return (out, r) if return_rotation else out
 
 
-def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
-    """Geodesic distance in radians, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,); the arguments' dtype as the
-    reference (rotation_representation.py:209-227): float32 through K4', float64 through so3_geodesic_f64."""
-    dev = _require_device(m1, m2)
-    if _is_f64(m1, m2):
-        return _angle_call_f64(m1, m2, True, False, geodesic=True)[0]
-    a, b_ = _f32_blocks(m1), _f32_blocks(m2)
-    if a.shape != b_.shape:
-        raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
+def _geodesic_rows(a, b_, dev):
+    """K4' on (B,9) float32 / float64 blocks: radians, hard clamp."""
+    if a.dtype is torch.float64:
+        return _angle_call_f64(a, b_, True, False, geodesic=True)[0]
     n = a.shape[0]
     theta = torch.empty((n,), dtype=torch.float32, device=dev)
     with _on_device(dev):
@@ -503,26 +578,87 @@ def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tens
     return theta
 
 
+class _GeodesicDistance(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m1, m2):
+        a, b_ = _save_metric_inputs(ctx, m1, m2, _is_f64(m1, m2))
+        return _geodesic_rows(a, b_, a.device)
+
+    @staticmethod
+    def backward(ctx, grad_theta):
+        return _metric_backward(ctx, grad_theta, 0.0, True, False, 1.0)
+
+
+def compute_geodesic_distance_from_two_matrices(m1: torch.Tensor, m2: torch.Tensor) -> torch.Tensor:
+    """Geodesic distance in radians, tr(m1 m2^T), hard clamp to [-1, 1]; shape (B,); the arguments' dtype as the
+    reference (rotation_representation.py:209-227): float32 through K4', float64 through so3_geodesic_f64.
+    Differentiable with respect to both arguments (K4b; a row on the clamp gets 0, as torch.min / torch.max's backward gives)."""
+    dev = _require_device(m1, m2)
+    f64 = _is_f64(m1, m2)
+    if not f64 and _as_blocks(m1).shape != _as_blocks(m2).shape:
+        raise RuntimeError(f"geodesic: shape mismatch {tuple(m1.shape)} vs {tuple(m2.shape)}")
+    if _wants_grad(m1, m2):
+        return _GeodesicDistance.apply(m1, m2)
+    if f64:
+        return _angle_call_f64(m1, m2, True, False, geodesic=True)[0]
+    return _geodesic_rows(_f32_blocks(m1), _f32_blocks(m2), dev)
+
+
+def _geodesic_eps(a, b_, reduction, dev):
+    """geodesic(...)'s launch on (B,9) blocks: float32 through so3_geodesic_eps_f32, float64 through its twin."""
+    n = a.shape[0]
+    dt = a.dtype
+    f64 = dt is torch.float64
+    theta = torch.empty((n,), dtype=dt, device=dev) if reduction == "none" else None
+    acc = None if reduction == "none" else torch.empty((1,), dtype=torch.float64, device=dev)
+    out = None if reduction == "none" else torch.empty((), dtype=dt, device=dev)
+    with _on_device(dev):
+        st = _stream(dev)
+        if f64:
+            _check(_libh().so3_geodesic_eps_f64(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7, n, st),
+                   "so3_geodesic_eps_f64")
+        else:
+            ws = _workspace(dev, st) if reduction != "none" else None           # the kernel's last workgroup writes the reduced value
+            _check(_libh().so3_geodesic_eps_f32(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7,
+                                                _ptr(ws), n, st), "so3_geodesic_eps_f32")
+    return theta if reduction == "none" else out
+
+
+class _Geodesic(torch.autograd.Function):
+    """geodesic(R1, R2, reduction) as a graph node: the use its eps was written for (point_cloud/main.py:64)."""
+
+    @staticmethod
+    def forward(ctx, r1, r2, reduction):
+        a, b_ = _save_metric_inputs(ctx, r1, r2, _is_f64(r1, r2))
+        ctx.divisor = float(a.shape[0]) if reduction == "mean" else 1.0
+        return _geodesic_eps(a, b_, reduction, a.device)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.divisor == 0.0:                        # the mean of no rows: no rows to send a gradient to
+            (s1, d1), (s2, d2) = ctx.meta
+            a, _ = ctx.saved_tensors
+            return (torch.zeros(s1, dtype=d1, device=a.device) if ctx.needs_input_grad[0] else None,
+                    torch.zeros(s2, dtype=d2, device=a.device) if ctx.needs_input_grad[1] else None, None)
+        return (*_metric_backward(ctx, grad, 1e-7, True, False, ctx.divisor), None)
+
+
 def geodesic(R1: torch.Tensor, R2: torch.Tensor, reduction: str = "mean"):
-    """point_cloud/main.py:61-73: acos(clamp((tr(R1 R2^T) - 1)/2, -1 + 1e-7, 1 - 1e-7)) in float32, radians;
-    reduction "none" -> (B,), "mean" / "sum" -> 0-dim float32; any other string returns None, as the reference's if-chain does.
-    Angles and their sum leave one launch (float64 accumulation; the reference's float32 .mean() agrees to its own round-off)."""
+    """point_cloud/main.py:61-73: acos(clamp((tr(R1 R2^T) - 1)/2, -1 + 1e-7, 1 - 1e-7)), radians, in the arguments' dtype (float32
+    on the hot path; float64 arguments go to the float64 twin);
+    reduction "none" -> (B,), "mean" / "sum" -> 0-dim; any other string returns None, as the reference's if-chain does.
+    Angles and their sum leave one launch (float64 accumulation; the reference's float32 .mean() agrees to its own round-off).
+    Differentiable with respect to both arguments (K4b, so3_angle_bwd_*): one launch for dR1 and dR2, the reduction's 1/B folded in."""
     dev = _require_device(R1, R2)
-    a, b_ = _f32_blocks(R1), _f32_blocks(R2)
-    if a.shape != b_.shape:
+    f64 = _is_f64(R1, R2)
+    blocks = _f64_blocks if f64 else _f32_blocks
+    if _as_blocks(R1).shape != _as_blocks(R2).shape:
         raise RuntimeError(f"geodesic: shape mismatch {tuple(R1.shape)} vs {tuple(R2.shape)}")
     if reduction not in ("none", "mean", "sum"):
         return None
-    n = a.shape[0]
-    theta = torch.empty((n,), dtype=torch.float32, device=dev) if reduction == "none" else None
-    acc = None if reduction == "none" else torch.empty((1,), dtype=torch.float64, device=dev)
-    out = None if reduction == "none" else torch.empty((), dtype=torch.float32, device=dev)
-    with _on_device(dev):
-        st = _stream(dev)
-        ws = _workspace(dev, st) if reduction != "none" else None               # the kernel's last workgroup writes the reduced value
-        _check(_libh().so3_geodesic_eps_f32(_ptr(a), _ptr(b_), _ptr(theta), _ptr(acc), _ptr(out), 1 if reduction == "mean" else 0, 1e-7,
-                                            _ptr(ws), n, st), "so3_geodesic_eps_f32")
-    return theta if reduction == "none" else out
+    if _wants_grad(R1, R2):
+        return _Geodesic.apply(R1, R2, reduction)
+    return _geodesic_eps(blocks(R1), blocks(R2), reduction, dev)
 
 
 # --------------------------------------------------------------------------------------------

@@ -45,17 +45,17 @@ def test_a_library_of_another_abi_version_is_refused(built_library, monkeypatch)
     from poseestimation_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "ABI_VERSION", 100)
-    with pytest.raises(ImportError, match="ABI version 200"):
+    with pytest.raises(ImportError, match="ABI version 210"):
         _lib.load()
-    monkeypatch.setattr(_lib, "ABI_VERSION", 200)
-    assert _lib.load().so3_version() == 200
+    monkeypatch.setattr(_lib, "ABI_VERSION", 210)
+    assert _lib.load().so3_version() == 210
 
 
 def test_binding_table_matches_header(built_library):
     from poseestimation_amd import _lib
     assert sorted(_lib.SYMBOLS) == header_symbols()
     lib = _lib.load()
-    assert lib.so3_version() == 200 == _lib.ABI_VERSION
+    assert lib.so3_version() == 210 == _lib.ABI_VERSION
     assert lib.so3_last_error() == b""
 
 
@@ -181,8 +181,8 @@ def test_fastcall_module_reaches_the_library_without_a_gpu():
     from poseestimation_amd import _so3fast
     lib = _lib.load()
     addr = lambda name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
-    assert _so3fast.call(addr("so3_version")) == lib.so3_version() == 200
-    assert _so3fast.call(addr("so3_version"), 1, None, 2 ** 63 + 5, -1) == 200          # extra integer arguments are ignored
+    assert _so3fast.call(addr("so3_version")) == lib.so3_version() == 210
+    assert _so3fast.call(addr("so3_version"), 1, None, 2 ** 63 + 5, -1) == 210          # extra integer arguments are ignored
     assert _so3fast.call(addr("so3_scale_f32"), None, None, None, 5, None) != 0          # null pointers: SO3_ERR_INVALID
     assert b"so3_scale_f32" in lib.so3_last_error()
     assert _so3fast.call(addr("so3_project_fwd_f32"), None, None, None, 0, None) == 0     # B = 0: nothing to do, no launch

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ROOT, load_golden, orth_err, well_conditioned
+from conftest import METRIC_GRAD_CASES, ROOT, load_golden, metric_grad_check, orth_err, well_conditioned
 
 pytestmark = pytest.mark.gpu
 
@@ -668,6 +668,143 @@ def _haar_rows(n, gen):
     w, x, y, z = q.unbind(1)
     return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
                         2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# K4b: the metrics are differentiable, like the reference's tensor code (G15)
+# ------------------------------------------------------------------------------------------------
+def _metric_call(rr, name, a, b):
+    if name.startswith("geo_"):
+        return rr.geodesic(a, b, name[4:])
+    if name == "cgd":
+        return rr.compute_geodesic_distance_from_two_matrices(a, b)
+    out = rr.angle_error(a, b)
+    return out.mean() if name == "ang_mean" else out
+
+
+def test_g15_metric_gradients_against_the_reference(rr):
+    """loss.backward() through geodesic / compute_geodesic_distance_from_two_matrices / angle_error against autograd through the
+    reference's own functions (tools/gen_golden.py g15): both arguments, float32 and float64 tensors, per-row and reduced forms,
+    pairs at 0 and 180 degrees (gradient exactly 0 on the clamp, as the reference's masked fill gives) and at 1e-4 rad.
+    Tolerance: the slope's conditioning times a few float32 ulps of the cosine (conftest.metric_grad_check); float64 graphs 1e-12."""
+    g = load_golden("g15_metric_gradients.npz")
+    ambiguous = 0
+    for tag in ("g3", "haar"):
+        n = g[tag + "_r1"].shape[0]
+        c64 = (np.einsum("bij,bij->b", g[tag + "_r1"].astype(np.float64), g[tag + "_r2"].astype(np.float64)) - 1) / 2
+        for name, (eps, unit, div, up) in METRIC_GRAD_CASES.items():
+            for dt, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+                key = "%s_%s_%s" % (tag, name, dt)
+                a = dev(g[tag + "_r1"], tdt).requires_grad_(True)
+                b = dev(g[tag + "_r2"], tdt).requires_grad_(True)
+                y = _metric_call(rr, name, a, b)
+                assert y.requires_grad and y.grad_fn is not None, key
+                assert y.dtype == (torch.float64 if name.startswith("ang") else tdt), key
+                ref_y = g[key + "_y"].astype(np.float64)
+                got_y = y.detach().double().cpu().numpy()
+                if name in ("geo_mean", "geo_sum", "ang_mean"):
+                    assert abs(got_y - ref_y) <= 3e-6 * abs(ref_y) + 1e-5, key
+                else:
+                    assert np.abs(np.cos(got_y / unit) - np.cos(ref_y / unit)).max() < 1e-6, key
+                if up == "w":
+                    y.backward(dev(g[tag + "_w"], y.dtype))
+                else:
+                    y.backward()
+                assert a.grad.dtype == tdt and a.grad.shape == a.shape and b.grad.shape == b.shape
+                f64_graph = dt == "f64" or name.startswith("ang")
+                ambiguous += metric_grad_check(a.grad.cpu().numpy(), b.grad.cpu().numpy(), g[key + "_d1"], g[key + "_d2"], c64, eps,
+                                               1e-15 if f64_graph else 6e-7, 1e-12 if dt == "f64" else 4e-7, key)
+                # rows 0, 1 of G3: 0 and 180 degrees -- finite everywhere, and 0 where the reference has 0
+                assert torch.isfinite(a.grad).all() and torch.isfinite(b.grad).all(), key
+                if tag == "g3":
+                    for row in (0, 1):
+                        if not np.any(g[key + "_d1"][row]):
+                            assert not a.grad[row].any() and not b.grad[row].any(), (key, row)
+    assert ambiguous < 40
+
+
+def test_metric_gradients_on_large_ragged_batches_and_views(rr):
+    """K4b on the streaming engine and its remainder kernel against the float64 closed form (oracle.metric_backward_np): 100 003
+    rows (an odd number of 64-row units plus 35 rows), a view 36 bytes into its tensor, one gradient alone (either argument),
+    an upstream gradient per row and one expanded by .sum() / .mean(), and the three spellings' units and clamps."""
+    from oracle import so3_oracle as so
+    gen = torch.Generator(device=DEV).manual_seed(150)
+    n = 100_003
+    big_a, big_b = _haar_rows(n + 1, gen), _haar_rows(n + 1, gen)
+    big_b[5] = big_a[5]                                                   # 0 degrees
+    big_b[6] = (big_a[6].view(3, 3) @ torch.diag(torch.tensor([1.0, -1.0, -1.0], device=DEV))).reshape(9)     # 180 degrees
+    w = torch.randn(n + 1, device=DEV, generator=gen)
+    for lo in (0, 1):
+        an, bn, wn = big_a[lo:lo + n].cpu().numpy(), big_b[lo:lo + n].cpu().numpy(), w[lo:lo + n].cpu().numpy()
+        for name, (eps, unit, div, up) in METRIC_GRAD_CASES.items():
+            a = big_a[lo:lo + n].detach().requires_grad_(True)
+            b = big_b[lo:lo + n].detach().requires_grad_(True)
+            y = _metric_call(rr, name, a, b)
+            if up == "w":
+                y.backward(w[lo:lo + n].to(y.dtype))
+            else:
+                y.backward()
+            f64_graph = name.startswith("ang")
+            d1, d2, c = so.metric_backward_np(an, bn, wn if up == "w" else 1.0, eps=eps, unit=unit, divisor=float(n) if div == "B" else 1.0,
+                                              clamp_dtype=np.float64 if f64_graph else np.float32)
+            metric_grad_check(a.grad.cpu().numpy(), b.grad.cpu().numpy(), d1, d2, c, eps, 1e-15 if f64_graph else 6e-7, 4e-7, (name, lo))
+            assert torch.isfinite(a.grad).all() and torch.isfinite(b.grad).all()
+    # one gradient alone: the first argument's, then the second's (the library swaps the pair), bit for bit the two-gradient launch's
+    a = big_a[:n].detach().requires_grad_(True)
+    b = big_b[:n].detach().requires_grad_(True)
+    rr.geodesic(a, b, "sum").backward()
+    a1 = big_a[:n].detach().requires_grad_(True)
+    rr.geodesic(a1, big_b[:n], "sum").backward()
+    b1 = big_b[:n].detach().requires_grad_(True)
+    rr.geodesic(big_a[:n], b1, "sum").backward()
+    assert torch.equal(a1.grad, a.grad) and torch.equal(b1.grad, b.grad)
+    # .sum() / .mean() on the per-row forms hand an EXPANDED gradient over: it travels as one element, and gives what the reduced forms give
+    a2 = big_a[:n].detach().requires_grad_(True)
+    rr.geodesic(a2, big_b[:n], "none").sum().backward()
+    assert torch.equal(a2.grad, a.grad)
+    a3 = big_a[:n].detach().requires_grad_(True)
+    (3.0 * rr.angle_error(a3, big_b[:n]).mean()).backward()
+    d1, _, c = so.metric_backward_np(big_a[:n].cpu().numpy(), big_b[:n].cpu().numpy(), 3.0, unit=180.0 / np.pi, divisor=float(n))
+    metric_grad_check(a3.grad.cpu().numpy(), a3.grad.cpu().numpy(), d1, d1, c, 0.0, 1e-15, 4e-7, "3 * angle_error.mean()")
+    # shapes, dtypes and the no-graph path
+    x9 = big_a[:64].reshape(64, 9).detach().requires_grad_(True)
+    rr.compute_geodesic_distance_from_two_matrices(x9.view(64, 3, 3), big_b[:64]).sum().backward()
+    assert x9.grad.shape == (64, 9)
+    h = big_a[:128].half().requires_grad_(True)
+    rr.geodesic(h, big_b[:128]).backward()
+    assert h.grad.dtype == torch.float16 and h.grad.shape == h.shape
+    with torch.no_grad():
+        assert rr.geodesic(a, b).grad_fn is None and not rr.angle_error(a, b).requires_grad
+    assert not rr.geodesic(big_a[:n], big_b[:n]).requires_grad
+    e = torch.zeros(0, 3, 3, device=DEV, requires_grad=True)
+    rr.geodesic(e, torch.zeros(0, 3, 3, device=DEV), "sum").backward()
+    assert e.grad.shape == (0, 3, 3)
+    # a second derivative is refused loudly, never returned wrong: the backward's result is a constant of the graph
+    with pytest.raises(RuntimeError, match="differentiate twice|does not require grad"):
+        a4 = big_a[:64].detach().requires_grad_(True)
+        (ga,) = torch.autograd.grad(rr.geodesic(a4, big_b[:64]), a4, create_graph=True)
+        ga.sum().backward()
+
+
+def test_a_geodesic_loss_trains_the_head_like_the_reference_graph(rr):
+    """`lossfunc` = geodesic in the reference's loops (point_cloud/main.py:194-197, UPNA/main.py:56-59): head -> metric -> backward,
+    against the same chain in float64 torch (the oracle's port of the head and autograd through the reference's expression)."""
+    from oracle import so3_oracle as so
+    torch.manual_seed(77)
+    x = torch.randn(4096, 9)
+    t = so.symmetric_orthogonalization_torch(torch.randn(4096, 9))
+    xd = x.to(DEV).requires_grad_(True)
+    loss = rr.loss_frobenius(t.to(DEV), rr.symmetric_orthogonalization(xd)) + 0.5 * rr.geodesic(t.to(DEV), rr.symmetric_orthogonalization(xd))
+    loss.backward()
+    xr = x.double().requires_grad_(True)
+    rd = so.symmetric_orthogonalization_torch(xr)
+    cos = ((t.double() @ rd.transpose(1, 2)).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+    ref = so.loss_frobenius_torch(rd, t.double()) + 0.5 * torch.acos(torch.clamp(cos, -1 + 1e-7, 1 - 1e-7)).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5
+    err = (xd.grad.cpu().double() - xr.grad).abs().reshape(4096, -1).amax(1)
+    scale = xr.grad.abs().reshape(4096, -1).amax(1)
+    assert torch.median(err / scale) < 2e-6 and (err <= 2e-3 * scale + 1e-9).float().mean() > 0.995
 
 
 def test_g4_backward_generic_gradient(rr):

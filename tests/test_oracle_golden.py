@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, orth_err, well_conditioned
+from conftest import METRIC_GRAD_CASES, load_golden, metric_grad_check, orth_err, well_conditioned
 from oracle import so3_oracle as so
 
 # names in g2_adversarial whose projection is unique (rank >= 2 and no s2==s3 flip degeneracy)
@@ -115,6 +115,28 @@ def test_g14_geodesic_with_reduction():
         assert abs(float(so.geodesic_eps_np(a, b, "sum")) - float(g[tag + "_sum"])) < 2e-6 * float(g[tag + "_sum"]) + 3e-3
     assert so.geodesic_eps_np(g["a"], g["b"], "median") is None
     assert list(g["dtypes"]) == ["torch.float32"] * 3
+
+
+def test_g15_metric_gradients():
+    """The closed form of the metrics' gradient (oracle.metric_backward_np: what K4b computes) against autograd through the
+    reference's three spellings, both arguments, float32 and float64 graphs, 0 / 180 degrees and 1e-4 rad included."""
+    g = load_golden("g15_metric_gradients.npz")
+    assert list(g["dtypes"]) == ["torch.float64", "torch.float32", "torch.float32", "torch.float64"]
+    ambiguous = 0
+    for tag in ("g3", "haar"):
+        n = g[tag + "_r1"].shape[0]
+        for name, (eps, unit, div, up) in METRIC_GRAD_CASES.items():
+            for dt, np_dt in (("f32", np.float32), ("f64", np.float64)):
+                key = "%s_%s_%s" % (tag, name, dt)
+                a, b = g[tag + "_r1"].astype(np_dt), g[tag + "_r2"].astype(np_dt)
+                f64_graph = dt == "f64" or name.startswith("ang")            # angle_error casts to float64 itself
+                # geodesic's clamp bounds are float32 scalars on a float32 tensor
+                d1, d2, c = so.metric_backward_np(a, b, g[tag + "_w"].astype(np_dt) if up == "w" else 1.0, eps=eps, unit=unit,
+                                                  divisor=float(n) if div == "B" else 1.0, clamp_dtype=np.float64 if f64_graph else np.float32)
+                assert g[key + "_d1"].dtype == np_dt and g[key + "_d1"].shape == (n, 3, 3)
+                ambiguous += metric_grad_check(d1, d2, g[key + "_d1"], g[key + "_d2"], c, eps, 1e-15 if f64_graph else 4e-7,
+                                               1e-12 if dt == "f64" else 3e-7, key)
+    assert ambiguous < 40          # of 2304 row checks: the 0 / 180 degree pairs of G3
 
 
 def test_g4_loss_and_gradients(c_oracle):

@@ -251,7 +251,52 @@ def g14_geodesic_reduction():
     save("g14_geodesic_reduction.npz", **out)
 
 
+def g15_metric_gradients():
+    """Autograd through the three metric spellings, as the reference's training loops can use them (`lossfunc` hooks:
+    point_cloud/main.py:194-197, UPNA/main.py:56-59): geodesic(R1, R2, reduction) (point_cloud/main.py:61-73, whose eps exists for
+    this gradient), compute_geodesic_distance_from_two_matrices and angle_error (rotation_representation.py:209-242).  Pairs: G3's
+    (their first 64: 0 and 180 degrees, 1e-4 and 3e-3 rad included; outside the clamp the reference's masked fill gives exactly 0) and the first 128 of G14's Haar-like pairs; float32 and float64; gradients with respect to BOTH arguments; a per-row
+    upstream gradient for the unreduced forms."""
+    (geodesic,) = functions_from(os.path.join(REF, "point_cloud", "main.py"), ["geodesic"])
+    g3 = np.load(os.path.join(OUT, "g3_angles.npz"))
+    g14 = np.load(os.path.join(OUT, "g14_geodesic_reduction.npz"))
+    sets = {"g3": (torch.from_numpy(g3["r1"][:64]), torch.from_numpy(g3["r2"][:64])),       # rows 0-4: 0, 180, 179.96, 0.044, 0.155 degrees
+            "haar": (torch.from_numpy(g14["a"][:128]), torch.from_numpy(g14["b"][:128]))}
+    out = {}
+    for tag, (p, q) in sets.items():
+        torch.manual_seed(15)
+        w = torch.randn(p.shape[0])                        # upstream gradient of the per-row forms
+        out[tag + "_r1"], out[tag + "_r2"], out[tag + "_w"] = p, q, w
+        for dt_tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            def run(fn, upstream):
+                a = p.to(dt).clone().requires_grad_(True)
+                b = q.to(dt).clone().requires_grad_(True)
+                y = fn(a, b)
+                if upstream is None:
+                    y.backward()
+                else:
+                    y.backward(upstream.to(y.dtype))
+                return y.detach(), a.grad, b.grad
+            cases = {
+                "geo_mean": (lambda a, b: geodesic(a, b, "mean"), None),
+                "geo_sum": (lambda a, b: geodesic(a, b, "sum"), None),
+                "geo_none": (lambda a, b: geodesic(a, b, "none"), w),
+                "cgd": (rr.compute_geodesic_distance_from_two_matrices, w),
+                "ang": (rr.angle_error, w),
+                "ang_mean": (lambda a, b: rr.angle_error(a, b).mean(), None),
+            }
+            for name, (fn, up) in cases.items():
+                y, da, db = run(fn, up)
+                key = "%s_%s_%s" % (tag, name, dt_tag)
+                out[key + "_y"], out[key + "_d1"], out[key + "_d2"] = y, da, db
+    out["dtypes"] = np.array([str(out["haar_ang_f32_y"].dtype), str(out["haar_ang_f32_d1"].dtype), str(out["haar_geo_mean_f32_d1"].dtype),
+                              str(out["haar_cgd_f64_d1"].dtype)])
+    save("g15_metric_gradients.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "g15":
+        return g15_metric_gradients()
     if len(sys.argv) > 1 and sys.argv[1] == "g14":
         return g14_geodesic_reduction()
     if len(sys.argv) > 1 and sys.argv[1] == "g13":
