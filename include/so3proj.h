@@ -323,8 +323,10 @@ int so3_add_l1_disentangled_f32(const float *Tpred, const float *Tgt, const floa
  *   stats     out ncls x 8 doubles: count, mean, std (population, as np.std), max, median (EXACT: radix select
  *                 on the float64 bits, the two middle elements averaged as np.median does), acc<30, acc<15, acc<7.5
  *   workspace     caller-owned scratch of so3_angle_stats_workspace_bytes() bytes (~10 MB: histograms and a buffer for the
- *                 candidates of the medians), ZERO-FILLED ONCE before its first use -- every call leaves it zeroed --, used by ONE
- *                 stream at a time (re-zero it after a call that returned an error)
+ *                 candidates of the medians), ZERO-FILLED ONCE before its first use -- every call leaves its sums and histograms
+ *                 zeroed and re-initialises its control words in its first launch --, used by ONE stream at a time (re-zero it
+ *                 after a call that returned an error).  A call whose launches are delayed by other work on the device (its
+ *                 workgroups wait for each other, boundedly) is slower, never wrong, and leaves the workspace as usable as before.
  * ncls <= 64.  A class containing a NaN angle reports NaN for mean/std/max/median, as numpy does.
  * Two launches, two passes over the rows: a histogram pass, and a pass that compacts the rows of the medians' 1/16-octave bins and
  * then, one workgroup per class behind a ticket, selects among them.

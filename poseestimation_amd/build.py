@@ -104,5 +104,25 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_test_variant(name: str, defines, force: bool = False, verbose: bool = False) -> str:
+    """libso3proj_<name>.so next to the library: the same sources with -D switches, for tests that need a code path the shipped
+    constants make rare (spins0: SO3_STAT_SPINS=0 -- every finishing workgroup of so3_angle_stats times out at once -- and four workgroups per CU, so
+    that most of its launch-mates start after it has finished).  Test
+    infrastructure: nothing in the package loads it."""
+    out = os.path.join(_HERE, "libso3proj_%s.so" % name)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = [hipcc(), *HIPCC_FLAGS, *["-D" + d for d in defines], "-o", out + ".tmp", *[os.path.join(CSRC, s) for s in SOURCES]]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
+TEST_VARIANTS = {"spins0": ["SO3_STAT_SPINS=0", "SO3_STAT_GRID_MULT=4"]}
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))

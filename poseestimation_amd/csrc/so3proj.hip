@@ -1328,10 +1328,17 @@ constexpr int kStatLdsKeys = 16384;                // candidates of one class th
 #endif
 constexpr int kStatReplicas = SO3_STAT_REPLICAS;
 static_assert(kStatReplicas >= 1 && kStatReplicas <= 16 && (kStatReplicas & (kStatReplicas - 1)) == 0, "SO3_STAT_REPLICAS: a power of two (stat_replica masks the XCD id with it)");
-struct StatWork {                                  // layout of the caller's workspace: zero-filled once, left zeroed by every call (up to `hist` included)
+// Layout of the caller's workspace.  `acc` and `hist` are zero-filled once by the caller and left zeroed by every call (only
+// k_stats_window adds into them, only a class's own finishing workgroup clears them).  The CONTROL words -- overflow, ticket,
+// class_cursor -- are put to zero by the FIRST launch of every call (k_stats_window, workgroup 0): stream order puts that after every
+// workgroup of the previous call, late ones included.  Round 5 cleared them at the END of the second launch, by the last class to
+// finish: a finishing workgroup whose launch-mates had not arrived within its wait then cleared the words while those mates were
+// still queued, and they added to the cleared words afterwards -- the next call started with a ticket above zero and trusted a
+// half-filled candidate buffer (the advisor's finding; tests/test_gpu_parity.py::test_angle_stats_survives_timed_out_waits).
+struct StatWork {
     double acc[kStatReplicas][kMaxClasses][4];     // sum, sumsq, max (bits), nan_count
-    unsigned int overflow, ticket;                 // some collecting workgroup's staging overflowed; collecting workgroups that have published their candidates
-    unsigned int done, pad;                        // classes finished (the last one clears the three words)
+    unsigned int overflow, ticket;                 // bit 0: some collecting workgroup's staging overflowed, bit 2: some finishing workgroup's wait timed out; collecting workgroups that have published their candidates
+    unsigned int unused, pad;
     unsigned int class_cursor[kMaxClasses];        // k_stats_collect: how much of class c's stretch of the candidate buffer is taken
     unsigned int hist[kStatReplicas][kHistWords];  // class c's bins from c * Win<FINE>::kRow on
     unsigned char tag[kCandCap];                   // bit 0: counts for the lower middle element, bit 1: for the upper
@@ -1403,6 +1410,10 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_window(const double *__res
     __shared__ unsigned int sh[LCLS][kHistBins];
     __shared__ double sacc[LCLS][4][kSlots];
     STAT_STAMP(w, 16);
+    if (blockIdx.x == 0) {        // the call's control words (StatWork): whatever the previous call's last workgroups left in them
+        if (threadIdx.x < kMaxClasses) w->class_cursor[threadIdx.x] = 0u;
+        if (threadIdx.x == kMaxClasses) { w->overflow = 0u; w->ticket = 0u; w->unused = 0u; }
+    }
     for (int i = threadIdx.x; i < LCLS * kHistBins; i += kStatBlock) (&sh[0][0])[i] = 0;
     for (int i = threadIdx.x; i < ncls * 4 * kSlots; i += kStatBlock) (&sacc[0][0][0])[i] = 0.0;
     __syncthreads();
@@ -1556,7 +1567,13 @@ __device__ __forceinline__ void put_candidate(StatWork *w, unsigned int at, unsi
 __device__ __forceinline__ unsigned long long get_candidate(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned int get_tag(const unsigned char *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-constexpr unsigned int kStatSpins = 16384;         // x ~0.6 us: how long a finishing workgroup waits for its launch-mates' tickets before it helps itself
+#ifndef SO3_STAT_SPINS
+#define SO3_STAT_SPINS 16384                       // x ~0.6 us: how long a finishing workgroup waits for its launch-mates' tickets before it helps itself
+#endif                                             // (0 in the test build poseestimation_amd/libso3proj_spins0.so: every wait times out at once)
+constexpr unsigned int kStatSpins = SO3_STAT_SPINS;
+#ifndef SO3_STAT_GRID_MULT
+#define SO3_STAT_GRID_MULT 1
+#endif
 
 // One class, by the whole workgroup: the class's candidates (a contiguous stretch of the buffer; into LDS when they fit), both middle
 // elements by ONE radix select of 8-bit digits -- two (prefix, rank) states side by side, they part where the two elements differ --
@@ -1769,7 +1786,6 @@ __device__ __forceinline__ void stats_finish_class(int c, const double *__restri
     // the class's part of the workspace back to zero (the next call's launches come later on the stream: plain stores)
     for (int i = threadIdx.x; i < kStatReplicas * Win<FINE>::kHist; i += kStatBlock) w->hist[i / Win<FINE>::kHist][c * Win<FINE>::kRow + i % Win<FINE>::kHist] = 0u;
     if (threadIdx.x < 4 * kStatReplicas) w->acc[threadIdx.x >> 2][c][threadIdx.x & 3] = 0.0;
-    if (threadIdx.x == 4 * kStatReplicas) w->class_cursor[c] = 0u;
 }
 
 // The rows of the selected bins: staged in LDS (a cursor: no global atomic, no barrier in the loop), then grouped by class -- a
@@ -1850,8 +1866,14 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
             ++spins;
         }
         const bool all_in = __hip_atomic_load(&w->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x;
-        const bool spilled = __hip_atomic_load(&w->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        s_state = (all_in ? 0u : 1u) | (spilled ? 2u : 0u);
+        // A wait that timed out is made known to every finishing workgroup that comes later, BEFORE this one clears anything (the
+        // returning atomic has been performed when its value is here): a launch-mate that starts after this workgroup has put its
+        // class's histogram back to zero derives other stretches of the candidate buffer than everyone else did, and a finishing
+        // workgroup that then finds all tickets in must not trust that buffer.
+        unsigned int flags = all_in ? 0u : atomicOr(&w->overflow, 4u) | 4u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flags |= __hip_atomic_load(&w->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_state = flags;
     }
     __syncthreads();
     STAT_STAMP(w, 4);
@@ -1860,16 +1882,8 @@ __global__ __launch_bounds__(kStatBlock) void k_stats_collect(const double *__re
         stats_finish_class<FINE>(c, deg, cls, w, B, stats, sel, overflow, lkey, ltag, hh);
         __syncthreads();
         STAT_STAMP(w, 5);
-        if (threadIdx.x == 0) {
-            // the last class to be finished puts the launch's three words back to zero (every finishing workgroup has read them by then)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (atomicAdd(&w->done, 1u) == static_cast<unsigned int>(ncls) - 1u) {
-                __hip_atomic_store(&w->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&w->overflow, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&w->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
     }
+    // (ticket, overflow and the cursors stay as they are: the next call's first launch clears them, see StatWork)
 }
 
 inline unsigned grid_for(int64_t B) { return static_cast<unsigned>((B + kBlock - 1) / kBlock); }
@@ -2658,7 +2672,9 @@ int so3_angle_stats(const double *deg, const int32_t *cls, int32_t ncls, double 
     };
     const int mode = vec_ok(0) ? 0 : (vec_ok(1) ? 1 : 2);
     // one 1024-thread workgroup per CU, two rows per thread and trip (two per CU measured slower: twice the flushes and LDS histograms)
-    int64_t cap = static_cast<int64_t>(device_cus());
+    // (SO3_STAT_GRID_MULT > 1, test builds only: more workgroups than CUs, so that the later ones START when the first ones have finished --
+    // with SO3_STAT_SPINS=0 the launch-mates of every finishing workgroup then arrive after it has cleared its class)
+    int64_t cap = static_cast<int64_t>(device_cus()) * SO3_STAT_GRID_MULT;
     if (cap > kStatMaxWgs) cap = kStatMaxWgs;
     const int64_t want = (B / 2 + kStatBlock - 1) / kStatBlock;
     const unsigned grid = static_cast<unsigned>(want < 1 ? 1 : (want < cap ? want : cap));

@@ -284,6 +284,10 @@ def _no_double_backward(*grads) -> None:
 
 def _check(code: int, what: str) -> None:
     if code != 0:
+        # a call that failed may have enqueued part of its launches: the cached workspaces (include/so3proj.h: "re-zero it after a
+        # call that returned an error") are dropped, the next call zero-fills fresh ones
+        _WORKSPACES.clear()
+        _STAT_WORKSPACES.clear()
         _lib.check(code, what)
 
 
@@ -1135,7 +1139,7 @@ def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None,
     stats = torch.empty((num_classes, len(STAT_FIELDS)), dtype=torch.float64, device=dev)
     with _on_device(dev):
         st = _stream(dev)
-        # the statistics' workspace of (device, stream): zero-filled once, every call leaves it zeroed (include/so3proj.h) -- 10 MB kept
+        # the statistics' workspace of (device, stream): zero-filled once, every call leaves it usable (include/so3proj.h) -- 10 MB kept
         # per stream that ever asked; a fresh zero-filled one while the stream is being captured (a replay may run beside eager calls)
         key = (dev.index, st)
         work = None if _capturing(dev) else _STAT_WORKSPACES.get(key)
@@ -1143,7 +1147,12 @@ def angle_error_statistics(angles: torch.Tensor, class_ids: torch.Tensor = None,
             work = torch.zeros((lib.so3_angle_stats_workspace_bytes(),), dtype=torch.uint8, device=dev)
             if not _capturing(dev):
                 _STAT_WORKSPACES[key] = work
-        _check(lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), st), "so3_angle_stats")
+        code = lib.so3_angle_stats(_ptr(a), _ptr(c), num_classes, _ptr(stats), _ptr(work), a.numel(), st)
+        if code != 0:
+            # include/so3proj.h: a workspace is to be re-zeroed after a call that returned an error -- a refused call may have
+            # enqueued its first launch: the cached one is dropped, the next call starts from a fresh zero-filled one
+            _STAT_WORKSPACES.pop(key, None)
+            _check(code, "so3_angle_stats")
     return {name: stats[:, i] for i, name in enumerate(STAT_FIELDS)}
 
 

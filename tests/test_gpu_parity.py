@@ -1732,9 +1732,14 @@ def test_angle_error_statistics_far_candidates_and_overflow(rr, case):
     assert np.allclose(got["mean"].cpu().numpy(), ref["mean"], rtol=0, atol=1e-9, equal_nan=True)
 
 
+_STAT_ACC_BYTES = 4 * 64 * 4 * 8                   # StatWork (csrc/so3proj.hip): acc[replicas][classes][4] float64 ...
+_STAT_HIST_AT = _STAT_ACC_BYTES + 16 + 64 * 4      # ... overflow, ticket, 2 spare words, class_cursor[64]; then the histograms
+
+
 def test_angle_error_statistics_leave_their_workspace_zeroed(rr):
-    """include/so3proj.h: the caller zero-fills so3_angle_stats's workspace ONCE and every call leaves its counted part zeroed -- sums,
-    histograms (all replicas, both bin widths), cursors, ticket, overflow flag; the candidate buffer behind them is scratch.  One workspace
+    """include/so3proj.h: the caller zero-fills so3_angle_stats's workspace ONCE and every call leaves its counted part zeroed -- sums and
+    histograms (all replicas, both bin widths); the control words between them (overflow flag, ticket, cursors: 272 bytes) are
+    re-initialised by every call's first launch, and the candidate buffer behind is scratch.  One workspace
     through few classes (bins of 1/64 octave), many (1/16), the 64-class histograms, NaN rows, an overflowing staging area (every row the
     same) and back: all zeros after every call, and the answers do not depend on what ran before."""
     from oracle import so3_oracle as so
@@ -1759,7 +1764,7 @@ def test_angle_error_statistics_leave_their_workspace_zeroed(rr):
         stats = torch.empty(ncls, 8, dtype=torch.float64, device=DEV)
         assert lib.so3_angle_stats(a.data_ptr(), c.data_ptr(), ncls, stats.data_ptr(), work.data_ptr(), n, st) == 0
         torch.cuda.synchronize()
-        assert int(torch.count_nonzero(work[:counted]).item()) == 0, (ncls, kind)
+        assert int(torch.count_nonzero(work[:_STAT_ACC_BYTES]).item()) == 0 and int(torch.count_nonzero(work[_STAT_HIST_AT:counted]).item()) == 0, (ncls, kind)
         ref = so.angle_statistics_np(ang, cls, ncls)
         got = stats.cpu().numpy()
         for i, k in enumerate(("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")):
@@ -1767,6 +1772,52 @@ def test_angle_error_statistics_leave_their_workspace_zeroed(rr):
                 assert np.allclose(got[:, i], ref[k], rtol=0, atol=1e-9, equal_nan=True), (ncls, kind, k)
             else:
                 assert np.array_equal(got[:, i], ref[k], equal_nan=True), (ncls, kind, k)
+
+
+def test_angle_stats_survives_timed_out_waits():
+    """The advisor's round-5 finding: a finishing workgroup of so3_angle_stats whose launch-mates do not arrive within its wait
+    finishes its class over the rows themselves -- and round 5 then cleared ticket / overflow / cursors while the late mates were
+    still to come, so the NEXT call on that workspace started from a non-zero ticket and could trust a half-filled candidate buffer.
+    The library built with SO3_STAT_SPINS=0 and four workgroups per CU (poseestimation_amd/libso3proj_spins0.so, build.TEST_VARIANTS)
+    makes every wait time out at once and three quarters of the launch start after the finishing workgroups have cleared their
+    classes: several calls in a row on ONE workspace, exact medians every time, sums and histograms zero after every call -- then
+    the shipped library on the same workspace, and once more with the control words deliberately scribbled on (they are the
+    call's own to initialise)."""
+    from oracle import so3_oracle as so
+    from poseestimation_amd import _lib, build
+    path = os.path.join(os.path.dirname(build.LIB), "libso3proj_spins0.so")
+    if not os.path.exists(path):
+        build.build_test_variant("spins0", build.TEST_VARIANTS["spins0"])          # (hipcc is on the GPU box too)
+    slow = ctypes.CDLL(path)
+    slow.so3_angle_stats.restype = ctypes.c_int
+    slow.so3_angle_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    assert slow.so3_version() == _lib.ABI_VERSION
+    lib = _lib.load()
+    rng = np.random.default_rng(91)
+    total = lib.so3_angle_stats_workspace_bytes()
+    counted = total - 9 * (1 << 20)
+    work = torch.zeros(total, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    plan = [(slow, 10, 1_000_000), (slow, 10, 1_000_000), (slow, 1, 300_000), (slow, 40, 300_000), (lib, 10, 1_000_000), (slow, 3, 50_000),
+            ("scribble", 0, 0), (lib, 10, 1_000_000), (slow, 64, 200_000), (lib, 1, 1_000_000)]
+    for which, ncls, n in plan:
+        if which == "scribble":
+            work[_STAT_ACC_BYTES:_STAT_HIST_AT] = 0xA5
+            continue
+        ang = np.minimum(np.abs(rng.standard_normal(n)) * 25.0, 180.0)
+        cls = rng.integers(0, ncls, n).astype(np.int32)
+        a, c = dev(ang, torch.float64), dev(cls, torch.int32)
+        stats = torch.full((ncls, 8), float("nan"), dtype=torch.float64, device=DEV)
+        assert which.so3_angle_stats(a.data_ptr(), c.data_ptr(), ncls, stats.data_ptr(), work.data_ptr(), n, st) == 0
+        torch.cuda.synchronize()
+        assert int(torch.count_nonzero(work[:_STAT_ACC_BYTES]).item()) == 0 and int(torch.count_nonzero(work[_STAT_HIST_AT:counted]).item()) == 0
+        ref = so.angle_statistics_np(ang, cls, ncls)
+        got = stats.cpu().numpy()
+        for i, k in enumerate(("count", "mean", "std", "max", "median", "acc30", "acc15", "acc7.5")):
+            if k in ("mean", "std"):
+                assert np.allclose(got[:, i], ref[k], rtol=0, atol=1e-9, equal_nan=True), (ncls, n, k)
+            else:
+                assert np.array_equal(got[:, i], ref[k], equal_nan=True), (which is slow, ncls, n, k)
 
 
 def test_angle_error_statistics_end_to_end_and_nan(rr):
