@@ -250,6 +250,63 @@ def max_over_ranks(values, dist, device=None):
     return t.tolist()
 
 
+# ---- what rank 0 says about the OTHER ranks (no GPU in it: tests/test_distributed_gloo.py drives it with two gloo ranks) ------------
+# The driver's 8-GPU run is the first time more than one rank meets real devices and nobody watches it live: the line therefore carries,
+# per rank, the device it bound to, that device's architecture and CU count, and its own clock readings -- a rank that landed on the wrong
+# device, a partitioned (CPX / DPX) device or a slow one shows in the record.  One all-reduce of a (world, K) float64 matrix in which every
+# rank fills its own row (the same machinery as the metric's (sum, count) pair; strings travel as bytes).
+ARCH_BYTES = 24
+
+
+def preflight_device(local_rank: int, device_count: int, visible=None):
+    """None when LOCAL_RANK names a device this process can see, else the one-line reason the rank must stop with (before any
+    process group exists: a rank that dies inside init_process_group leaves the others waiting for the rendezvous' timeout)."""
+    if 0 <= local_rank < device_count:
+        return None
+    return ("LOCAL_RANK=%d but this process sees %d HIP device(s)%s: start at most one rank per visible GPU"
+            % (local_rank, device_count, "" if not visible else " (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = %s)" % visible))
+
+
+def rank_report_row(device_index: int, arch: str, cus: int, numbers) -> list:
+    """One rank's row of the report matrix: device index, CU count, its own clock readings, the architecture name as bytes."""
+    raw = arch.encode("ascii", "replace")[:ARCH_BYTES]
+    return [float(device_index), float(cus)] + [float(v) for v in numbers] + [float(b) for b in raw] + [0.0] * (ARCH_BYTES - len(raw))
+
+
+def gather_rank_reports(row, rank: int, world: int, dist, device=None, names=()) -> list:
+    """Every rank's row on every rank (ONE SUM all-reduce; the rows themselves without a group) as dicts:
+    {"rank", "device_index", "arch", "cus", <names...>}."""
+    k = len(row)
+    m = torch.zeros((world, k), dtype=torch.float64, device=device)
+    m[rank] = torch.tensor(row, dtype=torch.float64, device=device)
+    if dist is not None and world > 1:
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+    out = []
+    for r, vals in enumerate(m.tolist()):
+        nums = vals[2:k - ARCH_BYTES]
+        arch = bytes(int(b) for b in vals[k - ARCH_BYTES:] if int(b) != 0).decode("ascii", "replace")
+        d = {"rank": r, "device_index": int(vals[0]), "arch": arch, "cus": int(vals[1])}
+        d.update({n: v for n, v in zip(names, nums)})
+        out.append(d)
+    return out
+
+
+def spread(reports, key) -> dict:
+    """min / max over the ranks of one reported number, and which ranks hold them: a slow rank shows."""
+    vals = [r[key] for r in reports]
+    lo, hi = min(vals), max(vals)
+    return {"min": lo, "max": hi, "rank_of_min": vals.index(lo), "rank_of_max": vals.index(hi)}
+
+
+def collective_library_version():
+    """RCCL's version as torch reports it ("2.21.5"), or None (a CPU build, the gloo test path)."""
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
+
+
 def headline(rows_per_gpu: int, world: int, steps: int, warmup: int, wall_s: float, config: dict) -> dict:
     """The contract's fields: value = rows of ALL ranks x steps / the slowest rank's time (whole-job throughput, weak scaling)."""
     total_rows = rows_per_gpu * world
@@ -259,10 +316,11 @@ def headline(rows_per_gpu: int, world: int, steps: int, warmup: int, wall_s: flo
 
 
 def run_skeleton(rank: int, world: int, steps: int, warmup: int, rows: int, step, sync, dist, device, config: dict, extra_times=(),
-                 run=None, do_warmup=True):
+                 run=None, do_warmup=True, own=None):
     """Warm-up, the timed region, the MAX over ranks, the headline -- what main() does around the launches, callable with a
     stub `step(i)` on CPU tensors.  Returns (line or None, job times): rank 0 gets the dict it will print, the others None.
     extra_times: callables evaluated after the region on every rank (e.g. the HIP-event time), MAX-reduced with the wall time.
+    own: a dict that receives this rank's own wall time ("wall_s") before the reduction (main() reports every rank's).
     run: what the region executes instead of `steps` calls of step (main(): one replay of the hipGraph that holds them)."""
     if do_warmup:
         for i in range(warmup):
@@ -274,6 +332,8 @@ def run_skeleton(rank: int, world: int, steps: int, warmup: int, rows: int, step
 
     barrier = dist.barrier if dist is not None else None
     wall = timed_region(run, sync, barrier)
+    if own is not None:
+        own["wall_s"] = wall                    # this rank's own clock (the job's is the MAX over ranks below)
     times = max_over_ranks([wall] + [f() for f in extra_times], dist, device)
     line = headline(rows, world, steps, warmup, times[0], config) if rank == 0 else None
     return line, times
@@ -324,23 +384,6 @@ def secondary_configs(lib, dev):
         loss, _r = rr.frobenius_head(xg, t4.view(b, 3, 3))
         loss.backward()
         xg.grad = None
-    for i in range(200):                      # the autograd engine's device thread and the allocator's small pool settle over ~100 calls
-        mirror(i)
-    blocks = []                               # the cost is bimodal (~65 or ~110 us) with where the engine's thread is scheduled
-    for _ in range(6):                        # (docs/history/tools/mirror_bisect.py): report the median block and the best one
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(300):
-            mirror(i)
-        torch.cuda.synchronize()
-        blocks.append((time.perf_counter() - t0) / 300 * 1e6)
-    blocks.sort()
-    # which autograd node served those steps: csrc/autograd_node.cpp's (no interpreter inside forward / backward) or the Python class
-    probe, _ = rr.frobenius_head(xg, t4.view(b, 3, 3))
-    out["config4_head_loss_backward_b512_bf16"]["mirror_path"] = "cpp_node" if "FrobeniusHeadNode" in probe.grad_fn.name() else "python"
-    out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd"] = 0.5 * (blocks[2] + blocks[3])
-    out["config4_head_loss_backward_b512_bf16"]["us_per_step_python_mirror_autograd_best_block"] = blocks[0]
-
     # torch's own floor in THIS process: an autograd.Function that launches nothing (it returns an empty scalar, its backward a
     # stored buffer) stepped the same way -- what any custom node costs here before it does any work of its own
     class _Floor(torch.autograd.Function):
@@ -358,20 +401,36 @@ def secondary_configs(lib, dev):
     def floor(_):
         _Floor.apply(xg, buf).backward()
         xg.grad = None
-    for i in range(200):
-        floor(i)
-    fblocks = []
-    for _ in range(6):
+
+    def block(fn, n=300):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(300):
-            floor(i)
+        for i in range(n):
+            fn(i)
         torch.cuda.synchronize()
-        fblocks.append((time.perf_counter() - t0) / 300 * 1e6)
-    fblocks.sort()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    for i in range(200):                      # the autograd engine's device thread and the allocator's small pool settle over ~100 calls
+        mirror(i)
+        floor(i)
+    # Mirror and floor in ALTERNATING 300-step blocks of one loop.  Either one alone is bimodal with where the autograd engine's device
+    # thread is scheduled (~26 or ~66 us for the floor; docs/history/tools/mirror_bisect.py), and measured in two separate loops the two
+    # landed in their modes independently: rounds 4-5's ratio said which mode each had drawn.  Neighbouring blocks share the mode, so the
+    # per-pair DIFFERENCE is what the mirror adds to an empty autograd.Function: median and interquartile range over the pairs.
+    mblocks, fblocks, diffs = [], [], []
+    for _ in range(9):
+        m_us, f_us = block(mirror), block(floor)
+        mblocks.append(m_us); fblocks.append(f_us); diffs.append(m_us - f_us)
+    q = lambda v, f: float(np.quantile(np.asarray(v), f))
+    # which autograd node served those steps: csrc/autograd_node.cpp's (no interpreter inside forward / backward) or the Python class
+    probe, _ = rr.frobenius_head(xg, t4.view(b, 3, 3))
     c4 = out["config4_head_loss_backward_b512_bf16"]
-    c4["us_per_step_empty_autograd_function_floor"] = 0.5 * (fblocks[2] + fblocks[3])
-    c4["mirror_over_floor"] = c4["us_per_step_python_mirror_autograd"] / c4["us_per_step_empty_autograd_function_floor"]
+    c4["mirror_path"] = "cpp_node" if "FrobeniusHeadNode" in probe.grad_fn.name() else "python"
+    c4["us_per_step_python_mirror_autograd"] = q(mblocks, 0.5)
+    c4["us_per_step_python_mirror_autograd_best_block"] = min(mblocks)
+    c4["us_per_step_empty_autograd_function_floor"] = q(fblocks, 0.5)
+    c4["mirror_minus_floor_us"] = {"median": q(diffs, 0.5), "iqr": q(diffs, 0.75) - q(diffs, 0.25), "min": min(diffs), "max": max(diffs),
+                                   "pairs": len(diffs), "note": "alternating 300-step blocks of the mirror's step and of an autograd.Function that launches nothing; per-pair difference"}
     # the head alone, no autograd (evaluation loops), B = 512 float32, by the host clock
     x512 = torch.randn(b, 9, device=dev)
     for i in range(100):
@@ -447,8 +506,10 @@ def config5_leg(lib, rr, dist, dev, rank: int, world: int, steps: int, warmup: i
     for i in range(max(warmup, NBUF)):
         step(i)
     e0.record(stream); e1.record(stream)
+    own = {}
     line, times = run_skeleton(rank, world, steps, warmup, rows, step, torch.cuda.synchronize, dist, dev, config,
-                               extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False)
+                               extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False, own=own)
+    own_ev_ms = e0.elapsed_time(e1) / steps
     # the evaluation: one fused launch per rank, one all-reduce of (sum, count)
     gt = torch.Generator().manual_seed(1 + 1000 * rank)
     t_rot = rr.symmetric_orthogonalization(torch.randn(rows, 9, generator=gt).to(dev))
@@ -470,7 +531,12 @@ def config5_leg(lib, rr, dist, dev, rank: int, world: int, steps: int, warmup: i
     a1.record()
     torch.cuda.synchronize()
     host_us = (time.perf_counter() - t0) / 20 * 1e6
-    ar = max_over_ranks([a0.elapsed_time(a1) * 1e3 / 20, host_us], dist, dev)
+    own_ar_us = a0.elapsed_time(a1) * 1e3 / 20
+    ar = max_over_ranks([own_ar_us, host_us], dist, dev)
+    props = torch.cuda.get_device_properties(dev)
+    reports = gather_rank_reports(rank_report_row(dev.index, getattr(props, "gcnArchName", props.name), props.multi_processor_count,
+                                                  [own["wall_s"] * 1e3 / steps, own_ev_ms, own_ar_us]),
+                                  rank, world, dist, dev, names=("ms_per_step", "ms_per_step_events", "allreduce_us"))
     del xs, outs
     torch.cuda.empty_cache()
     if rank != 0:
@@ -479,6 +545,8 @@ def config5_leg(lib, rr, dist, dev, rank: int, world: int, steps: int, warmup: i
             "steps": steps, "ms_per_step": line["ms_per_step"], "ms_per_step_events": times[1] / steps, "value": line["value"], "unit": "projections/s",
             "frac_of_8TBps_per_gpu_events": BYTES_PER_PROJECTION * rows / (times[1] * 1e-3 / steps) / 1e9 / HBM_PEAK_GBS,
             "mean_angle_error_deg": mean_angle, "rows_counted_by_the_all_reduce": count_seen,
+            "ms_per_step_events_by_rank": spread(reports, "ms_per_step_events"), "allreduce_us_by_rank": spread(reports, "allreduce_us"),
+            "ranks": reports,
             "allreduce_us": ar[0], "allreduce_us_host_clock": ar[1], "allreduce_backend": dist.get_backend(),
             "allreduce_note": "one SUM all-reduce of a 16-byte (sum, count) device tensor; events on the launch stream around 20 calls, MAX over ranks",
             "hbm_bytes_resident_per_rank": rows * NBUF * BYTES_PER_PROJECTION}
@@ -499,6 +567,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:                  # under an outer launcher the environment is authoritative (python bench.py --gpus N with
         args.gpus = world                   # no WORLD_SIZE never gets here: _self_launch_if_needed started N ranks of its own)
+    # device_count() does not initialise HIP: the check runs before anything can fail in a less readable way (set_device on a device
+    # that does not exist; a rank that dies inside init_process_group while the others wait for the rendezvous)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        sys.exit("[bench] rank %d of %d: bench.py needs an MI355X and this process sees no HIP device (no CPU fallback for the product path)" % (rank, world))
+    why = preflight_device(local_rank, ndev, os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if why is not None:
+        sys.exit("[bench] rank %d of %d: %s" % (rank, world, why))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -510,10 +586,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         backend = os.environ.get("SO3_BENCH_BACKEND", "nccl")      # "gloo": two ranks on ONE device (RCCL refuses a shared GPU): the test of this path
+        import datetime
+        limit = datetime.timedelta(seconds=float(os.environ.get("SO3_BENCH_DIST_TIMEOUT_S", "300")))    # (default: 10 minutes of a dead job)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
     from poseestimation_amd import _lib
     from poseestimation_amd import rotation_representation as rr
@@ -635,8 +713,9 @@ def main():
 
     with torch.cuda.stream(stream):           # a graph replays on the CURRENT stream: entered before the clock starts
         e0.record(stream); e1.record(stream)  # (torch creates an event's handle at its first record: not inside the region either)
+        own_clock = {}
         out, (wall, ev_ms) = run_skeleton(rank, world, args.steps, args.warmup, rows, step, synchronize, dist, dev, config,
-                                          extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False)
+                                          extra_times=(lambda: e0.elapsed_time(e1),), run=region, do_warmup=False, own=own_clock)
         # per-launch spread (median and min): a second, untimed pass of 20 eager launches with an event
         # between every two of them
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
@@ -648,6 +727,12 @@ def main():
         torch.cuda.synchronize()
         per_launch_us = sorted(marks[i].elapsed_time(marks[i + 1]) * 1e3 for i in range(20))
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # every rank's device and its OWN clocks (wall / ev_ms above are the job's: MAX over ranks), gathered with one all-reduce
+    props = torch.cuda.get_device_properties(dev)
+    own_wall_ms, own_ev_ms = own_clock["wall_s"] * 1e3 / args.steps, e0.elapsed_time(e1) / args.steps
+    reports = gather_rank_reports(rank_report_row(dev.index, getattr(props, "gcnArchName", props.name), props.multi_processor_count,
+                                                  [own_wall_ms, own_ev_ms]),
+                                  rank, world, dist, dev, names=("ms_per_step", "ms_per_step_events"))
 
     # parity metric: mean geodesic angle vs the decoy target (config #2), one all-reduce of (sum, count)
     gt = torch.Generator().manual_seed(1 + 1000 * rank)
@@ -690,6 +775,13 @@ def main():
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},
             "pre_timing": pre,
+            # one entry per rank: the device it bound to and its own clocks (ms_per_step / ms_per_step_events above: MAX over ranks)
+            "devices_seen": reports,
+            "ms_per_step_events_by_rank": spread(reports, "ms_per_step_events"),
+            "world_size_seen": dist.get_world_size() if dist is not None else 1,
+            "allreduce_backend": dist.get_backend() if dist is not None else None,
+            # (backend "nccl" IS RCCL on ROCm; the version is the library torch was built against, whichever backend this job uses)
+            "collective_library": {"backend_in_use": dist.get_backend(), "rccl_version": collective_library_version()} if dist is not None else None,
         })
         if world == 1 and not args.no_secondary and graph is not None:
             # the same graph held for ~0.6 s: what the kernel sustains once the package sits at its power limit

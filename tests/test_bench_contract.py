@@ -45,7 +45,13 @@ def test_bench_json_contract(mode):
     assert abs(r["frac_host_clock"] - 72.0 * 1_000_000 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and r["frac_host_clock"] <= r["frac"]
     assert 0 < r["min_us"] <= r["median_us"] < 100.0
     c4 = d["secondary"]["config4_head_loss_backward_b512_bf16"]
-    assert c4["us_per_step_empty_autograd_function_floor"] > 0 and c4["mirror_over_floor"] > 0.5
+    assert c4["us_per_step_empty_autograd_function_floor"] > 0 and "mirror_over_floor" not in c4
+    mf = c4["mirror_minus_floor_us"]                     # mirror and floor in alternating blocks of one loop: the per-pair difference
+    assert mf["pairs"] == 9 and mf["min"] <= mf["median"] <= mf["max"] and mf["iqr"] >= 0 and -20.0 < mf["median"] < 120.0
+    # one rank: its device, its own clocks -- the same fields an 8-rank line carries per rank
+    (seen,) = d["devices_seen"]
+    assert seen["rank"] == 0 and seen["device_index"] == 0 and seen["arch"].startswith("gfx950") and seen["cus"] >= 64
+    assert abs(seen["ms_per_step_events"] - d["ms_per_step_events"]) < 1e-9 and d["world_size_seen"] == 1
     assert d["secondary"]["config1_head_b512_no_grad"]["us_per_call_host_clock"] > 0
     # the kernel is named by the library from the launch's own template arguments, not by a literal in bench.py
     assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false>,") and r["kernel"].endswith(">")
@@ -124,6 +130,29 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert c5["ms_per_step_events"] <= c5["ms_per_step"] * 1.001 and c5["allreduce_us"] > 0 and c5["allreduce_backend"] == "gloo"
     assert c5["rows_counted_by_the_all_reduce"] == 2_000_000 and 120.0 < c5["mean_angle_error_deg"] < 133.0
     assert c5["hbm_bytes_resident_per_rank"] == 1_000_000 * 8 * 72 and c5["workload"].startswith("configs[4]")
+    # what makes a first 8-GPU run readable after the fact: every rank's device, architecture, CU count and OWN clocks, the spread
+    # over the ranks, the backend and the collective library's version
+    assert [r["rank"] for r in d["devices_seen"]] == [0, 1] and all(r["device_index"] == 0 and r["arch"].startswith("gfx950") and r["cus"] >= 64
+                                                                     for r in d["devices_seen"])
+    sp = d["ms_per_step_events_by_rank"]
+    assert 0 < sp["min"] <= sp["max"] and abs(sp["max"] - d["ms_per_step_events"]) < 1e-9 and {sp["rank_of_min"], sp["rank_of_max"]} <= {0, 1}
+    assert d["world_size_seen"] == 2 and d["allreduce_backend"] == "gloo" and d["collective_library"]["backend_in_use"] == "gloo" and "rccl_version" in d["collective_library"]
+    assert [r["rank"] for r in c5["ranks"]] == [0, 1] and all(r["allreduce_us"] > 0 and r["ms_per_step_events"] > 0 for r in c5["ranks"])
+    assert abs(c5["allreduce_us_by_rank"]["max"] - c5["allreduce_us"]) < 1e-6
+
+
+def test_a_rank_without_a_device_stops_the_job_with_one_line():
+    """`python bench.py --gpus 2` on a box with ONE visible GPU (no SO3_BENCH_SHARE_DEVICE): rank 1's LOCAL_RANK names a device that does
+    not exist.  It must say so in one line and exit non-zero BEFORE any process group exists, and the launcher must stop rank 0 and
+    return non-zero promptly -- not after a rendezvous timeout, and without a JSON line on stdout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SO3_BENCH_SHARE_DEVICE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30", "--warmup", "3", "--rows", "100000"]
+    t0 = time.time()
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and time.time() - t0 < 120.0
+    assert "rank 1 of 2: LOCAL_RANK=1 but this process sees 1 HIP device(s)" in out.stderr, out.stderr[-1500:]
+    assert not [l for l in out.stdout.splitlines() if l.strip()]
 
 
 def test_config5_workload_string_at_the_configs_own_world():

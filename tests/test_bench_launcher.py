@@ -156,3 +156,4 @@ def test_bench_entry_with_gpus_2_and_no_rank_variables_starts_ranks_itself():
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0 and out.stdout.strip() == ""
     assert "needs an MI355X" in out.stderr and "must be launched through" not in out.stderr
+    assert "rank 0 of 2" in out.stderr or "rank 1 of 2" in out.stderr          # the rank that stopped says which one it is

@@ -110,3 +110,48 @@ def test_bench_skeleton_with_two_ranks(tmp_path, config5):
     for r in range(world):                                     # rank r's first buffer is randn under seed r
         g = torch.Generator().manual_seed(r)
         assert res[r]["x0"] == torch.randn(rows, 9, generator=g)[0].tolist()
+
+
+# ---- what rank 0 reports about every rank (bench.gather_rank_reports): one all-reduce of a (world, K) matrix ------------------
+def _report_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        row = bench.rank_report_row(3 + rank, "gfx950:sramecc+:xnack-" if rank == 0 else "gfx942", 256 - 64 * rank, [0.015 + 0.001 * rank, 0.0149 + 0.002 * rank])
+        reports = bench.gather_rank_reports(row, rank, world, dist, None, names=("ms_per_step", "ms_per_step_events"))
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"reports": reports, "spread": bench.spread(reports, "ms_per_step_events"), "backend": dist.get_backend(),
+                       "world": dist.get_world_size()}, fh)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_rank_is_reported_to_rank_0(tmp_path):
+    """bench.py's `devices_seen`: per rank the device index, architecture, CU count and the rank's OWN clock readings, identical on
+    every rank after ONE all-reduce; the spread names the slow rank.  (What a first 8-GPU run leaves behind to be read.)"""
+    import json
+    world = 2
+    mp.spawn(_report_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world)]
+    assert res[0] == res[1]
+    r0, r1 = res[0]["reports"]
+    assert r0 == {"rank": 0, "device_index": 3, "arch": "gfx950:sramecc+:xnack-", "cus": 256, "ms_per_step": 0.015, "ms_per_step_events": 0.0149}
+    assert r1["rank"] == 1 and r1["device_index"] == 4 and r1["arch"] == "gfx942" and r1["cus"] == 192
+    assert abs(r1["ms_per_step_events"] - 0.0169) < 1e-15
+    assert res[0]["spread"] == {"min": 0.0149, "max": r1["ms_per_step_events"], "rank_of_min": 0, "rank_of_max": 1}
+    assert res[0]["backend"] == "gloo" and res[0]["world"] == 2
+
+
+def test_preflight_and_single_rank_report():
+    import bench
+    assert bench.preflight_device(0, 1) is None and bench.preflight_device(7, 8) is None
+    why = bench.preflight_device(1, 1, "0")
+    assert why.startswith("LOCAL_RANK=1 but this process sees 1 HIP device(s)") and "HIP_VISIBLE_DEVICES" in why and "\n" not in why
+    assert "sees 0 HIP device(s)" in bench.preflight_device(0, 0)
+    (only,) = bench.gather_rank_reports(bench.rank_report_row(0, "gfx950", 256, [1.5]), 0, 1, None, None, names=("ms_per_step",))
+    assert only == {"rank": 0, "device_index": 0, "arch": "gfx950", "cus": 256, "ms_per_step": 1.5}
+    assert len(bench.rank_report_row(0, "x" * 100, 1, [])) == 2 + bench.ARCH_BYTES          # long names are cut, the row keeps its width
