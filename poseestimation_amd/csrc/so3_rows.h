@@ -361,10 +361,13 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
     // Round numbers are 32-bit: the scalar unit has no 64-bit ordered compare, and as int64 the loop's "any rounds left", "how many units
     // of this round exist" went through v_cmp_*_i64 on the vector unit every round.  (2^31 rounds of 128 rows are 10 TB of float32 rows;
     // the host refuses a batch beyond that, stream_units.)  Units and rows stay 64-bit where they become addresses.
-    const int nrounds = static_cast<int>((nunits + NPL - 1) / NPL);
-    const int stride = static_cast<int>(gridDim.x) * kWaves;
+    constexpr int kFixed = Op::kFixedRounds;
+    const int nrounds_all = static_cast<int>((nunits + NPL - 1) / NPL);
+    const int stride = kFixed > 0 ? 1 : static_cast<int>(gridDim.x) * kWaves;
     const int wave_id = static_cast<int>(blockIdx.x) * kWaves + wave_in_block;
-    int t = wave_id;
+    int t = kFixed > 0 ? wave_id * kFixed : wave_id;
+    // the wave's rounds are t, t + stride, ... below `nrounds`: all of the launch's for a persistent wave, its own k for a fixed one
+    const int nrounds = kFixed > 0 ? (t + kFixed < nrounds_all ? t + kFixed : nrounds_all) : nrounds_all;
     RowCtx<NPL> ctx;
     ctx.lane = lane;
     ctx.acc = 0.0;
@@ -508,7 +511,7 @@ void k_rows(Op op, int64_t nunits, unsigned long long *__restrict__ stamps) {
                                  [&](double t, bool any) { op.finish_total(t, any); });
         }
     }
-    if (STAMP && wave_id < nrounds) {
+    if (STAMP && (kFixed > 0 ? wave_id * kFixed : wave_id) < nrounds_all) {
         __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) {
             const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWaves + wave_in_block;
@@ -551,6 +554,9 @@ struct OpBase {
     // most kParkCap rows per workgroup) and provides
     //   template <int NPL> void redo_parked(RowCtx<NPL> &, int entry, bool valid)     one row per lane, behind the loop
     static constexpr int kParkWords = 0, kParkCap = 1;
+    // kFixedRounds > 0 (experiment builds, SO3_K1_FIXED_ROUNDS): NOT persistent -- wave w takes the kFixedRounds CONSECUTIVE rounds
+    // w k, w k + 1, ... and retires; the host launches ceil(rounds / k) waves and the dispatcher back-fills (round 6's A/B)
+    static constexpr int kFixedRounds = 0;
 #ifndef SO3_HOST_MODEL
     ReduceWs *ws = nullptr;        // reduction workspace (nullptr: atomics onto host-initialised accumulators)
     unsigned ws_slot0 = 0;         // slots below this one were filled by the remainder kernel launched before the engine
@@ -715,9 +721,13 @@ __device__ __forceinline__ typename Tr<T>::mask project_or_park(const T (&m)[9],
 
 // K1: R = U diag(1,1,det(UV^T)) V^T  (rotation_representation.py:192-206): the quaternion fast path; its hard rows parked, or
 // through the packed Jacobi path on the spot when the round is dense in them.
+#ifndef SO3_K1_FIXED_ROUNDS
+#define SO3_K1_FIXED_ROUNDS 0
+#endif
 template <int IN_BYTES, bool FLIP>
 struct OpProject : OpBase {
     static constexpr int kIn0 = IN_BYTES, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kFixedRounds = SO3_K1_FIXED_ROUNDS;
     static constexpr int kParkWords = 9, kParkCap = SO3_PARK_CAP1;          // 512 entries: 22 KB of LDS per workgroup
     uint8_t *flip = nullptr;
     template <class T, int NPL>

@@ -1962,7 +1962,11 @@ void launch_rows(const Op &op, int64_t nunits, hipStream_t s) {
     g_last_kernel = rows_kernel_name<Op, NPL, WPS, BLOCK>(s);
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     const int64_t want = (rounds + kWaves - 1) / kWaves;
-    const int64_t cap = static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;   // CUs x 4 SIMDs x WPS wave slots
+    int64_t cap = static_cast<int64_t>(device_cus()) * 4 * WPS / kWaves;          // CUs x 4 SIMDs x WPS wave slots
+    if (Op::kFixedRounds > 0) {                                                    // not persistent: a wave per k consecutive rounds, back-filled
+        const int64_t waves = (rounds + Op::kFixedRounds - 1) / Op::kFixedRounds;
+        cap = (waves + kWaves - 1) / kWaves;
+    }
     const dim3 grid(static_cast<unsigned>(want < cap ? want : cap)), block(BLOCK);
     hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, false>), grid, block, 0, s, op, nunits, nullptr);
 }

@@ -24,9 +24,12 @@ for path in sys.argv[1:]:
                 assert lib.so3_project_fwd_f32(P(x[i % NB].data_ptr()), P(r[i % NB].data_ptr()), None, n, st) == 0
     graphs[path.split("/")[-1]] = (g, lib)
 torch.cuda.synchronize()
+names = list(graphs)
 for rnd in range(int(__import__("os").environ.get("AB_ROUNDS", "4"))):
     line = []
-    for name, (g, _) in graphs.items():
+    order = names[rnd % len(names):] + names[:rnd % len(names)]          # the order rotates: no build always runs behind the same one
+    for name in order:
+        g, _ = graphs[name]
         with torch.cuda.stream(side):
             g.replay(); g.replay()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,5 +38,5 @@ for rnd in range(int(__import__("os").environ.get("AB_ROUNDS", "4"))):
                 g.replay()
             b.record(side)
         torch.cuda.synchronize()
-        line.append("%s %.2f" % (name, a.elapsed_time(b) * 1e3 / (4 * K)))
-    print("  ".join(line), flush=True)
+        line.append((name, a.elapsed_time(b) * 1e3 / (4 * K)))
+    print("  ".join("%s %.2f" % (n_, dict(line)[n_]) for n_ in names), flush=True)

@@ -34,6 +34,7 @@ __global__ void fill(float *p, int64_t n, unsigned seed) {
 // headers carry no copy mode).
 struct OpCopy : so3::OpBase {
     static constexpr int kIn0 = 4, kIn1 = 0, kOut0 = 4, kOut1 = 0;
+    static constexpr int kFixedRounds = SO3_K1_FIXED_ROUNDS;      // (-DSO3_K1_FIXED_ROUNDS=k: the non-persistent shape, as K1's)
     template <class T, int NPL>
     __device__ __forceinline__ void compute(so3::Rows<T, OpCopy> &rows, so3::RowCtx<NPL> &) const {
 #pragma unroll
@@ -47,7 +48,8 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     const int64_t rounds = (nunits + NPL - 1) / NPL;
     constexpr int kW = BLOCK / 64;
     const int64_t want = (rounds + kW - 1) / kW;
-    const unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
+    unsigned blocks = (unsigned)std::min<int64_t>(want, 256LL * 4 * WPS / kW);
+    if (Op::kFixedRounds > 0) blocks = (unsigned)(((rounds + Op::kFixedRounds - 1) / Op::kFixedRounds + kW - 1) / kW);   // a wave per k consecutive rounds
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     // second input (operations that have one): the OTHER buffer set's outputs, i.e. rotations once main() has run K1 over them;
     // reducing operations add onto a scratch accumulator with one atomic per workgroup (the library's no-workspace path)
@@ -72,7 +74,7 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     CHECK(hipMemset(stamps_d, 0, 8 * 46 * 8192));
     hipLaunchKernelGGL((so3::k_rows<Op, NPL, WPS, BLOCK, true>), dim3(blocks), dim3(BLOCK), 0, 0, mk(0), nunits, stamps_d);
     CHECK(hipDeviceSynchronize());
-    const int64_t nw = std::min<int64_t>((int64_t)blocks * kW, rounds);
+    const int64_t nw = Op::kFixedRounds > 0 ? (rounds + Op::kFixedRounds - 1) / Op::kFixedRounds : std::min<int64_t>((int64_t)blocks * kW, rounds);
     std::vector<unsigned long long> st6(6 * nw);
     CHECK(hipMemcpy(st6.data(), stamps_d, st6.size() * 8, hipMemcpyDeviceToHost));
     std::vector<unsigned long long> rs(40 * nw);
@@ -86,7 +88,7 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st6[6 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
     {   // per-wave dump for offline analysis (docs/history/tools/wave_csv.py, phase_csv.py)
-        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_npl%d_wps%d.csv", what, NPL, WPS);
+        char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_npl%d_wps%d_fixed%d.csv", what, NPL, WPS, Op::kFixedRounds);
         FILE *fh = fopen(name, "w");
         if (fh) {
             fprintf(fh, "wave,rounds,start_us,end_us,cycles,hw_id,xcc,first_wait_cyc,phases\n");
@@ -100,9 +102,9 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
             fclose(fh);
         }
     }
-    printf("%-8s NPL=%d WPS=%d block=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
+    printf("%-8s NPL=%d WPS=%d block=%d fixed=%d blocks=%u : %.2f us/launch (%.0f GB/s, %.1f%% of 8 TB/s) | stamped: span %.2f us, mean wave life %.2f us, "
            "wave start p50 %.2f p99 %.2f max %.2f us, memtime/realtime %.3f (x100 MHz)\n",
-           what, NPL, WPS, BLOCK, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
+           what, NPL, WPS, BLOCK, Op::kFixedRounds, blocks, us, 72.0 * ROWS / us * 1e-3, 72.0 * ROWS / us * 1e-3 / 80.0, (double)(r1 - r0) * 0.01, life / nw * 0.01,
            starts[nw / 2], starts[(size_t)(nw * 0.99)], starts.back(), clk / nw);
     {   // the waves' first four rounds: arithmetic per round, period between the starts of consecutive rounds, what lies in front of the
         // first round and behind the last stamped one (wall clock, 10 ns resolution)
