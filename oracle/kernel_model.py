@@ -28,7 +28,8 @@ def build(force: bool = False) -> str:
         raise RuntimeError("kernel_model needs clang++ (ext_vector_type); none found")
     stale = force or not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in [SRC] + HDRS)
     if stale:
-        subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", LIB + ".tmp", SRC])
+        extra = os.environ.get("SO3_MODEL_DEFINES", "").split()          # e.g. "-DSO3_QUAT_STALL=0": the A/B of a threshold, counted on the host
+        subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", *extra, "-o", LIB + ".tmp", SRC])
         os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -739,7 +739,7 @@ template <class T, bool SKIP = true> __device__ __forceinline__ typename Tr<T>::
     // (quat_settled above), keeps its first vector.  The quotient's own round-off, 2 ulp of LAMBDA, is charged to the move, so that the
     // bar means the same whatever lambda / s1 is (1 to 3).  What the bar buys, measured: 1.6e-3 of Gaussian rows refine (one round of 128
     // in five or six) and the device search (tests/test_gpu_certificate_search.py, 2e7 bred rows) finds a worst accepted |dR| gap / s1
-    // of 1.6e-6 against its bound of 2e-6 (round 4's residual test: 1.7e-3 and 1.25e-6; a bar of 1.1e-6: 1.0e-3 and 1.7e-6).  Where the
+    // of 1.6e-6 against its bound (2e-6 then, 2.5e-6 since round 6: sixty seeds read 1.90e-6) (round 4's residual test: 1.7e-3 and 1.25e-6; a bar of 1.1e-6: 1.0e-3 and 1.7e-6).  Where the
     // error of the first vector comes from is not Newton -- a third step changed nothing -- but the quartic's float32 coefficients,
     // which move its root by eps lambda^4 / tr adj: 1e-6 lambda where the gap product is a third of lambda^3.
     // (Rounds 2-4 asked the residual |K q - lam2 q| instead: 13 packed instructions per pair for the same decision -- what else the

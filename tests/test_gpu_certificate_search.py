@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 N = 1_000_000
 GENERATIONS = 20                      # 2e7 rows
-BOUND = 2e-6                          # max accepted |dR| gap / s1
+# max accepted |dR| gap / s1.  The build's own bar (north_star asks ||R^T R - I|| < 1e-5 and the mean angle to 1e-4 degrees: both met with an order of
+# magnitude to spare).  Stated with headroom since round 6: the worst row of SIXTY searches reads 1.90e-6 (profiles/r0N_search_seeds.txt), and a bound
+# of 2e-6 asserted on three seeds of a stochastic search that reruns every round had 5 % of margin -- a red run would have been a margin, not a bug.
+BOUND = 2.5e-6
 
 
 def _haar(n, gen):

@@ -22,15 +22,17 @@ def rr():
     return rotation_representation
 
 
-# What is CLAIMED for hard rows (x the same build's Gaussian batch; DESIGN.md section 4 quotes this test's own table): reported, and a
-# bar that is exceeded makes the test an expected failure (non-strict) -- the record shows it without going red on a device that clocks
-# K1 low.  What is ASSERTED are gross-regression caps, far enough above every ratio on record (profiles/r04_hard_rows_ab.txt: K1 <= 2.02,
-# K3 <= 1.42) that only a change of algorithm, not a throttled box, reaches them.
+# What is CLAIMED for hard rows (x the same build's Gaussian batch; README and DESIGN.md section 4 quote this table, which is the worst of
+# the driver's round-5 box (GPUTEST_r05: ties at 1 % 1.33, near-reflections 1.22, rank one 1.23) and of round 6's own runs): reported in
+# every run's tail.  What is ASSERTED: 1.25 x the claim for the hard families, and a cap of their own for the families that are NOT hard
+# (zero rows, rows far from unit scale, rank two: 0.95-1.19 on record) -- a prescale branch that became twice as slow, or a hard-row path
+# 40 % slower, turns the test red; only the band between a claim and its cap is an expected failure (a device that clocks K1 low).
 CLAIMED = {  # share of hard rows: (K1, K3)
-    0.01: (1.3, 1.2), 0.10: (1.6, 1.35), 1.0: (1.8, 1.5)}
+    0.01: (1.35, 1.2), 0.10: (1.6, 1.35), 1.0: (1.8, 1.5)}
 CLAIMED_TIES_ALL = 2.05          # K1 on a whole batch of generic ties: both algorithms on every row
-CLAIMED_EASY = (1.25, 1.15)      # zero rows (forward), rows far from unit scale (every round that holds one takes the prescale branch), rank two: not hard
-GROSS = {0.01: (1.9, 1.7), 0.10: (2.3, 2.0), 1.0: (2.9, 2.4)}
+CLAIMED_EASY = (1.25, 1.2)       # zero rows (forward), rows far from unit scale (every round that holds one takes the prescale branch), rank two: not hard
+CAP_EASY = (1.5, 1.5)            # asserted for those
+CAP_OVER_CLAIM = 1.25            # asserted for the hard families: this times the claim
 
 
 def test_hard_rows_cost_is_bounded(rr):
@@ -101,8 +103,9 @@ def test_hard_rows_cost_is_bounded(rr):
             table[key] = [round(k1 / g1, 2), round(k3 / g3, 2)]
             if k1 > claim1 * g1 or k3 > claim3 * g3:
                 over_claim.append((key, table[key], (claim1, claim3)))
-            if k1 > GROSS[share][0] * g1 or k3 > GROSS[share][1] * g3:
-                over_gross.append((key, table[key], GROSS[share]))
+            cap1, cap3 = (CAP_OVER_CLAIM * claim1, CAP_OVER_CLAIM * claim3) if (name in hard or name == "all zero") else CAP_EASY
+            if k1 > cap1 * g1 or k3 > cap3 * g3:
+                over_gross.append((key, table[key], (round(cap1, 2), round(cap3, 2))))
     line = json.dumps({"hard_rows_x_gaussian_K1_K3": table, "gaussian_us_K1_K3": [round(g1, 2), round(g3, 2)],
                        "over_claimed_bar": [k for k, _, _ in over_claim]})
     conftest.REPORT_LINES.append(line)

@@ -48,4 +48,6 @@ tools/ubench/k1_anatomy 1000 > $P/anatomy.txt 2>&1 || echo "k1_anatomy failed (s
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_stats -- python3 tools/stats_loop.py > $P/stats_loop.txt 2>&1
 python3 tools/mirror_modes.py > $P/mirror_modes.txt 2>&1
 python3 -m pytest tests/test_gpu_certificate_search.py -q -s -m gpu > $P/certificate_search.txt 2>&1
+say "the certificate's search under sixty seeds (the shipped constants)"
+python3 tools/search_seeds.py poseestimation_amd/libso3proj.so $(seq 101 160) > $P/search_seeds.txt 2>&1
 say "done"
