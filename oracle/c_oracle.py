@@ -8,14 +8,20 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libso3oracle.so")
+SANITIZE = os.environ.get("SO3_SANITIZE") == "1"          # see oracle/kernel_model.py
+_SO = os.path.join(_HERE, "libso3oracle_san.so" if SANITIZE else "libso3oracle.so")
 _lib = None
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "so3_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libso3oracle.so"])
+        if SANITIZE:
+            from . import kernel_model
+            cc = kernel_model.clangxx().replace("clang++", "clang")          # ONE sanitizer runtime per process: clang's, as the model's
+            subprocess.check_call([cc, "-std=c11", "-O1", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off", *kernel_model.SAN_FLAGS, "-shared", "-o", _SO, src, "-lm"])
+        else:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libso3oracle.so"])
     return _SO
 
 

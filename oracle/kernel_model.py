@@ -11,7 +11,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "kernel_model.cpp")
 HDRS = [os.path.join(_HERE, "..", "poseestimation_amd", "csrc", h) for h in ("so3_device.h", "so3_rows.h")]
-LIB = os.path.join(_HERE, "libso3model.so")
+# SO3_SANITIZE=1: the same sources with -fsanitize=address,undefined -fno-sanitize-recover, into a library of its own (tools/sanitize_cpu.py
+# drives it in a process that has the sanitizer's shared runtime preloaded; tests/test_sanitizers.py)
+SANITIZE = os.environ.get("SO3_SANITIZE") == "1"
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-shared-libasan", "-g", "-fno-omit-frame-pointer"]
+LIB = os.path.join(_HERE, "libso3model_san.so" if SANITIZE else "libso3model.so")
 _lib = None
 
 
@@ -29,7 +33,9 @@ def build(force: bool = False) -> str:
     stale = force or not os.path.exists(LIB) or any(os.path.getmtime(f) > os.path.getmtime(LIB) for f in [SRC] + HDRS)
     if stale:
         extra = os.environ.get("SO3_MODEL_DEFINES", "").split()          # e.g. "-DSO3_QUAT_STALL=0": the A/B of a threshold, counted on the host
-        subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O2", "-ffp-contract=off", "-fPIC", "-shared", *extra, "-o", LIB + ".tmp", SRC])
+        if SANITIZE:
+            extra += SAN_FLAGS
+        subprocess.check_call([cxx, "-x", "c++", "-std=c++17", "-O1" if SANITIZE else "-O2", "-ffp-contract=off", "-fPIC", "-shared", *extra, "-o", LIB + ".tmp", SRC])
         os.replace(LIB + ".tmp", LIB)
     return LIB
 

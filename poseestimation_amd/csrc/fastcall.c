@@ -16,6 +16,13 @@
 typedef int (*so3_fn_t)(intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t, intptr_t,
                         intptr_t);
 
+/* The one thing the sanitizers report in this file (round 6: tools/sanitize_cpu.py, -fsanitize=function) is its premise: the callee is
+ * invoked through the twelve-integer type above, not through its own prototype.  ISO C leaves that undefined; the x86-64 System V calling
+ * convention defines it (see the header of this file), and libffi / ctypes do the same one level down.  The check is switched off for
+ * this function alone -- everything else in it (argument conversion, the error paths) runs instrumented. */
+#if defined(__clang__)
+__attribute__((no_sanitize("function")))
+#endif
 static PyObject *so3fast_call(PyObject *self, PyObject *const *args, Py_ssize_t nargs) {
     intptr_t a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)self;
