@@ -353,9 +353,9 @@ int so3_kabsch_f32(const float *P, const float *Q, float *R, float *H, int64_t B
  * so3_kabsch_synth_f32: K5 with the second cloud synthesised on the fly,
  *       q_bi = Rgt_b p_bi + sigma * n(seed, b, i)        (pairing rule point_cloud/main.py:173-181, plus noise)
  *   so only P (12 B per point) is read from HBM instead of P and Q.  n is a stateless counter-based standard
- *   normal (32-bit mix -> two Box-Muller pairs per point, csrc/so3proj.hip `synth_normal3`; restated by the
+ *   normal (32-bit mix -> three Box-Muller pairs per PAIR of points 64 apart, csrc/so3proj.hip `synth_normal3x2`; restated by the
  *   test oracle, oracle/ `synth_normal_np`).  The stream a seed names belongs to the library's build, not to this
- *   ABI: it is the same on every device and launch shape, and it changed between rounds of this library.
+ *   ABI: it is the same on every device and launch shape, and it changed between rounds of this library (last: round 6).
  *   sigma = 0 skips the generator.  R, H as in so3_kabsch_f32.
  */
 int so3_rotations_axis_angle_f32(const float *theta, const float *axis, float *R, int64_t B, void *stream);

@@ -215,29 +215,38 @@ def _mix32(x):
     return x
 
 
-def synth_uniforms_np(seed, cloud, point):
-    """The four uniforms per point behind synth_normal_np (csrc/so3proj.hip `synth_normal3`): one full 32-bit mix of (seed, cloud, point),
-    two single-multiply rounds of it, 23 bits each -- radii u_a1, u_b1 in (0, 1], angles u_a2, u_b2 in [0, 1) turns."""
-    cloud, point = np.asarray(cloud, np.uint64), np.asarray(point, np.uint64)
+def synth_pair_uniforms_np(seed, cloud, pair):
+    """The six uniforms of a PAIR of points behind synth_normal_np (csrc/so3proj.hip `synth_normal3x2`): one full 32-bit mix of (seed, cloud,
+    pair), four single-multiply rounds of it, 23 bits each -- radii u_rA, u_rB, u_rC in (0, 1], angles u_A, u_B, u_C in [0, 1) turns; u_C from
+    the low bytes of the first four hashes.  Returned in the order (u_rA, u_A, u_rB, u_B, u_rC, u_C)."""
+    cloud, pair = np.asarray(cloud, np.uint64), np.asarray(pair, np.uint64)
     m = np.uint64(0xFFFFFFFF)
     key = _mix32(np.uint64(seed) ^ _mix32((cloud * 0x9e3779b9 + 0x85ebca6b) & m))
-    h0 = _mix32(key ^ ((point * 0x9e3779b9 + 0xc2b2ae35) & m))
-    h1 = (h0 + 0x27d4eb2f) & m
-    h1 ^= h1 >> 16; h1 = (h1 * 0x7feb352d) & m; h1 ^= h1 >> 15
-    h2 = h0 ^ np.uint64(0x165667b1)
-    h2 ^= h2 >> 15; h2 = (h2 * 0x2c1b3c6d) & m; h2 ^= h2 >> 16
+    h0 = _mix32(key ^ ((pair * 0x9e3779b9 + 0xc2b2ae35) & m))
+
+    def round_(h, s1, mul, s2):
+        h = h ^ (h >> np.uint64(s1)); h = (h * np.uint64(mul)) & m
+        return h ^ (h >> np.uint64(s2))
+    h1 = round_((h0 + 0x27d4eb2f) & m, 16, 0x7feb352d, 15)
+    h2 = round_(h0 ^ np.uint64(0x165667b1), 15, 0x2c1b3c6d, 16)
+    h3 = round_((h0 + 0x9e3779b1) & m, 17, 0x297a2d39, 14)
+    h4 = round_(h0 ^ np.uint64(0x85ebca77), 14, 0xc2b2ae3d, 17)
     unit = lambda h: (h >> 9).astype(np.float64) / 8388608.0                     # the device's float in [1, 2), minus one
-    x = (((h2 << 8) & m) + (((h0 & 0xFF) << 24) | ((h1 & 0xFF) << 16))) & m
-    return 1.0 - unit(h0), unit(h1), 1.0 - unit(h2), unit(x)
+    low = ((h0 & 0xFF) << 24) | ((h1 & 0xFF) << 16) | ((h2 & 0xFF) << 8) | (h3 & 0xFF)
+    return 1.0 - unit(h0), unit(h1), 1.0 - unit(h2), unit(h3), 1.0 - unit(h4), unit(low)
 
 
 def synth_normal_np(seed, cloud, point, comp):
-    """The stateless standard normals of so3_kabsch_synth_f32, restated: two Box-Muller pairs per point; components 0,1 =
-    r_a (cos, sin)(2 pi u_a2), component 2 = r_b cos(2 pi u_b2)."""
-    comp = np.asarray(comp)
-    a1, a2, b1, b2 = synth_uniforms_np(seed, cloud, point)
-    ra, rb = np.sqrt(-2.0 * np.log(a1)), np.sqrt(-2.0 * np.log(b1))
-    return np.where(comp == 0, ra * np.cos(2 * np.pi * a2), np.where(comp == 1, ra * np.sin(2 * np.pi * a2), rb * np.cos(2 * np.pi * b2)))
+    """The stateless standard normals of so3_kabsch_synth_f32, restated: three Box-Muller pairs per PAIR of points.  Point p belongs to pair
+    (p >> 7) * 64 + (p & 63) and is its point a or b by bit 6 (the two points a lane of the kernel holds in neighbouring trips);
+    a: (r_A cos, r_A sin)(2 pi u_A), r_C cos(2 pi u_C);  b: (r_B cos, r_B sin)(2 pi u_B), r_C sin(2 pi u_C)."""
+    comp, point = np.asarray(comp), np.asarray(point, np.int64)
+    pair, second = (point >> 7) * 64 + (point & 63), ((point >> 6) & 1).astype(bool)
+    ura, ua, urb, ub, urc, uc = synth_pair_uniforms_np(seed, cloud, pair)
+    r01 = np.sqrt(-2.0 * np.log(np.where(second, urb, ura)))
+    t01 = 2 * np.pi * np.where(second, ub, ua)
+    rc, tc = np.sqrt(-2.0 * np.log(urc)), 2 * np.pi * uc
+    return np.where(comp == 0, r01 * np.cos(t01), np.where(comp == 1, r01 * np.sin(t01), rc * np.where(second, np.sin(tc), np.cos(tc))))
 
 
 def synth_pairs_np(p, r_gt, sigma, seed):

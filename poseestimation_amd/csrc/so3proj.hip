@@ -692,34 +692,37 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-// Three standard normals per point from two Box-Muller pairs: (n0, n1) = r_a (cos, sin)(2 pi u_a2), n2 = r_b cos(2 pi u_b2),
-// r = sqrt(-2 ln u_1).  Hardware transcendentals: v_log_f32 (log2), v_cos_f32 / v_sin_f32 (argument in turns).
+// Six standard normals for a PAIR of points from three Box-Muller pairs (round 6; rounds 2-5: two pairs per point, the second one's sine
+// thrown away -- seven transcendentals and five quarter-rate integer multiplies per point, now six and three and a half):
+//     point a: (r_A cos, r_A sin)(2 pi u_A), r_C cos(2 pi u_C)        point b: (r_B cos, r_B sin)(2 pi u_B), r_C sin(2 pi u_C),   r = sqrt(-2 ln u_r).
+// The pair of point p is j = (p >> 7) * 64 + (p & 63) and p is its point a or b by bit 6: the two points a lane holds in neighbouring trips of
+// the kernel's loop (p and p + 64), whatever the cloud's length or the loop's unrolling.  Hardware transcendentals: v_log_f32 (log2),
+// v_cos_f32 / v_sin_f32 (argument in turns).
 // The integer side is what the generator costs (rounds 2-4: six full mixes per point, 80 us of the kernel's 223 per 65 536 x 1024
-// points; the seven transcendentals were the smaller half), so:
-//   * ONE full mix per point, h0 = mix(cloud's key ^ point's counter), and two single-multiply rounds of it with different
-//     constants, h1 = round_a(h0 + c), h2 = round_b(h0 ^ c') -- pairwise 64 x 64 and 256-fold-magnified chi-square of the four
-//     uniforms, against each other and against the next point's / cloud's, stay within 3.1 sigma over 4 seeds x 4M points
-//     (tests/test_oracle_golden.py holds a reduced form; two rounds of the SAME shape fail it at 9 sigma between h1 and h2);
+// points; the transcendentals were the smaller half), so:
+//   * ONE full mix per pair, h0 = mix(cloud's key ^ pair's counter), and four single-multiply rounds of it with different shifts,
+//     multipliers and pre-whitening, h1..h4 -- pairwise 64 x 64 and 256-fold-magnified chi-square of the six uniforms, against each
+//     other and against the next pair's / cloud's, stay within 3.1 sigma over 4 seeds x 4M pairs (tests/test_oracle_golden.py holds a
+//     reduced form; two rounds of the SAME shape fail it at 9 sigma);
 //   * a uniform is 23 bits dropped into the mantissa of a float in [1, 2) by one v_alignbit_b32: the radii take 2 - x in (0, 1], the
 //     angles take x as it is (cosine and sine have period one turn);
-//   * u_a1, u_a2, u_b1 = the high 23 bits of h0, h1, h2; u_b2 = the high 23 bits of (h2 << 8) + (h0's low byte << 24 | h1's low
-//     byte << 16): its top sixteen bits are padded by two bytes nothing else uses, below them sits h2's low byte.
+//   * u_rA, u_A, u_rB, u_B, u_rC = the high 23 bits of h0 .. h4; u_C = the high 23 bits of the four low bytes of h0 .. h3 (bits no other
+//     uniform uses).
 __device__ __forceinline__ unsigned synth_cloud_key(unsigned seed, unsigned cloud) { return mix32(seed ^ mix32(cloud * 0x9e3779b9u + 0x85ebca6bu)); }
 __device__ __forceinline__ float synth_unit_float(unsigned h) { return __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, h, 9u)); }   // 0x3f800000 | h >> 9
-__device__ __forceinline__ void synth_normal3(unsigned cloud_key, unsigned point, float &n0, float &n1, float &n2) {
-    const unsigned h0 = mix32(cloud_key ^ (point * 0x9e3779b9u + 0xc2b2ae35u));
+__device__ __forceinline__ void synth_normal3x2(unsigned cloud_key, unsigned pair, float (&na)[3], float (&nb)[3]) {
+    const unsigned h0 = mix32(cloud_key ^ (pair * 0x9e3779b9u + 0xc2b2ae35u));
     unsigned h1 = h0 + 0x27d4eb2fu; h1 ^= h1 >> 16; h1 *= 0x7feb352du; h1 ^= h1 >> 15;
     unsigned h2 = h0 ^ 0x165667b1u; h2 ^= h2 >> 15; h2 *= 0x2c1b3c6du; h2 ^= h2 >> 16;
-    const float a1 = 2.0f - synth_unit_float(h0);                                       // (0, 1]
-    const float a2 = synth_unit_float(h1);                                              // [1, 2) turns
-    const float b1 = 2.0f - synth_unit_float(h2);
-    const unsigned pad = __builtin_amdgcn_perm(h0, h1, 0x04000c0cu);                    // h0.byte0 << 24 | h1.byte0 << 16
-    const float b2 = synth_unit_float((h2 << 8) + pad);
-    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(a1));     // -2 ln2 log2(u)
-    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(b1));
-    n0 = ra * __builtin_amdgcn_cosf(a2);
-    n1 = ra * __builtin_amdgcn_sinf(a2);
-    n2 = rb * __builtin_amdgcn_cosf(b2);
+    unsigned h3 = h0 + 0x9e3779b1u; h3 ^= h3 >> 17; h3 *= 0x297a2d39u; h3 ^= h3 >> 14;
+    unsigned h4 = h0 ^ 0x85ebca77u; h4 ^= h4 >> 14; h4 *= 0xc2b2ae3du; h4 ^= h4 >> 17;
+    const unsigned low = __builtin_amdgcn_perm(__builtin_amdgcn_perm(h0, h1, 0x04000c0cu), __builtin_amdgcn_perm(h2, h3, 0x0c0c0400u), 0x07060100u);
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(2.0f - synth_unit_float(h0)));     // -2 ln2 log2(u), u in (0, 1]
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(2.0f - synth_unit_float(h2)));
+    const float rc = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(2.0f - synth_unit_float(h4)));
+    const float ta = synth_unit_float(h1), tb = synth_unit_float(h3), tc = synth_unit_float(low);                            // [1, 2) turns
+    na[0] = ra * __builtin_amdgcn_cosf(ta); na[1] = ra * __builtin_amdgcn_sinf(ta); na[2] = rc * __builtin_amdgcn_cosf(tc);
+    nb[0] = rb * __builtin_amdgcn_cosf(tb); nb[1] = rb * __builtin_amdgcn_sinf(tb); nb[2] = rc * __builtin_amdgcn_sinf(tc);
 }
 
 __global__ __launch_bounds__(kBlock) void k_rotations_axis_angle(const float *__restrict__ theta, const float *__restrict__ axis,
@@ -768,19 +771,23 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_synth(const float *__restrict
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u)
                 pp[u] = __builtin_amdgcn_raw_buffer_load_b96(rp, (i0 + 64 * u + lane) * 12, 0, so3::kStreamNt);
+            static_assert(kKabschUnroll % 2 == 0, "the noise is drawn for the lane's points of two neighbouring trips at a time");
+            float nz[kKabschUnroll][3];
+            if constexpr (NOISE) {          // (a lane past the cloud's end draws too: its p is the range check's zero, and so is q p^T)
+#pragma unroll
+                for (int u = 0; u < kKabschUnroll; u += 2)              // points i0 + 64 u + lane and 64 further: pair (i0 / 128 + u / 2) * 64 + lane
+                    synth_normal3x2(cloud_key, static_cast<unsigned>(((i0 >> 7) + (u >> 1)) * 64 + lane), nz[u], nz[u + 1]);
+            }
 #pragma unroll
             for (int u = 0; u < kKabschUnroll; ++u) {
-                const int pt = i0 + 64 * u + lane;
                 const float px = __uint_as_float(pp[u].x), py = __uint_as_float(pp[u].y), pz = __uint_as_float(pp[u].z);
                 float qx = fmaf(g[2], pz, fmaf(g[1], py, g[0] * px));               // q = R_gt p   (main.py:176-181)
                 float qy = fmaf(g[5], pz, fmaf(g[4], py, g[3] * px));
                 float qz = fmaf(g[8], pz, fmaf(g[7], py, g[6] * px));
-                if constexpr (NOISE) {      // (a lane past the cloud's end draws too: its p is the range check's zero, and so is q p^T)
-                    float n0, n1, n2;
-                    synth_normal3(cloud_key, static_cast<unsigned>(pt), n0, n1, n2);
-                    qx = fmaf(sigma, n0, qx);
-                    qy = fmaf(sigma, n1, qy);
-                    qz = fmaf(sigma, n2, qz);
+                if constexpr (NOISE) {
+                    qx = fmaf(sigma, nz[u][0], qx);
+                    qy = fmaf(sigma, nz[u][1], qy);
+                    qz = fmaf(sigma, nz[u][2], qz);
                 }
                 acc[0] = fmaf(qx, px, acc[0]); acc[1] = fmaf(qx, py, acc[1]); acc[2] = fmaf(qx, pz, acc[2]);
                 acc[3] = fmaf(qy, px, acc[3]); acc[4] = fmaf(qy, py, acc[4]); acc[5] = fmaf(qy, pz, acc[5]);

@@ -291,20 +291,25 @@ def test_g9_sampler_and_synthesis_oracle():
     assert abs((flat ** 3).mean()) < 0.05 and abs((flat ** 4).mean() - 3.0) < 0.1      # skewness 0, kurtosis 3
     z2 = so.synth_normal_np(4, *np.meshgrid(np.arange(50), np.arange(400), np.arange(3), indexing="ij"))
     assert abs(np.corrcoef(z.ravel(), z2.ravel())[0, 1]) < 0.02     # another seed: another stream
-    # the four uniforms behind a point's normals come from ONE full hash and two single-multiply rounds of it: pairwise independence on a
-    # 64 x 64 grid, plain and with the low bits magnified 256-fold, against each other and against the next point's (chi-square as a
-    # z-score over 4M points; two rounds of the same shape fail this at 8-9 sigma between the second and the third)
+    # points 64 apart share a Box-Muller pair for their third component (cosine and sine of one angle): independent all the same
+    zz = so.synth_normal_np(5, *np.meshgrid(np.arange(400), np.arange(128), np.arange(3), indexing="ij"))          # 25 600 pairs: sigma 0.006
+    for ca, cb in ((2, 2), (0, 0), (0, 2), (2, 1)):
+        assert abs(np.corrcoef(zz[:, :64, ca].ravel(), zz[:, 64:, cb].ravel())[0, 1]) < 0.025, (ca, cb)
+        assert abs(np.corrcoef((zz[:, :64, ca] ** 2).ravel(), (zz[:, 64:, cb] ** 2).ravel())[0, 1]) < 0.025, (ca, cb)
+    # the six uniforms behind a PAIR of points' normals come from ONE full hash and four single-multiply rounds of it: pairwise independence
+    # on a 64 x 64 grid, plain and with the low bits magnified 256-fold, against each other and against the next pair's (chi-square as a
+    # z-score over 4M pairs; two rounds of the same shape fail this at 8-9 sigma)
     cl, pt = np.meshgrid(np.arange(4096), np.arange(1024), indexing="ij")
-    u = so.synth_uniforms_np(3, cl.ravel(), pt.ravel())
-    assert all(0.0 < u[i].min() and u[i].max() <= 1.0 for i in (0, 2)) and all(0.0 <= u[i].min() and u[i].max() < 1.0 for i in (1, 3))
+    u = so.synth_pair_uniforms_np(3, cl.ravel(), pt.ravel())
+    assert all(0.0 < u[i].min() and u[i].max() <= 1.0 for i in (0, 2, 4)) and all(0.0 <= u[i].min() and u[i].max() < 1.0 for i in (1, 3, 5))
 
     def z_of(a, b, k=64):
         h = np.histogram2d(a % 1.0, b % 1.0, bins=k, range=[[0, 1], [0, 1]])[0]
         e = a.size / (k * k)
         return (((h - e) ** 2 / e).sum() - (k * k - 1)) / np.sqrt(2.0 * (k * k - 1))
     zs = []
-    for i in range(4):
-        for j in range(i + 1, 4):
+    for i in range(6):
+        for j in range(i + 1, 6):
             zs += [z_of(u[i], u[j]), z_of(u[i] * 256, u[j] * 256)]
         zs.append(z_of(u[i].reshape(4096, 1024)[:, :-1].ravel(), u[i].reshape(4096, 1024)[:, 1:].ravel()))
     assert max(abs(z) for z in zs) < 4.0, zs
