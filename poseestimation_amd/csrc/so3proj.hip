@@ -1920,6 +1920,11 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
 #ifndef SO3_WPS_K14
 #define SO3_WPS_K14 2
 #endif
+#ifndef SO3_K4B_NPL                  // K4b's launch shape (the metrics' backward)
+#define SO3_K4B_NPL 2
+#define SO3_K4B_WPS 3
+#define SO3_K4B_BLOCK 256
+#endif
 
 #define SO3_CHECK_ARGS(cond, name) \
     do { if (!(cond)) return fail(SO3_ERR_INVALID, name); } while (0)
@@ -2171,7 +2176,7 @@ void angle_bwd_launch(const float *R1, const float *R2, const void *grad, double
     if (GRAD == 0) op.gscalar = grad; else op.in2 = grad;
     const int64_t nunits = stream_units(B, {R1, R2, GRAD != 0 ? grad : nullptr, d1, d2});
     // light arithmetic, 108-152 B per row: two rows per lane, three waves per SIMD (11 KB of LDS per wave)
-    if (nunits > 0) launch_rows<2, 3, 256>(op, nunits, s);
+    if (nunits > 0) launch_rows<SO3_K4B_NPL, SO3_K4B_WPS, SO3_K4B_BLOCK>(op, nunits, s);
     const int64_t done = nunits * so3::kUnitRows, rest = B - done;
     if (rest > 0) {
         so3::OpAngleBwd<GRAD, F64MATH, BOTH> t = op;

@@ -9,7 +9,10 @@ from poseestimation_amd import rotation_representation as rr
 
 P = ctypes.c_void_p
 dev = torch.device("cuda:0")
+if os.environ.get("SO3_LIB"):                    # another build of the library (tools/build_variant.sh), for A/B runs
+    _lib.LIB_PATH = os.path.abspath(os.environ["SO3_LIB"])
 lib = _lib.load()
+ONLY = os.environ.get("SO3_BENCH_ONLY")          # time only the lines whose name contains this
 st = P(torch.cuda.current_stream().cuda_stream)
 NB = 6
 
@@ -18,6 +21,8 @@ QUICK = os.environ.get("SO3_BENCH_QUICK") == "1"      # 2 calls per entry: for r
 
 
 def timeit(name, fn, bytes_per_call, iters=60, warm=5):
+    if ONLY and ONLY not in name:
+        return
     if QUICK:
         iters, warm = 2, 1
     us = float("inf")
@@ -94,6 +99,18 @@ def main():
     timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (workspace: one launch)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), p(ws), n, st), 72 * n)
     timeit("K4' geodesic(R1, R2, 'mean') so3_geodesic_eps_f32 (no workspace: memset + kernel + mean)", lambda i: lib.so3_geodesic_eps_f32(p(r[i % NB]), p(rt[i % NB]), None, p(ls), p(lm), 1, ctypes.c_float(1e-7), None, n, st), 72 * n)
     del r64, g64
+    # K4b: the metrics' backward (round 6): dR1 / dR2 of geodesic(..., 'mean') from a 0-dim upstream gradient, of the per-row form from a
+    # per-row one, and angle_error's float64 spelling
+    RAD, GS, F64 = _lib.RADIANS, _lib.GRAD_SCALAR, _lib.F64_MATH
+    one32, one64 = torch.ones(1, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+    w32, w64 = torch.randn(n, device=dev), torch.randn(n, dtype=torch.float64, device=dev)
+    kb = lib.so3_angle_bwd_f32
+    D = ctypes.c_double
+    timeit("K4b so3_angle_bwd_f32 geodesic mean: dR1 + dR2", lambda i: kb(p(r[i % NB]), p(rt[i % NB]), p(one32), D(n), D(1e-7), RAD | GS, p(dm[i % NB]), p(g[i % NB]), n, st), 144 * n)
+    timeit("K4b so3_angle_bwd_f32 geodesic mean: dR1 alone", lambda i: kb(p(r[i % NB]), p(rt[i % NB]), p(one32), D(n), D(1e-7), RAD | GS, p(dm[i % NB]), None, n, st), 108 * n)
+    timeit("K4b so3_angle_bwd_f32 per-row upstream gradient: dR1 alone", lambda i: kb(p(r[i % NB]), p(rt[i % NB]), p(w32), D(1), D(0), RAD, p(dm[i % NB]), None, n, st), 112 * n)
+    timeit("K4b so3_angle_bwd_f32 angle_error.mean() (float64 math): dR1 alone", lambda i: kb(p(r[i % NB]), p(rt[i % NB]), p(one64), D(n), D(0), GS | F64, p(dm[i % NB]), None, n, st), 108 * n)
+    timeit("K4b so3_angle_bwd_f32 angle_error per-row float64 gradient: dR1 + dR2", lambda i: kb(p(r[i % NB]), p(rt[i % NB]), p(w64), D(1), D(0), F64, p(dm[i % NB]), p(g[i % NB]), n, st), 152 * n)
     timeit("K4' so3_geodesic_f32", lambda i: lib.so3_geodesic_f32(p(r[i % NB]), p(rt[i % NB]), p(th), n, st), 76 * n)
     print("--- next rows (f1, f2, f3) at 1M rows ---")
     x6 = [torch.randn(n, 6, device=dev) for _ in range(NB)]
