@@ -467,6 +467,55 @@ def secondary_configs(lib, dev):
     out["config2_cache_resident_single_buffer_pair"] = {"us_per_call": us, "note": "same 36 MB in / 36 MB out replayed: served by the Infinity Cache, not HBM; eager launches"}
     del xr, rr_
     torch.cuda.empty_cache()
+    # Independent batches on SEVERAL streams (a serving loop's shape, not a training step's): a launch of the persistent engine leaves wave
+    # slots idle while its first loads are in flight and while the waves that hold one round more than the others finish (46 % of a 1M-row
+    # launch's waves hold two rounds, the rest three); launches on other streams fill them.  One hipGraph of 240 launches over 8 rotating
+    # buffer pairs per shape -- a chain on one stream, and forked over two and three -- replayed in turn; microseconds per launch = event time
+    # / launches, which with more than one stream is a THROUGHPUT figure (a profiler's per-dispatch duration is longer: launches overlap).
+    # The headline above stays the one-stream chain: its time per step IS the kernel's duration, which is what `roofline` prices.
+    nl = 240
+    xs_ = [torch.randn(ROWS_DEFAULT, 9, device=dev) for _ in range(NBUF)]
+    rs_ = [torch.empty(ROWS_DEFAULT, 9, device=dev) for _ in range(NBUF)]
+
+    def chain(nstreams):
+        lanes = [torch.cuda.Stream() for _ in range(nstreams)]
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(lanes[0]):
+            with torch.cuda.graph(g, stream=lanes[0], capture_error_mode="thread_local"):
+                for s_ in lanes[1:]:
+                    s_.wait_stream(lanes[0])
+                for i in range(nl):
+                    if lib.so3_project_fwd_f32(P(xs_[i % NBUF].data_ptr()), P(rs_[i % NBUF].data_ptr()), None, ROWS_DEFAULT, P(lanes[i % nstreams].cuda_stream)) != 0:
+                        raise RuntimeError("so3_project_fwd_f32 failed: %s" % lib.so3_last_error().decode())
+                for s_ in lanes[1:]:
+                    lanes[0].wait_stream(s_)
+        return g, lanes[0]
+
+    try:
+        shapes = {k: chain(k) for k in (1, 2, 3)}
+        best = {k: float("inf") for k in shapes}
+        for _ in range(4):
+            for k, (g, s0) in shapes.items():
+                with torch.cuda.stream(s0):
+                    g.replay()
+                    a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(s0)
+                    g.replay(); g.replay()
+                    b_.record(s0)
+                torch.cuda.synchronize()
+                best[k] = min(best[k], a.elapsed_time(b_) * 1e3 / (2 * nl))
+        out["config2_independent_batches_on_several_streams"] = {
+            "us_per_launch_by_streams": {str(k): v for k, v in best.items()},
+            "frac_of_8TBps_by_streams": {str(k): BYTES_PER_PROJECTION * ROWS_DEFAULT / (v * 1e-6) / 1e9 / HBM_PEAK_GBS for k, v in best.items()},
+            "projections_per_s_3_streams": ROWS_DEFAULT / (best[3] * 1e-6),
+            "note": "throughput of a 240-launch hipGraph over 8 rotating buffer pairs, chained on one stream or forked over two / three; launches on "
+                    "different streams overlap (the tail of one with the fill of the next), so the per-launch figure is event time / launches, not a kernel duration"}
+        del shapes
+    except Exception as exc:                   # a capture that the runtime refuses must not cost the headline its line
+        out["config2_independent_batches_on_several_streams"] = {"error": repr(exc)}
+    del xs_, rs_
+    torch.cuda.empty_cache()
     return out
 
 

@@ -53,6 +53,9 @@ def test_bench_json_contract(mode):
     assert seen["rank"] == 0 and seen["device_index"] == 0 and seen["arch"].startswith("gfx950") and seen["cus"] >= 64
     assert abs(seen["ms_per_step_events"] - d["ms_per_step_events"]) < 1e-9 and d["world_size_seen"] == 1
     assert d["secondary"]["config1_head_b512_no_grad"]["us_per_call_host_clock"] > 0
+    ov = d["secondary"]["config2_independent_batches_on_several_streams"]          # independent batches on 1 / 2 / 3 streams: throughput, labelled as such
+    assert "error" not in ov and set(ov["us_per_launch_by_streams"]) == {"1", "2", "3"}
+    assert 0 < ov["us_per_launch_by_streams"]["3"] <= 1.05 * ov["us_per_launch_by_streams"]["1"] and ov["frac_of_8TBps_by_streams"]["3"] < 1.0
     # the kernel is named by the library from the launch's own template arguments, not by a literal in bench.py
     assert r["kernel"].startswith("so3::k_rows<so3::OpProject<4, false>,") and r["kernel"].endswith(">")
     assert c4["mirror_path"] in ("cpp_node", "python")                               # which autograd node produced the mirror's figure
