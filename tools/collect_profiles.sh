@@ -18,6 +18,7 @@ cp $P/anatomy.txt profiles/${tag}_k1_engine_copy.txt
 cp $P/stats_loop.txt profiles/${tag}_angle_stats.txt
 grep -h "k_stats" $P/kt_stats/*/*kernel_stats.csv >> profiles/${tag}_angle_stats.txt || true
 cp $P/mirror_modes.txt profiles/${tag}_mirror_overhead.txt
+[ -f $P/k1_two_streams.txt ] && cp $P/k1_two_streams.txt profiles/${tag}_k1_two_streams.txt
 cp $P/certificate_search.txt profiles/${tag}_certificate_search.txt
 [ -f $P/search_seeds.txt ] && cp $P/search_seeds.txt profiles/${tag}_search_seeds.txt
 cp $P/device.txt profiles/${tag}_device.txt

@@ -34,9 +34,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_all -- python3 too
 mkdir -p $P/pmc_all
 SO3_BENCH_QUICK=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/pmc_all/fetch -- python3 tools/bench_all.py > /dev/null 2> $P/pmc_all_fetch.log
 SO3_BENCH_QUICK=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/pmc_all/write -- python3 tools/bench_all.py > /dev/null 2> $P/pmc_all_write.log
-say "A/B against rounds 3 and 4: K1 as a 500-launch graph and eager, the projection kernels, hard rows"
+say "A/B against rounds 3, 4 and 5: K1 as a 500-launch graph and eager, the projection kernels, hard rows"
 cp poseestimation_amd/libso3proj.so build/variants/libso3proj_$tag.so
-libs=""; for r in r03 r04; do [ -f build/variants/libso3proj_$r.so ] && libs="$libs build/variants/libso3proj_$r.so"; done
+libs=""; for r in r03 r04 r05; do [ -f build/variants/libso3proj_$r.so ] && libs="$libs build/variants/libso3proj_$r.so"; done
 AB_ROUNDS=6 python3 tools/ab_k1_graph.py $libs build/variants/libso3proj_$tag.so > $P/ab_k1_graph.txt 2>&1
 AB_ROUNDS=5 python3 tools/ab_v2.py $libs build/variants/libso3proj_$tag.so > $P/ab_kernels.txt 2>&1
 [ -f build/variants/libso3proj_r04.so ] && AB_HARD=1 AB_ROUNDS=3 AB_ONLY=K1 python3 tools/ab_v2.py build/variants/libso3proj_r04.so build/variants/libso3proj_$tag.so > $P/ab_hard_rows.txt 2>&1
@@ -47,7 +47,10 @@ say "engine anatomy, statistics, mirror, certificate search"
 tools/ubench/k1_anatomy 1000 > $P/anatomy.txt 2>&1 || echo "k1_anatomy failed (see $P/anatomy.txt)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/kt_stats -- python3 tools/stats_loop.py > $P/stats_loop.txt 2>&1
 python3 tools/mirror_modes.py > $P/mirror_modes.txt 2>&1
+python3 tools/k1_two_streams.py > $P/k1_two_streams.txt 2>&1
 python3 -m pytest tests/test_gpu_certificate_search.py -q -s -m gpu > $P/certificate_search.txt 2>&1
+if [ "${SKIP_SEEDS:-0}" != "1" ]; then      # (~5 minutes; SKIP_SEEDS=1 leaves it to a call of its own: gpurun's limit is 20 minutes per call)
 say "the certificate's search under sixty seeds (the shipped constants)"
 python3 tools/search_seeds.py poseestimation_amd/libso3proj.so $(seq 101 160) > $P/search_seeds.txt 2>&1
+fi
 say "done"
