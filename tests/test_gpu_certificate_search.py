@@ -164,6 +164,6 @@ def test_adversarial_search_finds_no_accepted_row_beyond_the_bound(seed):
         pop = torch.cat([_breed(parents, N - N // 4, gen), _seeds(N // 4, gen)])
     assert accepted_total + hard_total == GENERATIONS * N >= 20_000_000
     assert accepted_total > 5_000_000 and flips_checked > 10_000_000          # the search did exercise the fast path
-    print("\\nadversarial search: %d rows, %d accepted, worst accepted |dR| gap/s1 = %.3g (bound %.1g); per generation "
+    print("\\nadversarial search: %d rows, %d accepted, worst accepted |dR| gap/s1 = %.3g (bound %.2g); per generation "
           "(accepted, LAPACK-judged worst, device-scored worst): %s"
           % (GENERATIONS * N, accepted_total, worst_overall, BOUND, [(a, "%.2g" % w, "%.2g" % s) for _, a, w, s in history]))
