@@ -47,7 +47,7 @@ constexpr int kUnitRows = 64;
 constexpr int kRsrcFlags = 0x00020000;           // gfx9 raw buffer, 32-bit data format
 // Cache policy of the streamed accesses (each byte is touched once): aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1.
 // A plain 36 MB -> 36 MB copy: 14.8 us with the default policy, 13.1 us nt (tools/ubench/copy_ceiling.hip).
-// (default, sc0, sc1 and their combinations were swept on one device in round 3: nt / nt stays, profiles/r03_k1_engine_experiments.txt)
+// (default, sc0, sc1 and their combinations were swept on one device in round 3: nt / nt stays, docs/history/profiles/r03_k1_engine_experiments.txt)
 constexpr int kLoadCpol = 2, kStoreCpol = 2;
 constexpr int kStreamNt = 2;                     // the cloud kernels' once-read points
 
@@ -580,7 +580,7 @@ struct OpBase {
 //   * a round DENSE in hard rows (or one the list has no room for) runs the packed Jacobi path on the spot, in front of the block
 //     store, as before: parked, such rows would be stored twice, the second time four bytes per lane and store.
 // (Built and measured first: row NUMBERS parked instead of inputs, every hard row redone from memory behind the loop, no Jacobi
-// code in any loop -- profiles/r04_row_number_queue*: the redo waits for its re-read inputs and for the round's stores, 10 % of
+// code in any loop -- docs/history/profiles/r04_row_number_queue*: the redo waits for its re-read inputs and for the round's stores, 10 % of
 // hard rows 1.8 x, whole batches 2.0-2.3 x.  The same experiment showed K2 at three waves per SIMD, spill-free, no faster than at two.)
 template <int CAP> __device__ __forceinline__ int park_reserve(unsigned *count, int n) {
     int base = 0;
@@ -985,7 +985,7 @@ struct OpAngle : OpBase {
 // The REDUCED forms of the metric -- sum_b acos(clamp((tr(R1_b^T R2_b) - 1)/2)), what `angle_error(...).mean()` (3D-Pose/main.py:62) and
 // the (sum, count) pair of the multi-GPU layer need -- without float64 arithmetic on every row.  The reference casts both
 // rotations to float64 before the product (rotation_representation.py:232-233); reproducing that costs 18 v_cvt_f64_f32, 9 float64
-// FMAs and a 35-instruction float64 acos per row, 560 cycles per pair of rows on top of K1's 1 750 (profiles/r03_valu_rates_f64.txt),
+// FMAs and a 35-instruction float64 acos per row, 560 cycles per pair of rows on top of K1's 1 750 (docs/history/profiles/r03_valu_rates_f64.txt),
 // for a sum whose INPUTS are float32 rotations carrying 1e-7 of orthonormality defect.  Here the same formula runs in packed
 // float32 -- trace, cosine, acos as pi/2 - asin(c) for |c| <= 1/2 and through asin(sqrt((1 - |c|)/2)) beyond, a degree-5 polynomial
 // (1.2e-9 rad, fitted for float32 evaluation: mean error -3e-10 rad) -- and only the asin part r travels to the float64

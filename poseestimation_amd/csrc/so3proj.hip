@@ -1329,7 +1329,7 @@ constexpr int kStatMaxWgs = 1024;
 constexpr int kStatLdsKeys = 16384;                // candidates of one class that k_stats_finish keeps in LDS (128 KB + 16 KB of tags)
 // The window pass's per-class sums and histograms exist kStatReplicas times, a workgroup adds into replica (its XCD's id) % kStatReplicas:
 // 256 workgroups flushing ~100 bins per class into ONE copy were 256 atomics in a row on every address -- the flush was issued 3.9 us
-// into the launch and performed 9-12.6 us into it, the larger half of the pass (stamps, profiles/r05_stats_anatomy.txt).
+// into the launch and performed 9-12.6 us into it, the larger half of the pass (stamps, docs/history/profiles/r05_stats_anatomy.txt).
 #ifndef SO3_STAT_REPLICAS
 #define SO3_STAT_REPLICAS 4
 #endif
@@ -1898,7 +1898,7 @@ inline unsigned persistent_grid(int64_t B) { const unsigned t = grid_for(B); ret
 
 // Resident waves per SIMD the two-input kernels K2 / K3 / K1+K4 are built for (K1 runs at 3): their rare Jacobi branch keeps the frames
 // live across the backward (190-216 VGPRs).  Round 4 measured what three waves would buy with that branch out of the loop
-// (profiles/r04_row_number_queue_ab.txt): K2 at 168 VGPRs, spill-free, 22.10 us against 22.01 us at two -- occupancy is not what bounds it.
+// (docs/history/profiles/r04_row_number_queue_ab.txt): K2 at 168 VGPRs, spill-free, 22.10 us against 22.01 us at two -- occupancy is not what bounds it.
 #ifndef SO3_BLOCK_K1
 #define SO3_BLOCK_K1 256
 #endif
@@ -2481,7 +2481,7 @@ static int geodesic_f32(const float *R1, const float *R2, float *theta, double *
                 so3::OpGeodesic<true> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.sum = sum; op.lo = lo; op.hi = hi;
                 op.ws = ws; op.ws_slot0 = tile_wgs; op.result = result; op.scale = scale;
                 // 1024-thread workgroups as K4: 256 partials / same-address atomics at the end, not 768 (at ~12 ns each the
-                // <2, 3, 256> shape spent 5 us of its 18.5 queueing on one address: profiles/r04_all_kernels_stats.csv)
+                // <2, 3, 256> shape spent 5 us of its 18.5 queueing on one address: docs/history/profiles/r04_all_kernels_stats.csv)
                 launch_rows<1, 4, 1024>(op, nunits, s);
             } else { so3::OpGeodesic<false> op; op.in0 = R1; op.in1 = R2; op.theta = theta; op.lo = lo; op.hi = hi; launch_rows<2, 3, 256>(op, nunits, s); }
         }

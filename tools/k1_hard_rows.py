@@ -6,7 +6,7 @@ Families: rank two (one singular value 0: not hard), near-reflections (-R + nois
 small integers (entries in {-1, 0, 1}: ties and rank deficiency), 1e5 * Gaussian (outside the fast path's scale window:
 prescaled, not hard since round 3), generic ties (s2 = s3, det < 0, general position), rank one, all zero (a dead head).  The reference (torch.svd -> LAPACK / gesvdj) has no such cliff: this table puts ours on record.
 
-usage: k1_hard_rows.py [--lib path/to/libso3proj.so] [--rows N]      (prints a table; profiles/r03_k1_hard_rows.txt)
+usage: k1_hard_rows.py [--lib path/to/libso3proj.so] [--rows N]      (prints a table; docs/history/profiles/r03_k1_hard_rows.txt)
 """
 import argparse
 import ctypes

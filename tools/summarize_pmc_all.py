@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_all.py.
-usage: summarize_pmc_all.py gpurun_out/pmc_all r01   ->  profiles/r01_all_kernels_pmc_traffic.json
+usage: summarize_pmc_all.py gpurun_out/pmc_all r01   ->  docs/history/profiles/r01_all_kernels_pmc_traffic.json
 gfx950: FETCH_SIZE reports half of a wide coalesced streaming read (MI355X_MICROARCH.md) -> doubled."""
 import collections, csv, glob, json, os, re, sys
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-dispatch SQ counters of K2 / K3 / K1+K4 from tools/profile_round.sh's passes (sqa_<k>, sqb_<k> over tools/kernel_loop.py).
-usage: summarize_sq_two_input.py gpurun_out/prof_r05 r05   ->  profiles/r05_two_input_pmc_sq.json"""
+usage: summarize_sq_two_input.py gpurun_out/prof_r05 r05   ->  docs/history/profiles/r05_two_input_pmc_sq.json"""
 import csv, glob, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
