@@ -614,6 +614,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SO3_BENCH_SHARE_DEVICE") == "1":      # the one-GPU test box: every rank on cuda:0, whichever launcher set LOCAL_RANK
+        local_rank = 0
     if world != args.gpus:                  # under an outer launcher the environment is authoritative (python bench.py --gpus N with
         args.gpus = world                   # no WORLD_SIZE never gets here: _self_launch_if_needed started N ranks of its own)
     # device_count() does not initialise HIP: the check runs before anything can fail in a less readable way (set_device on a device
@@ -799,11 +801,12 @@ def main():
         per_launch_s = ev_ms * 1e-3 / args.steps
         achieved = BYTES_PER_PROJECTION * rows / per_launch_s / 1e9
         achieved_host = BYTES_PER_PROJECTION * rows / (wall / args.steps) / 1e9
-        traffic = None
+        traffic, traffic_from = None, None
         pmc = os.path.join(ROOT, "profiles", "k1_pmc_traffic.json")
         if rows == ROWS_DEFAULT and os.path.exists(pmc):      # the stored figure belongs to the default row count only
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                stored = json.load(open(pmc))
+                traffic, traffic_from = stored.get("hbm_bytes_per_launch"), stored.get("source")
             except (OSError, ValueError):
                 traffic = None
         out.update({
@@ -813,6 +816,9 @@ def main():
             "mean_angle_error_delta_vs_ref_deg": delta,
             "roofline": {"bound": "hbm", "kernel": k1_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         # `achieved` / `frac` are the contract's: algorithmic bytes / the kernel's average launch duration by HIP events on the
+                         # launch stream over the timed region (the figure a rocprofv3 trace of this command agrees with); under its own name too
+                         "frac_events": achieved / HBM_PEAK_GBS, "clock": "hip_events_on_the_launch_stream",
                          # the same fraction on the contract's clock (barrier + synchronize around the K steps: ~10 us of submission
                          # and synchronisation latency are inside it, 3 % of a 20-step region)
                          "frac_host_clock": achieved_host / HBM_PEAK_GBS,
@@ -820,7 +826,8 @@ def main():
                          "median_us": 0.5 * (per_launch_us[9] + per_launch_us[10]), "min_us": per_launch_us[0],
                          "traffic": traffic,
                          "traffic_source": ("stored profile profiles/k1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                            "this workload, FETCH_SIZE doubled per the gfx950 caveat); not measured in this run") if traffic is not None else None,
+                                            "this workload, FETCH_SIZE doubled per the gfx950 caveat; written by tools/collect_profiles.sh from: %s); "
+                                            "not measured in this run" % traffic_from) if traffic is not None else None,
                          "bytes_per_launch_algorithmic": BYTES_PER_PROJECTION * rows,
                          "avg_launch_us": per_launch_s * 1e6},
             "pre_timing": pre,

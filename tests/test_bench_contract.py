@@ -40,7 +40,8 @@ def test_bench_json_contract(mode):
     assert abs(d["mean_angle_error_delta_vs_ref_deg"]) < 1e-4                      # the parity half of the metric
     # both clocks are reported: the host clock of the contract and the HIP events the roofline uses
     assert d["ms_per_step_events"] <= d["ms_per_step"] and abs(r["avg_launch_us"] - d["ms_per_step_events"] * 1e3) < 1e-6
-    assert r["traffic"] is None or "stored profile" in r["traffic_source"]
+    assert r["traffic"] is None or ("stored profile" in r["traffic_source"] and "profiles/r0" in r["traffic_source"])
+    assert r["frac_events"] == r["frac"] and r["clock"].startswith("hip_events")
     # the fraction on the contract's clock beside the event one, and the per-launch spread (median, fastest of 20 eager launches)
     assert abs(r["frac_host_clock"] - 72.0 * 1_000_000 / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 1e-9 and r["frac_host_clock"] <= r["frac"]
     assert 0 < r["min_us"] <= r["median_us"] < 100.0
@@ -156,6 +157,29 @@ def test_a_rank_without_a_device_stops_the_job_with_one_line():
     assert out.returncode != 0 and time.time() - t0 < 120.0
     assert "rank 1 of 2: LOCAL_RANK=1 but this process sees 1 HIP device(s)" in out.stderr, out.stderr[-1500:]
     assert not [l for l in out.stdout.splitlines() if l.strip()]
+
+
+def test_bench_under_torch_distributed_run_as_the_driver_spells_it():
+    """The driver's N > 1 command, word for word -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 --steps K --warmup W` -- on this one-GPU box: both ranks on cuda:0 (SO3_BENCH_SHARE_DEVICE) over gloo (RCCL
+    refuses two ranks on one device).  The launcher's environment is authoritative (bench.py does not start ranks of its own under it), rank 0
+    prints the one line, and the line carries both ranks."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SO3_BENCH_BACKEND="gloo", SO3_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--rows", "250000"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2500:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["world_size_seen"] == 2
+    assert [r["rank"] for r in d["devices_seen"]] == [0, 1] and d["config"]["global_rows"] == 500_000
+    assert d["secondary"]["config5"]["world_size_seen"] == 2 and d["secondary"]["config5"]["rows_counted_by_the_all_reduce"] == 1_000_000
 
 
 def test_config5_workload_string_at_the_configs_own_world():
