@@ -644,6 +644,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
 
+    if world > 1:
+        # N ranks on one host: each draws its first buffer with torch's CPU generator (config #2 / #5's recipe), and N processes with a thread per
+        # hardware thread each would queue on each other for it
+        torch.set_num_threads(max(1, host_cores() // world))
     from poseestimation_amd import _lib
     from poseestimation_amd import rotation_representation as rr
     from poseestimation_amd.distributed import allreduce_sum_count
