@@ -198,10 +198,9 @@ template <int BYTES> __device__ __forceinline__ rsrc_t row_rsrc(void *base, int6
 }
 
 // ---- reductions without a zero-fill launch and without atomics on the result ----------------------------------
-// A caller-owned WORKSPACE (so3_reduce_workspace_bytes(), zero-filled once, used by one stream at a time): every workgroup adds
-// its partial to its own slot (the slot holds 0, so the slot becomes the partial exactly; float64 atomics execute at the
-// memory side, coherent across the XCDs), takes a ticket, and the workgroup that draws the last ticket sums the slots in a
-// fixed order, writes the result and leaves slots, flag and ticket zeroed for the next call.  Against round 2 (a memset or
+// A caller-owned WORKSPACE (so3_reduce_workspace_bytes(), zero-filled once, used by one stream at a time): every workgroup stores
+// its partial into its own slot (performed at the memory side, coherent across the XCDs), takes a ticket, and the workgroup that
+// draws the last ticket sums the slots in a fixed order, writes the result and leaves slots, flag and ticket zeroed for the next call.  Against round 2 (a memset or
 // 1-thread init launch in front of the kernel, one same-address atomic per workgroup behind it) that is one launch less per
 // call, and the sum no longer depends on the order in which workgroups retire: the same input gives the same bits.
 constexpr int kMaxPartials = 4094;
@@ -217,32 +216,64 @@ __device__ __forceinline__ double coherent_f64(const double *p) {         // oth
     return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// A slot holds its partial's bit pattern PLUS ONE: 0, what a slot holds when nobody has written it, then stands for "not here yet" -- no sum of
+// angles or norms is the NaN 0xFFFF...F -- and the workgroup that sums the slots can tell a partial that has not arrived from a partial of 0.0.
+__device__ __forceinline__ unsigned long long slot_encode(double v) { return static_cast<unsigned long long>(__double_as_longlong(v)) + 1ull; }
+__device__ __forceinline__ double slot_decode(unsigned long long s) { return __longlong_as_double(static_cast<long long>(s - 1ull)); }
+__device__ __forceinline__ void slot_publish(ReduceWs *ws, unsigned slot, double v) {           // performed at the memory side (agent scope), not waited for
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&ws->part[slot]), slot_encode(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr unsigned kTicketFlag = 0x10000u;         // a workgroup whose rows raised the flag draws its ticket with this on top (counts stay below 65 536)
+#ifndef SO3_SLOT_POLLS
+#define SO3_SLOT_POLLS 200000                      // ~0.1 s of polling one slot before the sum is declared lost (NaN): a store issued in front of a ticket arrives within microseconds
+#endif
+
 // Called by ALL threads of a workgroup at the end of the kernel; wg_total / wg_flag are thread 0's.  `expected` = how many
 // workgroups take tickets in this launch (0: publish only -- a remainder kernel whose partials the following launch collects),
 // `npart` = slots to sum.  write_result(total, any_flag) runs on thread 0 of the last workgroup.
+// Round 6: ONE round trip to memory per workgroup instead of two.  Rounds 3-5 added the partial to its slot with a RETURNING atomic, waited for
+// it (so that it had been performed), and only then drew the ticket -- two dependent memory-side operations of ~1 us each behind every
+// workgroup's last row, and a third (the slots' loads) behind the last one.  Now the partial is a plain agent-scope store that nobody waits for
+// and the slots synchronise themselves: the summing workgroup polls a slot that still reads "not here yet" (rare: the store was issued in front
+// of the ticket it has just seen).  The flag rides on the ticket.  Same slots, same order of summation, same bits from call to call.
 template <int BLOCK, class F>
 __device__ __forceinline__ void ticket_finish(ReduceWs *ws, unsigned slot, unsigned expected, unsigned npart, double wg_total, bool wg_flag,
                                               F &&write_result) {
     __shared__ int is_last;
+    __shared__ unsigned ticket_flags;
+    __shared__ int lost;
     __shared__ double fin[BLOCK / 64];
     if (threadIdx.x == 0) {
-        // Everything that crosses workgroups here is an agent-scope atomic (performed at the memory side, past the XCDs'
-        // L2s) or a coherent load: no release fence -- a __threadfence() per workgroup writes back the XCD's whole L2, i.e.
-        // the kernel's own streamed output, and made K3 50 us instead of 31.  Order: the partial's atomic RETURNS (the
-        // old value comes back, so it has been performed) before the ticket is drawn.
-        fin[0] = atomicAdd(&ws->part[slot], wg_total);        // (the old value is parked in LDS so that the returning form is kept)
-        if (wg_flag) fin[1 % (BLOCK / 64)] = static_cast<double>(atomicOr(&ws->flag, 1));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // Everything that crosses workgroups here is performed at the memory side (agent scope, past the XCDs' L2s) or a coherent load: no
+        // release fence -- a __threadfence() per workgroup writes back the XCD's whole L2, i.e. the kernel's own streamed output, and made K3
+        // 50 us instead of 31.
+        slot_publish(ws, slot, wg_total);
         int last = 0;
-        if (expected != 0) last = atomicAdd(&ws->ticket, 1u) == expected - 1 ? 1 : 0;
+        unsigned flags = wg_flag ? 1u : 0u;
+        if (expected != 0) {
+            const unsigned seen = atomicAdd(&ws->ticket, 1u + (wg_flag ? kTicketFlag : 0u));
+            last = (seen & (kTicketFlag - 1u)) == expected - 1 ? 1 : 0;
+            flags += seen >> 16;
+        } else if (wg_flag) {
+            atomicOr(&ws->flag, 1);                            // publish only: the launch that collects comes later on the stream
+        }
         is_last = last;
+        ticket_flags = flags;
+        lost = 0;
     }
     __syncthreads();
     if (!is_last) return;
     double v = 0.0;
     for (unsigned i = threadIdx.x; i < npart; i += BLOCK) {            // thread t sums slots t, t + BLOCK, ...: a fixed order
-        v += coherent_f64(&ws->part[i]);
-        __hip_atomic_store(&ws->part[i], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long *p = reinterpret_cast<unsigned long long *>(&ws->part[i]);
+        unsigned long long got = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int polls = 0; got == 0ull && polls < SO3_SLOT_POLLS; ++polls) {
+            __builtin_amdgcn_s_sleep(2);
+            got = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (got == 0ull) lost = 1;                                     // (never seen; the result then says so instead of being a wrong number)
+        else v += slot_decode(got);
+        __hip_atomic_store(p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -252,8 +283,9 @@ __device__ __forceinline__ void ticket_finish(ReduceWs *ws, unsigned slot, unsig
         double total = 0.0;
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) total += fin[w];
-        const int flag = __hip_atomic_load(&ws->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        write_result(total, flag != 0);
+        if (lost) total = __longlong_as_double(0x7ff8000000000000ll);
+        const int flag = __hip_atomic_load(&ws->flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // set by a remainder kernel of an earlier launch
+        write_result(total, flag != 0 || ticket_flags != 0u);
         __hip_atomic_store(&ws->flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ws->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

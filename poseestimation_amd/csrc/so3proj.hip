@@ -169,7 +169,7 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /* >= 4 do
 // A remainder kernel's share of a workspace reduction (so3_rows.h): its workgroups fill slots [0, gridDim.x) and take no
 // ticket; the engine launch that follows on the stream sums them with its own.
 __device__ __forceinline__ void publish_partial(so3::ReduceWs *ws, double total, bool flag) {
-    atomicAdd(&ws->part[blockIdx.x], total);
+    so3::slot_publish(ws, blockIdx.x, total);
     if (flag) atomicOr(&ws->flag, 1);
 }
 
