@@ -414,7 +414,7 @@ def secondary_configs(lib, dev):
         mirror(i)
         floor(i)
     # Mirror and floor in ALTERNATING 300-step blocks of one loop.  Either one alone is bimodal with where the autograd engine's device
-    # thread is scheduled (~26 or ~66 us for the floor; docs/history/tools/mirror_bisect.py), and measured in two separate loops the two
+    # thread is scheduled (~26 or ~66 us for the floor; docs/history/tools.tar.gz:tools/mirror_bisect.py), and measured in two separate loops the two
     # landed in their modes independently: rounds 4-5's ratio said which mode each had drawn.  Neighbouring blocks share the mode, so the
     # per-pair DIFFERENCE is what the mirror adds to an empty autograd.Function: median and interquartile range over the pairs.
     mblocks, fblocks, diffs = [], [], []
@@ -696,12 +696,12 @@ def main():
             stream = side
             torch.cuda.synchronize()
             # Untimed replays: graph upload / first-touch effects, and the shader clock.  From idle the chip needs ~20 ms of
-            # load before its clock is up (docs/history/tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
+            # load before its clock is up (docs/history/tools.tar.gz:tools/k1_ramp.py: 20 us per launch falling to 16 over the first 20-30 ms), so a
             # fixed number of warm-up steps would time the ramp, not the kernel.  The timed graph is replayed once (upload,
             # first touch); then a SHORT graph of the same launches (<= 25 steps, so the ramp is sampled every ~0.4 ms) is
             # replayed until its time has stopped falling: the mean of the last 32 replays (10 ms) no longer beats the mean of
             # the 32 before it by 0.3 %, after at least 50 ms and at most 120 ms of load (the ramp is a staircase: one device
-            # sat on a 16.2-us step at 25 ms and reached 14.9 us by 50 ms, docs/history/tools/k1_ramp_fine.py).  (`sustained` below is the same graph after
+            # sat on a 16.2-us step at 25 ms and reached 14.9 us by 50 ms, docs/history/tools.tar.gz:tools/k1_ramp_fine.py).  (`sustained` below is the same graph after
             # 0.6 s: devices differ in whether that is faster -- clock still rising -- or slower -- power limit reached.)
             with torch.cuda.stream(side):
                 graph.replay()

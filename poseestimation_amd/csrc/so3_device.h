@@ -17,7 +17,7 @@
 //
 // One-sided Jacobi works on M itself (never forms M^T M), so small singular values keep their
 // relative accuracy; measured against float64 LAPACK the result is closer than the reference's
-// own float32 LAPACK path (docs/history/tools/proto_jacobi.py, DESIGN.md section "accuracy").
+// own float32 LAPACK path (docs/history/tools.tar.gz:tools/proto_jacobi.py, DESIGN.md section "accuracy").
 // Rank <= 1 input (where the SVD is not unique) takes a rarely-executed divergent branch.
 //
 // The arithmetic is written once, generic over the "scalar" type T:
@@ -69,7 +69,7 @@ __device__ __forceinline__ float med3(float a, float b, float c) { return __buil
 // Sweep schedule: kSweeps fixed cyclic sweeps, then -- if any matrix held by the wave still has a relative
 // off-orthogonality of its (0,1) pair above kResidualTol (a wave-uniform branch) -- one more rotation of that pair,
 // kept by the matrices that failed.  On Gaussian input 99.93 % of the rows are below 1e-5 after three sweeps
-// (docs/history/tools/proto_jacobi.py), so about one wave round in eight takes the branch.
+// (docs/history/tools.tar.gz:tools/proto_jacobi.py), so about one wave round in eight takes the branch.
 constexpr int kSweeps = 3;
 constexpr float kResidualTol2 = 0.5e-10f;  // (0.7e-5)^2 on  gamma_01^2 / (|a_0|^2 |a_1|^2)
 constexpr float kDelta = 1e-18f;    // keeps the rotation well defined when alpha=beta, gamma=0
@@ -501,7 +501,7 @@ template <class T> __device__ __forceinline__ void rotation_from(const SignedSvd
 //      quotient stays within kQuatClose of it keeps q; the others take q again from the adjugate at the quotient, in one rare loop;
 //   5. R(q) -- orthogonal by construction.
 // Per PAIR of matrices (round 5, K1's counters): 340 vector instructions -- about 215 packed, 26 transcendental, 100 plain -- against
-// 569 (394 / 45 / 130) for the three Jacobi sweeps and the frames above (rounds 2-4: 408-431; docs/history/tools/proto/qpath2.py is the numpy float32
+// 569 (394 / 45 / 130) for the three Jacobi sweeps and the frames above (rounds 2-4: 408-431; docs/history/tools.tar.gz:tools/proto/qpath2.py is the numpy float32
 // prototype: 1M Gaussian rows median |dR| 1.4e-7, |dR| gap/s1 <= 1.4e-6 on twenty adversarial families).
 //
 // What the fast path cannot do it says so: a row is HARD when (a) the Rayleigh quotient moved lambda by more than kQuatConv times a lower

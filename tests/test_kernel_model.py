@@ -40,7 +40,7 @@ def _families(n, rng):
     yield "rank two", np.concatenate((a[:, :2], a[:, :1] + a[:, 1:2]), 1)
     yield "scaled 1e18", 1e18 * a
     yield "scaled 1e-18", 1e-18 * a
-    # families that broke prototypes of the quaternion fast path (docs/history/tools/proto): exact double roots at the top of K's spectrum
+    # families that broke prototypes of the quaternion fast path (docs/history/tools.tar.gz:tools/proto): exact double roots at the top of K's spectrum
     # (entries in -1..1: s2 = s3 with det < 0), reflections (a triple root), near-reflections (the SECOND gap small), and scales
     # at the edges of the window in which the fast path works without a prescale
     yield "entries in -1..1", rng.integers(-1, 2, (n, 3, 3)).astype(np.float64)

@@ -87,7 +87,7 @@ void run(const char *what, float **in, float **out, unsigned long long *stamps_d
     }
     for (int64_t w = 0; w < nw; ++w) starts.push_back((double)(st6[6 * w] - r0) * 0.01);
     std::sort(starts.begin(), starts.end());
-    {   // per-wave dump for offline analysis (docs/history/tools/wave_csv.py, phase_csv.py)
+    {   // per-wave dump for offline analysis (docs/history/tools.tar.gz:tools/wave_csv.py, phase_csv.py)
         char name[128]; snprintf(name, sizeof name, "gpurun_out/k1_waves_%s_npl%d_wps%d_fixed%d.csv", what, NPL, WPS, Op::kFixedRounds);
         FILE *fh = fopen(name, "w");
         if (fh) {
