@@ -417,6 +417,17 @@ def _angle_call_f64(r1, r2, want_rows, want_sum, radians=False, geodesic=False):
     return rows, sc, flag
 
 
+_WARNED = set()
+
+
+def _warn_once(key: str, message: str) -> None:
+    """One warning per process and key: a metric that silently drops a gradient is how a training run goes wrong without an error."""
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+
+
 def _wants_grad(*ts) -> bool:
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
 
@@ -521,6 +532,9 @@ def angle_error_sum_count(t_R1: torch.Tensor, t_R2: torch.Tensor, check: bool = 
 
     This pair is what one all-reduce sums across GPUs (poseestimation_amd.distributed); the
     per-row vector is never materialised."""
+    if _wants_grad(t_R1, t_R2):
+        _warn_once("angle_error_sum_count", "angle_error_sum_count is an evaluation call: the (sum, count) pair carries no gradient although an "
+                                            "argument requires grad.  angle_error(...).sum() is the differentiable spelling.")
     _, sc, flag = (_angle_call_f64 if _is_f64(t_R1, t_R2) else _angle_call)(t_R1, t_R2, False, True)
     if check and int(flag.item()) != 0:
         raise ValueError(_RANGE_MSG)
@@ -546,6 +560,10 @@ def head_angle_error(x: torch.Tensor, R_true: torch.Tensor, reduce: str = "none"
     if reduce not in ("none", "mean", "sum_count"):
         raise ValueError("reduce must be 'none', 'mean' or 'sum_count'")
     dev = _require_device(x, R_true)
+    if _wants_grad(x, R_true):
+        _warn_once("head_angle_error",
+                   "head_angle_error is an evaluation call: its result carries no gradient although an argument requires grad.  "
+                   "angle_error(symmetric_orthogonalization(x), R_true) and geodesic(...) are the differentiable spellings.")
     m = _head_input(x.detach())
     if m.dtype != torch.float32:
         m = m.float()

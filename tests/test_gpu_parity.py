@@ -776,6 +776,19 @@ def test_metric_gradients_on_large_ragged_batches_and_views(rr):
     with torch.no_grad():
         assert rr.geodesic(a, b).grad_fn is None and not rr.angle_error(a, b).requires_grad
     assert not rr.geodesic(big_a[:n], big_b[:n]).requires_grad
+    # the build's own fused evaluation calls are metrics only -- and say so ONCE when an argument requires grad, instead of dropping it silently
+    rr._WARNED.clear()
+    xq = torch.randn(256, 9, device=DEV, requires_grad=True)
+    with pytest.warns(RuntimeWarning, match="evaluation call"):
+        out = rr.head_angle_error(xq, big_b[:256].reshape(256, 3, 3))
+    assert not out.requires_grad
+    with pytest.warns(RuntimeWarning, match="angle_error\\(...\\).sum\\(\\)"):
+        rr.angle_error_sum_count(a[:256], b[:256])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                    # once per process: the second call is quiet; without grad it never speaks
+        rr.head_angle_error(xq, big_b[:256].reshape(256, 3, 3))
+        rr.head_angle_error(xq.detach(), big_b[:256].reshape(256, 3, 3))
     e = torch.zeros(0, 3, 3, device=DEV, requires_grad=True)
     rr.geodesic(e, torch.zeros(0, 3, 3, device=DEV), "sum").backward()
     assert e.grad.shape == (0, 3, 3)
