@@ -52,7 +52,7 @@ def test_bench_json_contract(mode):
     # one rank: its device, its own clocks -- the same fields an 8-rank line carries per rank
     (seen,) = d["devices_seen"]
     assert seen["rank"] == 0 and seen["device_index"] == 0 and seen["arch"].startswith("gfx950") and seen["cus"] >= 64
-    assert abs(seen["ms_per_step_events"] - d["ms_per_step_events"]) < 1e-9 and d["world_size_seen"] == 1
+    assert abs(seen["ms_per_step_events"] - d["ms_per_step_events"]) < 1e-6 * seen["ms_per_step_events"] and d["world_size_seen"] == 1      # (two reads of one pair of events)
     assert d["secondary"]["config1_head_b512_no_grad"]["us_per_call_host_clock"] > 0
     ov = d["secondary"]["config2_independent_batches_on_several_streams"]          # independent batches on 1 / 2 / 3 streams: throughput, labelled as such
     assert "error" not in ov and set(ov["us_per_launch_by_streams"]) == {"1", "2", "3"}
@@ -139,10 +139,10 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert [r["rank"] for r in d["devices_seen"]] == [0, 1] and all(r["device_index"] == 0 and r["arch"].startswith("gfx950") and r["cus"] >= 64
                                                                      for r in d["devices_seen"])
     sp = d["ms_per_step_events_by_rank"]
-    assert 0 < sp["min"] <= sp["max"] and abs(sp["max"] - d["ms_per_step_events"]) < 1e-9 and {sp["rank_of_min"], sp["rank_of_max"]} <= {0, 1}
+    assert 0 < sp["min"] <= sp["max"] and abs(sp["max"] - d["ms_per_step_events"]) < 1e-6 * sp["max"] and {sp["rank_of_min"], sp["rank_of_max"]} <= {0, 1}
     assert d["world_size_seen"] == 2 and d["allreduce_backend"] == "gloo" and d["collective_library"]["backend_in_use"] == "gloo" and "rccl_version" in d["collective_library"]
     assert [r["rank"] for r in c5["ranks"]] == [0, 1] and all(r["allreduce_us"] > 0 and r["ms_per_step_events"] > 0 for r in c5["ranks"])
-    assert abs(c5["allreduce_us_by_rank"]["max"] - c5["allreduce_us"]) < 1e-6
+    assert abs(c5["allreduce_us_by_rank"]["max"] - c5["allreduce_us"]) < 1e-6 * c5["allreduce_us"]
 
 
 def test_a_rank_without_a_device_stops_the_job_with_one_line():
